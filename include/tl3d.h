@@ -1,0 +1,184 @@
+/*
+ * tl3d.h -- C-ABI of the MI355X depth-fusion back end (libtl3d.so).
+ *
+ * The reference (kamalnath26/textureless-3d-reconstruction) is pure Python and has no FFI of its
+ * own; the seam this library sits under is the Python method surface of its dense back end
+ * (SURVEY.md section 8b).  Each entry point below names the reference code it replaces
+ * (file:line relative to the reference checkout).  INTEGRATION.md shows the ctypes stubs a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns int: 0 = TL3D_OK, negative = error; no exception crosses the boundary;
+ *     tl3d_last_error() returns a thread-local message for the last failing call.
+ *   - the caller owns every host buffer it passes in or out for the duration of the call; the library
+ *     owns all device memory inside a tl3d_ctx.  "hd" pointers may be host OR device pointers
+ *     (copied with hipMemcpyDefault).
+ *   - arrays are C-contiguous row-major: depth [H][W], bgr [H][W][3], poses fp64 row-major.
+ *   - a pose is world->camera  X_cam = R X_world + t  (depth_to_reconstruction.py:373-376, 543-546).
+ *   - one tl3d_ctx per GPU per process; a ctx is not thread-safe; calls enqueue on the ctx's HIP
+ *     stream and return, every call with a host output blocks until that output is ready.
+ */
+#ifndef TL3D_H
+#define TL3D_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TL3D_ABI_VERSION 1
+
+/* error codes */
+#define TL3D_OK 0
+#define TL3D_E_INVALID (-1)     /* bad argument / shape / slot                       */
+#define TL3D_E_HIP (-2)         /* a HIP runtime call failed                         */
+#define TL3D_E_NOMEM (-3)       /* device allocation failed                          */
+#define TL3D_E_CAPACITY (-4)    /* output buffer too small; *out_n holds the need    */
+#define TL3D_E_STATE (-5)       /* call not valid in this state (channel disabled..) */
+#define TL3D_E_NODEVICE (-6)    /* no usable GPU                                     */
+
+/* grid channels */
+#define TL3D_CH_TSDF 1u         /* {int32 sum of quantised tsdf, int32 weight}         8 B/voxel  */
+#define TL3D_CH_CENTROID 2u     /* {sx|sy<<32, sz|n<<32, sr|sg<<32, sb} u64 x4         32 B/voxel */
+
+/* fixed-point formats of the accumulators (exact, order-free sums => bit-identical multi-GPU merge) */
+#define TL3D_TSDF_QSCALE 32767          /* tsdf in [-1,1] -> rint(tsdf * 32767)                  */
+#define TL3D_CENTROID_FRAC_BITS 12      /* in-voxel offset in units of voxel/4096                */
+#define TL3D_BRICK 8                    /* grid is stored brick-major, 8x8x8 voxels per brick    */
+
+/* depth upload kinds (depth_to_reconstruction.py:80-97) */
+#define TL3D_DEPTH_F32_M 0      /* float32 metres (or relative units), as np.load().astype(f32) */
+#define TL3D_DEPTH_U16_MM 1     /* uint16 millimetres; converted on device as f32(u16)/1000.0f  */
+
+/* flags of tl3d_backproject / tl3d_accumulate_centroid */
+#define TL3D_F_SCALE_F64 1u     /* depth*scale and the range compares run in fp64 (numpy-2 promotion when
+                                   `scale` is an np.float64: depth_to_reconstruction.py:356 with :323) */
+#define TL3D_F_NO_POSE 2u       /* pose=None: points stay in the camera frame (D2R:377-378)            */
+
+/* extraction modes */
+#define TL3D_EXTRACT_CENTROID 0 /* one point per occupied voxel = centroid (Open3D voxel_down_sample)   */
+#define TL3D_EXTRACT_TSDF 1     /* zero crossings of the TSDF along +x,+y,+z edges                      */
+
+typedef struct tl3d_ctx tl3d_ctx;
+
+/* Replaces ReconstructionConfig (depth_to_reconstruction.py:45-73) and CameraIntrinsics
+ * (depth_enhanced_reconstruction.py:57-80) for the device path, plus the grid geometry. */
+typedef struct tl3d_config {
+    int32_t abi_version;        /* = TL3D_ABI_VERSION                                              */
+    int32_t width, height;      /* W, H of every frame of this ctx                                 */
+    double fx, fy, cx, cy;      /* intrinsics; pixel centres sit on integer (u,v) (D2R:291-293)    */
+    double min_depth, max_depth;/* strict validity range (D2R:359-361); 0.1/50 D2R, 0.1/100 DER    */
+    int32_t n_slots;            /* resident frame slots                                            */
+    uint32_t channels;          /* TL3D_CH_* bit mask; 0 = no grid (back-projection / ICP only)    */
+    int32_t nx, ny, nz;         /* voxels per axis, multiples of TL3D_BRICK                        */
+    double origin[3];           /* world position of the min corner of voxel (0,0,0)               */
+    double voxel_size;          /* metres (D2R:64: 0.005)                                          */
+    double sdf_trunc;           /* metres                                                          */
+    void *ext_tsdf;             /* optional caller-owned device memory for the grids (e.g. a torch */
+    void *ext_centroid;         /*   tensor's data_ptr, so torch.distributed can all-reduce it)    */
+    void *stream;               /* optional hipStream_t to enqueue on; NULL = library-owned stream */
+} tl3d_config;
+
+/* Result of an ICP run (device solve, read back once at the end). */
+typedef struct tl3d_icp_result {
+    double T[16];               /* src-camera -> tgt-camera, row-major 4x4                         */
+    double fitness;             /* correspondences / valid source samples, at T                    */
+    double rmse;                /* sqrt(mean r^2) over correspondences, at T                       */
+    int64_t n_corr;             /* correspondences at T                                            */
+    int64_t n_src;              /* valid source samples                                            */
+    int32_t iters_run;          /* iterations that produced an update                              */
+    int32_t status;             /* 0 ok, 1 converged early, 2 singular system (T from last good)   */
+} tl3d_icp_result;
+
+typedef struct tl3d_icp_params {
+    int32_t iters;              /* maximum Gauss-Newton iterations                                 */
+    int32_t stride;             /* source pixel stride                                             */
+    double max_dist;            /* correspondence gate |p-q| (metres)                              */
+    double damping;             /* Levenberg factor: A += damping * trace(A)/6 * I                 */
+    double eps;                 /* stop when |update|_inf < eps                                    */
+} tl3d_icp_params;
+
+/* per-launch statistics of the fusion kernels, for roofline accounting */
+typedef struct tl3d_stats {
+    uint64_t tsdf_launches;
+    uint64_t tsdf_records_read;      /* voxel records loaded by tl3d_integrate kernels (counting mode) */
+    uint64_t tsdf_records_written;
+    uint64_t tsdf_bricks_visited;    /* bricks that passed culling                                      */
+    uint64_t centroid_launches;
+    uint64_t centroid_points;        /* points accumulated                                              */
+    uint64_t centroid_dropped;       /* valid points that fell outside the grid                         */
+    double tsdf_kernel_ms;           /* summed hipEvent time of the integrate kernels (profile mode)    */
+    uint64_t tsdf_kernel_timed;      /* launches contributing to tsdf_kernel_ms                         */
+} tl3d_stats;
+
+const char *tl3d_last_error(void);
+int tl3d_version(void);
+int tl3d_device_count(int *n);
+
+/* lifetime */
+int tl3d_create(const tl3d_config *cfg, int device, tl3d_ctx **out);
+int tl3d_destroy(tl3d_ctx *ctx);
+int tl3d_sync(tl3d_ctx *ctx);
+
+/* a2: frames.  Replaces DepthImageLoader.load_depth's dtype handling (D2R:80-97) and the in-RAM frame
+ * lists self.images/self.depths (D2R:434-437).  bgr may be NULL (colour (0,0,0)). */
+int tl3d_upload_frame(tl3d_ctx *ctx, int slot, const void *depth_hd, int depth_kind, const uint8_t *bgr_hd);
+int tl3d_download_depth(tl3d_ctx *ctx, int slot, float *depth_out_hd);
+
+/* a3+a4/a5: DenseReconstructor.depth_to_pointcloud (depth_to_reconstruction.py:328-384) and
+ * DensePointCloudGenerator.depth_to_pointcloud (depth_enhanced_reconstruction.py:554-613).
+ * Writes the surviving points in row-major pixel order.  cap = capacity in points; on
+ * TL3D_E_CAPACITY *out_n is the required count.  out_* may be host or device pointers. */
+int tl3d_backproject(tl3d_ctx *ctx, int slot, const double R[9], const double t[3], double scale,
+                     uint32_t flags, int subsample, double min_depth, double max_depth,
+                     float *out_xyz_hd, uint8_t *out_rgb_hd, int64_t cap, int64_t *out_n);
+
+/* a7 (fusion half): accumulate the same points straight into the centroid channel, no point list
+ * (replaces np.vstack + Open3D voxel_down_sample's hash-map insert, D2R:401-410). */
+int tl3d_accumulate_centroid(tl3d_ctx *ctx, int slot, const double R[9], const double t[3], double scale,
+                             uint32_t flags, int subsample, double min_depth, double max_depth);
+/* same, from an explicit point list (merge_pointclouds' call shape, D2R:386-420) */
+int tl3d_accumulate_points(tl3d_ctx *ctx, const float *xyz_hd, const uint8_t *rgb_hd, int64_t n);
+/* min/max bound of a point list (Open3D's voxel origin = min_bound - voxel/2) */
+int tl3d_points_bounds(tl3d_ctx *ctx, const float *xyz_hd, int64_t n, double out_min[3], double out_max[3]);
+
+/* a11: TSDF integration of one frame (no reference code; convention in DESIGN.md). */
+int tl3d_integrate(tl3d_ctx *ctx, int slot, const double R[9], const double t[3], double scale);
+
+/* a10: vertex/normal map + point-to-plane ICP (no reference code; replaces the SIFT/essential-matrix
+ * pose front end D2R:144-215 as the pose source, output in the convention of D2R:618-620). */
+int tl3d_build_normals(tl3d_ctx *ctx, int slot, double scale, double depth_jump);
+int tl3d_download_normals(tl3d_ctx *ctx, int slot, float *nmap_out_hd /* [H][W][4] */);
+int tl3d_icp_p2plane(tl3d_ctx *ctx, int slot_src, double scale_src, int slot_tgt, const double T_init[16],
+                     const tl3d_icp_params *prm, tl3d_icp_result *out);
+
+/* grids */
+int tl3d_grid_reset(tl3d_ctx *ctx);
+int tl3d_grid_device_ptr(tl3d_ctx *ctx, uint32_t channel, void **ptr, size_t *bytes);
+int tl3d_grid_download(tl3d_ctx *ctx, uint32_t channel, void *out_hd, size_t bytes);
+int tl3d_grid_upload(tl3d_ctx *ctx, uint32_t channel, const void *in_hd, size_t bytes);
+int tl3d_grid_add(tl3d_ctx *ctx, uint32_t channel, const void *other_hd, size_t bytes);   /* grid += other (merge) */
+
+/* a7 (read-back half) + N4: fused grid -> point list. min_count: centroid occupancy threshold;
+ * tsdf gate (centroid mode, only if the TSDF channel exists and min_weight > 0): keep voxels with
+ * weight >= min_weight and |mean tsdf| <= max_abs_tsdf. */
+int tl3d_extract(tl3d_ctx *ctx, int mode, int min_count, int min_weight, double max_abs_tsdf,
+                 float *out_xyz_hd, uint8_t *out_rgb_hd, int64_t cap, int64_t *out_n);
+
+/* f1: statistical outlier removal on a point list (Open3D remove_statistical_outlier, D2R:412-415) */
+int tl3d_statistical_outlier(tl3d_ctx *ctx, const float *xyz_hd, int64_t n, int nb_neighbors, double std_ratio,
+                             double cell_size, uint8_t *keep_out_hd, int64_t *out_kept);
+
+/* measurement */
+int tl3d_set_profile(tl3d_ctx *ctx, int count_records, int time_kernels);
+int tl3d_get_stats(tl3d_ctx *ctx, tl3d_stats *out);
+int tl3d_reset_stats(tl3d_ctx *ctx);
+int tl3d_event_record(tl3d_ctx *ctx, int which /* 0 or 1 */);
+int tl3d_event_elapsed_ms(tl3d_ctx *ctx, float *ms);      /* time between event 0 and event 1, blocks */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TL3D_H */

@@ -1,0 +1,542 @@
+/*
+ * tl3d_oracle.c -- CPU ORACLE (plain C), TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this file's
+ * library; the product path never does.  Build: oracle/Makefile (gcc -O2 -ffp-contract=off -mfma).
+ *
+ * What it restates, and how each part is pinned:
+ *   orc_backproject / orc_centroid_*   the reference's per-pixel back-projection
+ *        (depth_to_reconstruction.py:328-384, depth_enhanced_reconstruction.py:554-613) in fp64, feeding
+ *        voxel-centroid accumulators with the semantics of Open3D voxel_down_sample as called at
+ *        depth_to_reconstruction.py:406-410.  The back-projection is PINNED through oracle/ref_numpy.py,
+ *        which is bit-checked against vectors captured from the reference (tests/golden/); the voxel
+ *        centroid is checked against ref_numpy.voxel_centroid_open3d (Open3D itself: parity unpinned,
+ *        absent third-party dependency, see ref_numpy.py header).
+ *   orc_tsdf_integrate, orc_normals, orc_icp, orc_extract (TSDF mode)
+ *        PARITY UNPINNED at the reference: the reference contains no ICP and no TSDF (SURVEY.md
+ *        section 0.2, rows a10/a11).  These functions DEFINE the convention (DESIGN.md "Arithmetic
+ *        contracts"); they are pinned only by analytic known-answer scenes in tests/.
+ *
+ * Arithmetic contract shared with the HIP kernels (bit-exact integer grids):
+ *   - f32 per-voxel / per-pixel math with explicit fmaf() where written, no other contraction
+ *     (-ffp-contract=off here, -ffp-contract=off in the HIP build), IEEE division and sqrt;
+ *   - accumulators are integers (order-free); ICP normal equations accumulate fp64 products of f32.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define QSCALE 32767.0f
+#define FRAC_BITS 12
+#define FRAC_ONE 4096.0
+
+typedef struct orc_cfg {
+    int32_t width, height;
+    double fx, fy, cx, cy;
+    double min_depth, max_depth;
+    int32_t nx, ny, nz;
+    double origin[3];
+    double voxel_size;
+    double sdf_trunc;
+} orc_cfg;
+
+typedef struct orc_icp_params {
+    int32_t iters, stride;
+    double max_dist, damping, eps;
+} orc_icp_params;
+
+typedef struct orc_icp_result {
+    double T[16];
+    double fitness, rmse;
+    int64_t n_corr, n_src;
+    int32_t iters_run, status;
+} orc_icp_result;
+
+int orc_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* brick-major record index: 8x8x8 voxels per brick, x fastest inside a brick and across bricks */
+static inline size_t vox_index(int i, int j, int k, int nbx, int nby) {
+    size_t b = ((size_t)(k >> 3) * (size_t)nby + (size_t)(j >> 3)) * (size_t)nbx + (size_t)(i >> 3);
+    return (b << 9) + (size_t)(((k & 7) << 6) | ((j & 7) << 3) | (i & 7));
+}
+
+size_t orc_vox_index(const orc_cfg *c, int i, int j, int k) { return vox_index(i, j, k, c->nx >> 3, c->ny >> 3); }
+
+/* ------------------------------------------------------------------------------------------------
+ * a11  TSDF integration of one frame.  Convention (Curless-Levoy, projective signed distance along z):
+ *   voxel centre -> camera -> nearest pixel; sdf = d - z_c; update iff sdf >= -trunc;
+ *   tsdf = min(1, sdf/trunc); grid.sum += rint(tsdf*32767); grid.w += 1.
+ * grid: int32 [nvox][2] brick-major.
+ * ------------------------------------------------------------------------------------------------ */
+void orc_tsdf_integrate(const orc_cfg *c, const float *depth, const double R[9], const double t[3],
+                        double scale, int32_t *grid) {
+    const int W = c->width, H = c->height;
+    const int nbx = c->nx >> 3, nby = c->ny >> 3;
+    const float fx = (float)c->fx, fy = (float)c->fy, cx = (float)c->cx, cy = (float)c->cy;
+    const float ox = (float)c->origin[0], oy = (float)c->origin[1], oz = (float)c->origin[2];
+    const float vs = (float)c->voxel_size;
+    const float trunc = (float)c->sdf_trunc, inv_trunc = 1.0f / trunc;
+    const float mind = (float)c->min_depth, maxd = (float)c->max_depth, sc = (float)scale;
+    float r[9], tt[3];
+    for (int i = 0; i < 9; ++i) r[i] = (float)R[i];
+    for (int i = 0; i < 3; ++i) tt[i] = (float)t[i];
+    const float wlim = (float)W - 0.5f, hlim = (float)H - 0.5f;
+#pragma omp parallel for schedule(static)
+    for (int k = 0; k < c->nz; ++k) {
+        const float pz = fmaf((float)k + 0.5f, vs, oz);
+        for (int j = 0; j < c->ny; ++j) {
+            const float py = fmaf((float)j + 0.5f, vs, oy);
+            for (int i = 0; i < c->nx; ++i) {
+                const float px = fmaf((float)i + 0.5f, vs, ox);
+                const float xc = fmaf(r[0], px, fmaf(r[1], py, fmaf(r[2], pz, tt[0])));
+                const float yc = fmaf(r[3], px, fmaf(r[4], py, fmaf(r[5], pz, tt[1])));
+                const float zc = fmaf(r[6], px, fmaf(r[7], py, fmaf(r[8], pz, tt[2])));
+                if (!(zc > 0.0f)) continue;
+                const float inv = 1.0f / zc;
+                const float uf = fmaf(fx * xc, inv, cx);
+                const float vf = fmaf(fy * yc, inv, cy);
+                if (!(uf >= -0.5f && uf < wlim && vf >= -0.5f && vf < hlim)) continue;
+                int u = (int)floorf(uf + 0.5f), v = (int)floorf(vf + 0.5f);
+                if (u > W - 1) u = W - 1;
+                if (v > H - 1) v = H - 1;
+                const float d = depth[(size_t)v * W + u] * sc;
+                if (!(d > mind && d < maxd)) continue;
+                const float sdf = d - zc;
+                if (!(sdf >= -trunc)) continue;
+                const float tsdf = fminf(1.0f, sdf * inv_trunc);
+                const int q = (int)rintf(tsdf * QSCALE);
+                int32_t *rec = grid + 2 * vox_index(i, j, k, nbx, nby);
+                rec[0] += q;
+                rec[1] += 1;
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * a4/a5 in C (fp64 intermediates exactly as the reference: factors (u-cx)/fx in fp64, times z, R^T P - R^T t,
+ * cast to f32).  Returns 1 and fills p[3] if the pixel survives the mask, else 0.
+ * flags bit0: depth*scale and the compares in fp64 (np.float64 scale), else f32.  bit1: no pose.
+ * ------------------------------------------------------------------------------------------------ */
+static inline int bp_pixel(const orc_cfg *c, const float *depth, int u, int v, const double R[9], const double ct[3],
+                           double scale, uint32_t flags, double min_d, double max_d, float p[3]) {
+    const float d32 = depth[(size_t)v * c->width + u];
+    double z;
+    if (flags & 1u) {
+        const double d = (double)d32 * scale;
+        if (!(d > min_d && d < max_d && isfinite(d))) return 0;
+        z = d;
+    } else {
+        const float d = d32 * (float)scale;
+        if (!(d > (float)min_d && d < (float)max_d && isfinite(d))) return 0;
+        z = (double)d;
+    }
+    const double x = (((double)u - c->cx) / c->fx) * z;
+    const double y = (((double)v - c->cy) / c->fy) * z;
+    if (flags & 2u) {
+        p[0] = (float)x; p[1] = (float)y; p[2] = (float)z;
+    } else {
+        p[0] = (float)(((R[0] * x + R[3] * y) + R[6] * z) - ct[0]);
+        p[1] = (float)(((R[1] * x + R[4] * y) + R[7] * z) - ct[1]);
+        p[2] = (float)(((R[2] * x + R[5] * y) + R[8] * z) - ct[2]);
+    }
+    return 1;
+}
+
+static inline void rt_t(const double R[9], const double t[3], double ct[3]) {
+    for (int i = 0; i < 3; ++i) ct[i] = (R[0 + i] * t[0] + R[3 + i] * t[1]) + R[6 + i] * t[2];   /* (R^T t)_i */
+}
+
+int64_t orc_backproject(const orc_cfg *c, const float *depth, const uint8_t *bgr, const double R[9], const double t[3],
+                        double scale, uint32_t flags, int subsample, double min_d, double max_d,
+                        float *out_xyz, uint8_t *out_rgb) {
+    double ct[3] = {0, 0, 0};
+    if (!(flags & 2u)) rt_t(R, t, ct);
+    int64_t n = 0;
+    for (int v = 0; v < c->height; v += subsample)
+        for (int u = 0; u < c->width; u += subsample) {
+            float p[3];
+            if (!bp_pixel(c, depth, u, v, R, ct, scale, flags, min_d, max_d, p)) continue;
+            out_xyz[3 * n + 0] = p[0]; out_xyz[3 * n + 1] = p[1]; out_xyz[3 * n + 2] = p[2];
+            const uint8_t *px = bgr ? bgr + 3 * ((size_t)v * c->width + u) : NULL;
+            out_rgb[3 * n + 0] = px ? px[2] : 0; out_rgb[3 * n + 1] = px ? px[1] : 0; out_rgb[3 * n + 2] = px ? px[0] : 0;
+            ++n;
+        }
+    return n;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * a7 fusion half: voxel-centroid accumulators.  index = floor((p - origin)/voxel) in fp64 from the f32
+ * point (Open3D VoxelDownSample); in-voxel offset quantised to voxel/4096 (floor).
+ * record: u64[4] = { sx | sy<<32, sz | n<<32, sr | sg<<32, sb }.
+ * ------------------------------------------------------------------------------------------------ */
+static inline int centroid_add(const orc_cfg *c, const float p[3], const uint8_t rgb[3], uint64_t *grid) {
+    int idx[3];
+    uint64_t q[3];
+    const int dims[3] = {c->nx, c->ny, c->nz};
+    for (int a = 0; a < 3; ++a) {
+        const double rc = ((double)p[a] - c->origin[a]) / c->voxel_size;
+        const double fl = floor(rc);
+        if (!(fl >= 0.0 && fl < (double)dims[a])) return 0;
+        idx[a] = (int)fl;
+        int qq = (int)((rc - fl) * FRAC_ONE);
+        if (qq > (1 << FRAC_BITS) - 1) qq = (1 << FRAC_BITS) - 1;
+        q[a] = (uint64_t)qq;
+    }
+    uint64_t *rec = grid + 4 * vox_index(idx[0], idx[1], idx[2], c->nx >> 3, c->ny >> 3);
+    rec[0] += q[0] | (q[1] << 32);
+    rec[1] += q[2] | (1ull << 32);
+    rec[2] += (uint64_t)rgb[0] | ((uint64_t)rgb[1] << 32);
+    rec[3] += (uint64_t)rgb[2];
+    return 1;
+}
+
+void orc_centroid_accumulate(const orc_cfg *c, const float *depth, const uint8_t *bgr, const double R[9],
+                             const double t[3], double scale, uint32_t flags, int subsample, double min_d,
+                             double max_d, uint64_t *grid, uint64_t *n_acc, uint64_t *n_drop) {
+    double ct[3] = {0, 0, 0};
+    if (!(flags & 2u)) rt_t(R, t, ct);
+    uint64_t acc = 0, drop = 0;
+    for (int v = 0; v < c->height; v += subsample)
+        for (int u = 0; u < c->width; u += subsample) {
+            float p[3];
+            if (!bp_pixel(c, depth, u, v, R, ct, scale, flags, min_d, max_d, p)) continue;
+            uint8_t rgb[3] = {0, 0, 0};
+            if (bgr) {
+                const uint8_t *px = bgr + 3 * ((size_t)v * c->width + u);
+                rgb[0] = px[2]; rgb[1] = px[1]; rgb[2] = px[0];
+            }
+            if (centroid_add(c, p, rgb, grid)) ++acc; else ++drop;
+        }
+    if (n_acc) *n_acc += acc;
+    if (n_drop) *n_drop += drop;
+}
+
+void orc_centroid_points(const orc_cfg *c, const float *xyz, const uint8_t *rgb, int64_t n, uint64_t *grid,
+                         uint64_t *n_acc, uint64_t *n_drop) {
+    uint64_t acc = 0, drop = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (centroid_add(c, xyz + 3 * i, rgb + 3 * i, grid)) ++acc; else ++drop;
+    }
+    if (n_acc) *n_acc += acc;
+    if (n_drop) *n_drop += drop;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * N4  extraction.  Output order: ascending record index (brick-major).
+ * ------------------------------------------------------------------------------------------------ */
+static inline void rec_coords(size_t idx, int nbx, int nby, int *i, int *j, int *k) {
+    const size_t b = idx >> 9;
+    const int l = (int)(idx & 511);
+    const int bx = (int)(b % (size_t)nbx), by = (int)((b / (size_t)nbx) % (size_t)nby), bz = (int)(b / ((size_t)nbx * (size_t)nby));
+    *i = (bx << 3) | (l & 7);
+    *j = (by << 3) | ((l >> 3) & 7);
+    *k = (bz << 3) | (l >> 6);
+}
+
+int64_t orc_extract(const orc_cfg *c, int mode, int min_count, int min_weight, double max_abs_tsdf,
+                    const int32_t *tsdf, const uint64_t *cen, float *out_xyz, uint8_t *out_rgb, int64_t cap) {
+    const int nbx = c->nx >> 3, nby = c->ny >> 3;
+    const size_t nvox = (size_t)c->nx * c->ny * c->nz;
+    const int dims[3] = {c->nx, c->ny, c->nz};
+    int64_t n_out = 0;
+    if (min_count < 1) min_count = 1;
+    for (size_t idx = 0; idx < nvox; ++idx) {
+        int ijk[3];
+        rec_coords(idx, nbx, nby, &ijk[0], &ijk[1], &ijk[2]);
+        if (mode == 0) {
+            if (!cen) return -1;
+            const uint64_t *rec = cen + 4 * idx;
+            const uint64_t n = rec[1] >> 32;
+            if (n < (uint64_t)min_count) continue;
+            if (tsdf && min_weight > 0) {
+                const int32_t w = tsdf[2 * idx + 1];
+                if (w < min_weight) continue;
+                const double mean = (double)tsdf[2 * idx] / ((double)w * 32767.0);
+                if (!(fabs(mean) <= max_abs_tsdf)) continue;
+            }
+            if (n_out < cap) {
+                const uint64_t s[3] = {rec[0] & 0xffffffffull, rec[0] >> 32, rec[1] & 0xffffffffull};
+                for (int a = 0; a < 3; ++a) {
+                    const double f = ((double)s[a] + 0.5 * (double)n) / ((double)n * FRAC_ONE);
+                    out_xyz[3 * n_out + a] = (float)(c->origin[a] + ((double)ijk[a] + f) * c->voxel_size);
+                }
+                out_rgb[3 * n_out + 0] = (uint8_t)((rec[2] & 0xffffffffull) / n);
+                out_rgb[3 * n_out + 1] = (uint8_t)((rec[2] >> 32) / n);
+                out_rgb[3 * n_out + 2] = (uint8_t)((rec[3] & 0xffffffffull) / n);
+            }
+            ++n_out;
+        } else {
+            if (!tsdf) return -1;
+            const int32_t wa = tsdf[2 * idx + 1];
+            const int mw = min_weight < 1 ? 1 : min_weight;
+            if (wa < mw) continue;
+            const double ta = (double)tsdf[2 * idx] / ((double)wa * 32767.0);
+            if (!(fabs(ta) < 0.98)) continue;
+            for (int e = 0; e < 3; ++e) {
+                int nb[3] = {ijk[0], ijk[1], ijk[2]};
+                nb[e] += 1;
+                if (nb[e] >= dims[e]) continue;
+                const size_t jdx = vox_index(nb[0], nb[1], nb[2], nbx, nby);
+                const int32_t wb = tsdf[2 * jdx + 1];
+                if (wb < mw) continue;
+                const double tb = (double)tsdf[2 * jdx] / ((double)wb * 32767.0);
+                if (!(fabs(tb) < 0.98)) continue;
+                if (!(ta * tb < 0.0)) continue;
+                if (n_out < cap) {
+                    const double r0 = fabs(ta), r1 = fabs(tb);
+                    const double frac = r0 / (r0 + r1);
+                    for (int a = 0; a < 3; ++a) {
+                        const double cc = c->origin[a] + ((double)ijk[a] + 0.5) * c->voxel_size;
+                        out_xyz[3 * n_out + a] = (float)(a == e ? cc + frac * c->voxel_size : cc);
+                    }
+                    uint8_t col[3] = {128, 128, 128};
+                    if (cen) {
+                        const size_t first = (r0 <= r1) ? idx : jdx, second = (r0 <= r1) ? jdx : idx;
+                        const size_t cand[2] = {first, second};
+                        for (int q = 0; q < 2; ++q) {
+                            const uint64_t *rec = cen + 4 * cand[q];
+                            const uint64_t n = rec[1] >> 32;
+                            if (n > 0) {
+                                col[0] = (uint8_t)((rec[2] & 0xffffffffull) / n);
+                                col[1] = (uint8_t)((rec[2] >> 32) / n);
+                                col[2] = (uint8_t)((rec[3] & 0xffffffffull) / n);
+                                break;
+                            }
+                        }
+                    }
+                    out_rgb[3 * n_out + 0] = col[0]; out_rgb[3 * n_out + 1] = col[1]; out_rgb[3 * n_out + 2] = col[2];
+                }
+                ++n_out;
+            }
+        }
+    }
+    return n_out;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * a10  vertex / normal map (f32).  nmap[v][u] = (nx, ny, nz, d); d = 0 marks an invalid pixel.
+ *   V(u,v) = (((float)u - cx)/fx * d, ((float)v - cy)/fy * d, d),  d = depth*scale
+ *   n = normalize( (V(u+1,v) - V(u-1,v)) x (V(u,v+1) - V(u,v-1)) ), flipped to face the camera;
+ *   a pixel is valid iff it and its 4 neighbours are valid and |d_nb - d| <= depth_jump.
+ * ------------------------------------------------------------------------------------------------ */
+static inline int load_vertex(const orc_cfg *c, const float *depth, int u, int v, float sc, float mind, float maxd,
+                              float fx, float fy, float cx, float cy, float p[3]) {
+    const float d = depth[(size_t)v * c->width + u] * sc;
+    if (!(d > mind && d < maxd)) return 0;
+    p[0] = (((float)u - cx) / fx) * d;
+    p[1] = (((float)v - cy) / fy) * d;
+    p[2] = d;
+    return 1;
+}
+
+void orc_normals(const orc_cfg *c, const float *depth, double scale, double depth_jump, float *nmap) {
+    const int W = c->width, H = c->height;
+    const float fx = (float)c->fx, fy = (float)c->fy, cx = (float)c->cx, cy = (float)c->cy;
+    const float mind = (float)c->min_depth, maxd = (float)c->max_depth, sc = (float)scale, jump = (float)depth_jump;
+#pragma omp parallel for schedule(static)
+    for (int v = 0; v < H; ++v)
+        for (int u = 0; u < W; ++u) {
+            float *o = nmap + 4 * ((size_t)v * W + u);
+            o[0] = o[1] = o[2] = o[3] = 0.0f;
+            if (u < 1 || v < 1 || u > W - 2 || v > H - 2) continue;
+            float p[3], l[3], r[3], up[3], dn[3];
+            if (!load_vertex(c, depth, u, v, sc, mind, maxd, fx, fy, cx, cy, p)) continue;
+            if (!load_vertex(c, depth, u - 1, v, sc, mind, maxd, fx, fy, cx, cy, l)) continue;
+            if (!load_vertex(c, depth, u + 1, v, sc, mind, maxd, fx, fy, cx, cy, r)) continue;
+            if (!load_vertex(c, depth, u, v - 1, sc, mind, maxd, fx, fy, cx, cy, up)) continue;
+            if (!load_vertex(c, depth, u, v + 1, sc, mind, maxd, fx, fy, cx, cy, dn)) continue;
+            if (!(fabsf(l[2] - p[2]) <= jump && fabsf(r[2] - p[2]) <= jump && fabsf(up[2] - p[2]) <= jump &&
+                  fabsf(dn[2] - p[2]) <= jump)) continue;
+            const float ax = r[0] - l[0], ay = r[1] - l[1], az = r[2] - l[2];
+            const float bx = dn[0] - up[0], by = dn[1] - up[1], bz = dn[2] - up[2];
+            float nx = fmaf(ay, bz, -(az * by));
+            float ny = fmaf(az, bx, -(ax * bz));
+            float nz = fmaf(ax, by, -(ay * bx));
+            const float len2 = fmaf(nx, nx, fmaf(ny, ny, nz * nz));
+            if (!(len2 > 1e-30f)) continue;
+            const float inv = 1.0f / sqrtf(len2);
+            nx *= inv; ny *= inv; nz *= inv;
+            const float dotv = fmaf(nx, p[0], fmaf(ny, p[1], nz * p[2]));
+            if (dotv > 0.0f) { nx = -nx; ny = -ny; nz = -nz; }
+            o[0] = nx; o[1] = ny; o[2] = nz; o[3] = p[2];
+        }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * a10  point-to-plane ICP with projective association.  T maps source-camera to target-camera coordinates.
+ * Per iteration: for every source pixel on the stride grid with valid depth
+ *    p = R p_s + t (f32, R,t = (float)T); project to the target image (nearest pixel); (n, d_t) = nmap_t there;
+ *    q = back-projected target vertex; gate |p-q|^2 <= max_dist^2; r = (p-q).n; J = [p x n, n];
+ *    A += J J^T, b += J r, e += r^2  (fp64 sums of fp64 products of the f32 values).
+ * Solve (A + damping*trace(A)/6*I) x = -b by Cholesky; T <- [exp(w) | tau] * T.  A final pass evaluates fitness/rmse at T.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct { double a[21], b[6], e; int64_t cnt, nsrc; } icp_sums;
+
+static void icp_pass(const orc_cfg *c, const float *depth_s, float sc, const float *nmap_t, const double T[16],
+                     int stride, float max_dist, icp_sums *s) {
+    const int W = c->width, H = c->height;
+    const float fx = (float)c->fx, fy = (float)c->fy, cx = (float)c->cx, cy = (float)c->cy;
+    const float mind = (float)c->min_depth, maxd = (float)c->max_depth;
+    const float wlim = (float)W - 0.5f, hlim = (float)H - 0.5f, md2 = max_dist * max_dist;
+    float r[9], t[3];
+    r[0] = (float)T[0]; r[1] = (float)T[1]; r[2] = (float)T[2]; t[0] = (float)T[3];
+    r[3] = (float)T[4]; r[4] = (float)T[5]; r[5] = (float)T[6]; t[1] = (float)T[7];
+    r[6] = (float)T[8]; r[7] = (float)T[9]; r[8] = (float)T[10]; t[2] = (float)T[11];
+    memset(s, 0, sizeof(*s));
+    for (int v = 0; v < H; v += stride)
+        for (int u = 0; u < W; u += stride) {
+            float ps[3];
+            if (!load_vertex(c, depth_s, u, v, sc, mind, maxd, fx, fy, cx, cy, ps)) continue;
+            s->nsrc++;
+            const float px = fmaf(r[0], ps[0], fmaf(r[1], ps[1], fmaf(r[2], ps[2], t[0])));
+            const float py = fmaf(r[3], ps[0], fmaf(r[4], ps[1], fmaf(r[5], ps[2], t[1])));
+            const float pz = fmaf(r[6], ps[0], fmaf(r[7], ps[1], fmaf(r[8], ps[2], t[2])));
+            if (!(pz > 0.0f)) continue;
+            const float inv = 1.0f / pz;
+            const float uf = fmaf(fx * px, inv, cx);
+            const float vf = fmaf(fy * py, inv, cy);
+            if (!(uf >= -0.5f && uf < wlim && vf >= -0.5f && vf < hlim)) continue;
+            int ut = (int)floorf(uf + 0.5f), vt = (int)floorf(vf + 0.5f);
+            if (ut > W - 1) ut = W - 1;
+            if (vt > H - 1) vt = H - 1;
+            const float *nd = nmap_t + 4 * ((size_t)vt * W + ut);
+            const float dt = nd[3];
+            if (!(dt > 0.0f)) continue;
+            const float qx = (((float)ut - cx) / fx) * dt;
+            const float qy = (((float)vt - cy) / fy) * dt;
+            const float dx = px - qx, dy = py - qy, dz = pz - dt;
+            const float dist2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+            if (!(dist2 <= md2)) continue;
+            const float nx = nd[0], ny = nd[1], nz = nd[2];
+            const float res = fmaf(dx, nx, fmaf(dy, ny, dz * nz));
+            const float j0 = fmaf(py, nz, -(pz * ny));
+            const float j1 = fmaf(pz, nx, -(px * nz));
+            const float j2 = fmaf(px, ny, -(py * nx));
+            const double J[6] = {j0, j1, j2, nx, ny, nz};
+            const double rr = (double)res;
+            int m = 0;
+            for (int a = 0; a < 6; ++a) {
+                for (int b = a; b < 6; ++b) s->a[m++] += J[a] * J[b];
+                s->b[a] += J[a] * rr;
+            }
+            s->e += rr * rr;
+            s->cnt++;
+        }
+}
+
+/* Cholesky solve of the damped 6x6 system; returns 0 on success */
+static int solve6(const double a21[21], const double b[6], double damping, double x[6]) {
+    double A[6][6], L[6][6];
+    int m = 0;
+    double tr = 0.0;
+    for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 6; ++j) { A[i][j] = A[j][i] = a21[m++]; }
+    for (int i = 0; i < 6; ++i) tr += A[i][i];
+    const double lam = damping * (tr / 6.0);
+    for (int i = 0; i < 6; ++i) A[i][i] += lam;
+    memset(L, 0, sizeof(L));
+    for (int i = 0; i < 6; ++i) {
+        for (int j = 0; j <= i; ++j) {
+            double s = A[i][j];
+            for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
+            if (i == j) {
+                if (!(s > 1e-14 * (tr > 0 ? tr : 1.0))) return 1;
+                L[i][i] = sqrt(s);
+            } else {
+                L[i][j] = s / L[j][j];
+            }
+        }
+    }
+    double y[6];
+    for (int i = 0; i < 6; ++i) {
+        double s = -b[i];
+        for (int k = 0; k < i; ++k) s -= L[i][k] * y[k];
+        y[i] = s / L[i][i];
+    }
+    for (int i = 5; i >= 0; --i) {
+        double s = y[i];
+        for (int k = i + 1; k < 6; ++k) s -= L[k][i] * x[k];
+        x[i] = s / L[i][i];
+    }
+    return 0;
+}
+
+/* T <- [exp(w) | tau] * T */
+static void se3_apply(const double x[6], double T[16]) {
+    const double wx = x[0], wy = x[1], wz = x[2];
+    const double th2 = wx * wx + wy * wy + wz * wz;
+    const double th = sqrt(th2);
+    double a, bq;
+    if (th < 1e-12) { a = 1.0; bq = 0.5; } else { a = sin(th) / th; bq = (1.0 - cos(th)) / th2; }
+    const double K[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+    double K2[9], dR[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double s = 0;
+            for (int k = 0; k < 3; ++k) s += K[3 * i + k] * K[3 * k + j];
+            K2[3 * i + j] = s;
+        }
+    for (int i = 0; i < 9; ++i) dR[i] = (i % 4 == 0 ? 1.0 : 0.0) + a * K[i] + bq * K2[i];
+    double Tn[16];
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 4; ++j) {
+            double s = 0;
+            for (int k = 0; k < 3; ++k) s += dR[3 * i + k] * T[4 * k + j];
+            Tn[4 * i + j] = s;
+        }
+        Tn[4 * i + 3] += x[3 + i];
+    }
+    Tn[12] = 0; Tn[13] = 0; Tn[14] = 0; Tn[15] = 1;
+    memcpy(T, Tn, sizeof(Tn));
+}
+
+int orc_icp(const orc_cfg *c, const float *depth_s, double scale_s, const float *nmap_t, const double T_init[16],
+            const orc_icp_params *prm, orc_icp_result *out) {
+    double T[16];
+    memcpy(T, T_init, sizeof(T));
+    icp_sums s;
+    int status = 0, iters_run = 0;
+    for (int it = 0; it < prm->iters; ++it) {
+        icp_pass(c, depth_s, (float)scale_s, nmap_t, T, prm->stride, (float)prm->max_dist, &s);
+        double x[6];
+        if (s.cnt < 6 || solve6(s.a, s.b, prm->damping, x)) { status = 2; break; }
+        se3_apply(x, T);
+        ++iters_run;
+        double mx = 0;
+        for (int i = 0; i < 6; ++i) if (fabs(x[i]) > mx) mx = fabs(x[i]);
+        if (mx < prm->eps) { status = 1; break; }
+    }
+    icp_pass(c, depth_s, (float)scale_s, nmap_t, T, prm->stride, (float)prm->max_dist, &s);
+    memcpy(out->T, T, sizeof(T));
+    out->n_corr = s.cnt;
+    out->n_src = s.nsrc;
+    out->fitness = s.nsrc > 0 ? (double)s.cnt / (double)s.nsrc : 0.0;
+    out->rmse = s.cnt > 0 ? sqrt(s.e / (double)s.cnt) : 0.0;
+    out->iters_run = iters_run;
+    out->status = status;
+    return 0;
+}
+
+/* exposed for tests of the device reduction: one evaluation pass, sums out as 29 doubles + 2 counts */
+void orc_icp_sums(const orc_cfg *c, const float *depth_s, double scale_s, const float *nmap_t, const double T[16],
+                  int stride, double max_dist, double out29[29], int64_t *cnt, int64_t *nsrc) {
+    icp_sums s;
+    icp_pass(c, depth_s, (float)scale_s, nmap_t, T, stride, (float)max_dist, &s);
+    memcpy(out29, s.a, 21 * sizeof(double));
+    memcpy(out29 + 21, s.b, 6 * sizeof(double));
+    out29[27] = s.e;
+    out29[28] = 0.0;
+    *cnt = s.cnt;
+    *nsrc = s.nsrc;
+}

@@ -1,0 +1,142 @@
+"""GPU parity proper: HIP path (through the C-ABI) vs the CPU oracle on the same seeded inputs.
+Integer grids are compared bit for bit."""
+import numpy as np
+import pytest
+
+import tl3d
+from helpers import SMALL, make_pair, small_scene_frames, ulp_diff
+
+pytestmark = pytest.mark.gpu
+
+
+def test_tsdf_grid_bit_exact():
+    poses, frames = small_scene_frames(n=4, deg=6.0)
+    ctx, orc = make_pair(dims=(96, 64, 80), voxel=0.03, centre=(0.0, -0.2, 0.1))
+    with ctx:
+        for i, ((depth, bgr), pose) in enumerate(zip(frames, poses)):
+            ctx.upload(i % 4, depth, bgr)
+            ctx.integrate(i % 4, pose)
+            orc.tsdf_integrate(depth, pose[0], pose[1])
+        g = ctx.download_grid(tl3d.CH_TSDF)
+    assert g.shape == orc.tsdf.shape
+    assert orc.tsdf[:, 1].sum() > 10000, "scene must touch the grid"
+    assert np.array_equal(g, orc.tsdf)
+
+
+def test_tsdf_scale_and_limits():
+    poses, frames = small_scene_frames(n=2, deg=3.0)
+    ctx, orc = make_pair(dims=(64, 64, 64), voxel=0.04, min_depth=0.3, max_depth=1.6)
+    with ctx:
+        for i, ((depth, bgr), pose) in enumerate(zip(frames, poses)):
+            d = (depth / 1.25).astype(np.float32)
+            ctx.upload(i, d, None)
+            ctx.integrate(i, pose, scale=1.25)
+            orc.tsdf_integrate(d, pose[0], pose[1], scale=1.25)
+        g = ctx.download_grid(tl3d.CH_TSDF)
+    assert orc.tsdf[:, 1].sum() > 1000
+    assert np.array_equal(g, orc.tsdf)
+
+
+def test_tsdf_counting_mode_matches_and_counts():
+    poses, frames = small_scene_frames(n=2, deg=3.0)
+    ctx, orc = make_pair(dims=(64, 64, 64), voxel=0.04)
+    with ctx:
+        ctx.set_profile(count_records=True, time_kernels=True)
+        for i, ((depth, bgr), pose) in enumerate(zip(frames, poses)):
+            ctx.upload(i, depth, None)
+            ctx.integrate(i, pose)
+            orc.tsdf_integrate(depth, pose[0], pose[1])
+        g = ctx.download_grid(tl3d.CH_TSDF)
+        st = ctx.stats()
+    assert np.array_equal(g, orc.tsdf)
+    updates = int(orc.tsdf[:, 1].sum())
+    assert st["tsdf_launches"] == 2 and st["tsdf_kernel_timed"] == 2 and st["tsdf_kernel_ms"] > 0
+    # records move in 16-byte pairs: between 1x and 2x the number of updated voxels
+    assert updates <= st["tsdf_records_written"] <= 2 * updates
+    assert st["tsdf_records_read"] == st["tsdf_records_written"]
+    assert 0 < st["tsdf_bricks_visited"] <= 2 * 512
+
+
+def test_centroid_grid_bit_exact_and_extract():
+    poses, frames = small_scene_frames(n=3, deg=5.0)
+    ctx, orc = make_pair(dims=(128, 96, 128), voxel=0.02, centre=(0.0, -0.3, 0.0))
+    with ctx:
+        for i, ((depth, bgr), pose) in enumerate(zip(frames, poses)):
+            ctx.upload(i, depth, bgr)
+            sub = 1 + (i % 2)
+            ctx.accumulate_centroid(i, pose, subsample=sub)
+            orc.centroid_accumulate(depth, bgr, pose[0], pose[1], subsample=sub)
+        g = ctx.download_grid(tl3d.CH_CENTROID)
+        st = ctx.stats()
+        xyz, rgb = ctx.extract(tl3d.EXTRACT_CENTROID)
+    assert np.array_equal(g, orc.centroid)
+    assert st["centroid_points"] == orc.n_acc.value and st["centroid_dropped"] == orc.n_drop.value
+    assert orc.n_acc.value > 10000
+    oxyz, orgb = orc.extract(0)
+    assert len(xyz) == len(oxyz) > 1000
+    assert np.array_equal(xyz, oxyz) and np.array_equal(rgb, orgb)
+
+
+def test_extract_tsdf_mode_and_gate():
+    poses, frames = small_scene_frames(n=6, deg=8.0)
+    ctx, orc = make_pair(dims=(96, 96, 96), voxel=0.025, centre=(0.0, -0.2, 0.0))
+    with ctx:
+        for i, ((depth, bgr), pose) in enumerate(zip(frames, poses)):
+            ctx.upload(i % 4, depth, bgr)
+            ctx.integrate(i % 4, pose)
+            ctx.accumulate_centroid(i % 4, pose)
+            orc.tsdf_integrate(depth, pose[0], pose[1])
+            orc.centroid_accumulate(depth, bgr, pose[0], pose[1])
+        xyz, rgb = ctx.extract(tl3d.EXTRACT_TSDF, min_weight=2)
+        gx, gc = ctx.extract(tl3d.EXTRACT_CENTROID, min_count=2, min_weight=2, max_abs_tsdf=0.9)
+    oxyz, orgb = orc.extract(1, min_weight=2)
+    assert len(oxyz) > 500
+    assert np.array_equal(xyz, oxyz) and np.array_equal(rgb, orgb)
+    ogx, ogc = orc.extract(0, min_count=2, min_weight=2, max_abs_tsdf=0.9)
+    assert len(ogx) > 100
+    assert np.array_equal(gx, ogx) and np.array_equal(gc, ogc)
+
+
+def test_grid_add_upload_roundtrip():
+    poses, frames = small_scene_frames(n=2, deg=5.0)
+    ctx, orc = make_pair(dims=(64, 64, 64), voxel=0.04)
+    with ctx:
+        ctx.upload(0, *frames[0])
+        ctx.integrate(0, poses[0])
+        ctx.accumulate_centroid(0, poses[0])
+        t0, c0 = ctx.download_grid(tl3d.CH_TSDF), ctx.download_grid(tl3d.CH_CENTROID)
+        ctx.reset()
+        ctx.upload(1, *frames[1])
+        ctx.integrate(1, poses[1])
+        ctx.accumulate_centroid(1, poses[1])
+        ctx.add_grid(tl3d.CH_TSDF, t0)           # merge of two partial grids == both frames in one grid
+        ctx.add_grid(tl3d.CH_CENTROID, c0)
+        t01, c01 = ctx.download_grid(tl3d.CH_TSDF), ctx.download_grid(tl3d.CH_CENTROID)
+    for (d, b), p in zip(frames, poses):
+        orc.tsdf_integrate(d, p[0], p[1])
+        orc.centroid_accumulate(d, b, p[0], p[1])
+    assert np.array_equal(t01, orc.tsdf) and np.array_equal(c01, orc.centroid)
+
+
+def test_normals_and_icp_match_oracle():
+    poses, frames = small_scene_frames(n=2, deg=1.5)
+    ctx, orc = make_pair(channels=0, dims=(8, 8, 8))
+    with ctx:
+        ctx.upload(0, *frames[0])
+        ctx.upload(1, *frames[1])
+        ctx.build_normals(1, depth_jump=0.05)
+        nm = ctx.download_normals(1)
+        onm = orc.normals(frames[1][0], depth_jump=0.05)
+        assert (onm[..., 3] > 0).mean() > 0.5
+        assert np.array_equal(nm, onm)
+        res = ctx.icp(0, 1, iters=15, stride=2, max_dist=0.1)
+        ores = orc.icp(frames[0][0], onm, iters=15, stride=2, max_dist=0.1)
+    assert res["n_src"] == ores["n_src"] and abs(res["n_corr"] - ores["n_corr"]) <= 2
+    assert np.linalg.norm(res["T"] - ores["T"]) <= 1e-4        # north-star tolerance: pose within 1e-4 Frobenius
+    assert np.linalg.norm(res["T"] - ores["T"]) <= 1e-9        # what identical association actually gives
+    assert abs(res["rmse"] - ores["rmse"]) < 1e-9 and res["iters_run"] == ores["iters_run"]
+    # and both recover the analytic relative pose
+    from tl3d import synth
+    r_rel, t_rel = synth.relative_pose(poses[0], poses[1])
+    T_true = np.eye(4); T_true[:3, :3] = r_rel; T_true[:3, 3] = t_rel.ravel()
+    assert np.linalg.norm(res["T"] - T_true) < 5e-3

@@ -1,0 +1,44 @@
+// bp_device.h -- the per-pixel back-projection shared by the point-list kernel (kernels_backproject.hip)
+// and the fused centroid accumulation (kernels_centroid.hip).  One definition so both produce the same bits.
+// Reference: depth_to_reconstruction.py:343-384, depth_enhanced_reconstruction.py:572-613.
+#pragma once
+#include "tl3d_internal.h"
+
+namespace tl3d {
+
+__device__ __forceinline__ bool bp_pixel(const Cam &cam, const BpArgs &a, const PoseD &p, const float *__restrict__ depth,
+                                         int u, int v, float out[3]) {
+    const float d32 = depth[(size_t)v * cam.W + u];
+    double z;
+    if (a.flags & TL3D_F_SCALE_F64) {
+        const double d = (double)d32 * a.scale;
+        if (!(d > a.min_d && d < a.max_d)) return false;       // NaN and +-inf fail the strict compares
+        z = d;
+    } else {
+        const float d = d32 * (float)a.scale;
+        if (!(d > (float)a.min_d && d < (float)a.max_d)) return false;
+        z = (double)d;
+    }
+    const double x = (((double)u - cam.cxd) / cam.fxd) * z;
+    const double y = (((double)v - cam.cyd) / cam.fyd) * z;
+    if (a.flags & TL3D_F_NO_POSE) {
+        out[0] = (float)x; out[1] = (float)y; out[2] = (float)z;
+    } else {
+        out[0] = (float)(((p.r[0] * x + p.r[3] * y) + p.r[6] * z) - p.ct[0]);
+        out[1] = (float)(((p.r[1] * x + p.r[4] * y) + p.r[7] * z) - p.ct[1]);
+        out[2] = (float)(((p.r[2] * x + p.r[5] * y) + p.r[8] * z) - p.ct[2]);
+    }
+    return true;
+}
+
+__device__ __forceinline__ bool bp_valid_only(const Cam &cam, const BpArgs &a, const float *__restrict__ depth, int u, int v) {
+    const float d32 = depth[(size_t)v * cam.W + u];
+    if (a.flags & TL3D_F_SCALE_F64) {
+        const double d = (double)d32 * a.scale;
+        return d > a.min_d && d < a.max_d;
+    }
+    const float d = d32 * (float)a.scale;
+    return d > (float)a.min_d && d < (float)a.max_d;
+}
+
+}  // namespace tl3d

@@ -1,0 +1,23 @@
+#!/usr/bin/env bash
+# Builds libtl3d.so for gfx950 (MI355X) in-tree.  hipcc cross-compiles without a GPU.
+#   -ffp-contract=off : the f32/fp64 sequences are part of the parity contract with the oracle;
+#                       FMAs appear only where the source says fmaf().
+set -euo pipefail
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+OUT="${HERE}/../libtl3d.so"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function)
+OBJS=()
+PIDS=()
+mkdir -p "${HERE}/build"
+for f in tl3d_api kernels_backproject kernels_centroid kernels_tsdf kernels_icp kernels_extract kernels_sor; do
+  src="${HERE}/${f}.hip"; obj="${HERE}/build/${f}.o"
+  if [[ ! -f "$obj" || "$src" -nt "$obj" || "${HERE}/tl3d_internal.h" -nt "$obj" || "${HERE}/bp_device.h" -nt "$obj" || "${HERE}/../../include/tl3d.h" -nt "$obj" ]]; then
+    "$HIPCC" "${FLAGS[@]}" ${TL3D_EXTRA_FLAGS:-} -c "$src" -o "$obj" &
+    PIDS+=($!)
+  fi
+  OBJS+=("$obj")
+done
+for p in "${PIDS[@]:-}"; do [[ -z "$p" ]] || wait "$p"; done
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT" "${OBJS[@]}"
+echo "built $OUT"

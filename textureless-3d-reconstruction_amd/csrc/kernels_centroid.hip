@@ -1,0 +1,194 @@
+// kernels_centroid.hip -- row a7 (fusion half): voxel-centroid accumulators with the semantics of Open3D
+// voxel_down_sample as the reference calls it (depth_to_reconstruction.py:404-410; DER:635-640):
+//   index = floor((p - origin)/voxel) in fp64 from the f32 point, per-voxel mean of points and colours.
+// The np.vstack of every cloud (D2R:401-402) is never materialised: each frame's points go straight from the
+// depth map into integer accumulators (exact, order-free => bit-reproducible, and the multi-GPU merge is a sum).
+//
+// record (32 B, one 32-B sector): u64[4] = { sx | sy<<32, sz | n<<32, sr | sg<<32, sb }, s* in units of voxel/4096.
+// v1: one thread per sampled pixel, four 64-bit integer atomics per surviving point.
+#include "bp_device.h"
+#include "tl3d_internal.h"
+
+namespace tl3d {
+
+struct CenAdd {
+    unsigned long long rec;      // record index, ~0ull if none
+    unsigned long long a, b, c, d;
+};
+
+__device__ __forceinline__ CenAdd centroid_key(const Grid &g, const float p[3], unsigned r8, unsigned g8, unsigned b8) {
+    CenAdd o;
+    o.rec = ~0ull;
+    const double org[3] = {g.oxd, g.oyd, g.ozd};
+    const int dims[3] = {g.nx, g.ny, g.nz};
+    int idx[3];
+    unsigned long long q[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double rc = ((double)p[a] - org[a]) / g.vsd;
+        const double fl = floor(rc);
+        if (!(fl >= 0.0 && fl < (double)dims[a])) return o;
+        idx[a] = (int)fl;
+        int qq = (int)((rc - fl) * 4096.0);
+        if (qq > 4095) qq = 4095;
+        q[a] = (unsigned long long)qq;
+    }
+    o.rec = (unsigned long long)vox_index(idx[0], idx[1], idx[2], g.nbx, g.nby);
+    o.a = q[0] | (q[1] << 32);
+    o.b = q[2] | (1ull << 32);
+    o.c = (unsigned long long)r8 | ((unsigned long long)g8 << 32);
+    o.d = (unsigned long long)b8;
+    return o;
+}
+
+__global__ __launch_bounds__(256) void centroid_frame_kernel(Cam cam, Grid g, BpArgs a, PoseD p, const float *__restrict__ depth,
+                                                             const uint8_t *__restrict__ bgr, unsigned long long *__restrict__ grid,
+                                                             unsigned long long *__restrict__ counters) {
+    const long long s = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long ns = (long long)a.Ws * a.Hs;
+    CenAdd k;
+    k.rec = ~0ull;
+    k.a = k.b = k.c = k.d = 0;
+    bool valid = false;
+    if (s < ns) {
+        const int vs = (int)(s / a.Ws), us = (int)(s - (long long)vs * a.Ws);
+        const int u = us * a.sub, v = vs * a.sub;
+        float pt[3];
+        if (bp_pixel(cam, a, p, depth, u, v, pt)) {
+            valid = true;
+            unsigned r8 = 0, g8 = 0, b8 = 0;
+            if (bgr) {
+                const uint8_t *px = bgr + 3 * ((size_t)v * cam.W + u);
+                b8 = px[0]; g8 = px[1]; r8 = px[2];
+            }
+            k = centroid_key(g, pt, r8, g8, b8);
+        }
+    }
+    const unsigned long long mv = __ballot(valid), mk = __ballot(k.rec != ~0ull);
+    if ((threadIdx.x & 63) == 0 && mv) {
+        atomicAdd(counters + 0, (unsigned long long)__popcll(mk));
+        atomicAdd(counters + 1, (unsigned long long)(__popcll(mv) - __popcll(mk)));
+    }
+    if (k.rec != ~0ull) {
+        unsigned long long *rec = grid + 4 * k.rec;
+        atomicAdd(rec + 0, k.a);
+        atomicAdd(rec + 1, k.b);
+        atomicAdd(rec + 2, k.c);
+        atomicAdd(rec + 3, k.d);
+    }
+}
+
+__global__ __launch_bounds__(256) void centroid_points_kernel(Grid g, const float *__restrict__ xyz, const uint8_t *__restrict__ rgb,
+                                                              long long n, unsigned long long *__restrict__ grid,
+                                                              unsigned long long *__restrict__ counters) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    CenAdd k;
+    k.rec = ~0ull;
+    bool valid = false;
+    if (i < n) {
+        valid = true;
+        const float pt[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+        k = centroid_key(g, pt, rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]);
+    }
+    const unsigned long long mv = __ballot(valid), mk = __ballot(k.rec != ~0ull);
+    if ((threadIdx.x & 63) == 0 && mv) {
+        atomicAdd(counters + 0, (unsigned long long)__popcll(mk));
+        atomicAdd(counters + 1, (unsigned long long)(__popcll(mv) - __popcll(mk)));
+    }
+    if (k.rec != ~0ull) {
+        unsigned long long *rec = grid + 4 * k.rec;
+        atomicAdd(rec + 0, k.a);
+        atomicAdd(rec + 1, k.b);
+        atomicAdd(rec + 2, k.c);
+        atomicAdd(rec + 3, k.d);
+    }
+}
+
+// per-block min/max of a point list -> slab[block][6]
+__global__ __launch_bounds__(256) void bounds_kernel(const float *__restrict__ xyz, long long n, float *__restrict__ slab) {
+    __shared__ float sm[4][6];
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float v = xyz[3 * i + a];
+            mn[a] = fminf(mn[a], v);
+            mx[a] = fmaxf(mx[a], v);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+        for (int d = 32; d > 0; d >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_down(mn[a], d));
+            mx[a] = fmaxf(mx[a], __shfl_down(mx[a], d));
+        }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0)
+        for (int a = 0; a < 3; ++a) { sm[wid][a] = mn[a]; sm[wid][3 + a] = mx[a]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = sm[0][threadIdx.x];
+        for (int w = 1; w < 4; ++w) v = threadIdx.x < 3 ? fminf(v, sm[w][threadIdx.x]) : fmaxf(v, sm[w][threadIdx.x]);
+        slab[blockIdx.x * 6 + threadIdx.x] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void add_i32_kernel(int4 *__restrict__ dst, const int4 *__restrict__ src, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        int4 a = dst[i];
+        const int4 b = src[i];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        dst[i] = a;
+    }
+}
+
+__global__ __launch_bounds__(256) void add_u64_kernel(ulonglong2 *__restrict__ dst, const ulonglong2 *__restrict__ src, size_t n2) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (size_t)gridDim.x * 256) {
+        ulonglong2 a = dst[i];
+        const ulonglong2 b = src[i];
+        a.x += b.x; a.y += b.y;
+        dst[i] = a;
+    }
+}
+
+int launch_centroid_frame(hipStream_t s, const Cam &cam, const Grid &g, const BpArgs &a, const PoseD &p, const float *depth,
+                          const uint8_t *bgr, unsigned long long *grid, unsigned long long *counters) {
+    const long long ns = (long long)a.Ws * a.Hs;
+    const unsigned nb = (unsigned)((ns + 255) / 256);
+    hipLaunchKernelGGL(centroid_frame_kernel, dim3(nb), dim3(256), 0, s, cam, g, a, p, depth, bgr, grid, counters);
+    TL3D_HIP(hipGetLastError());
+    return TL3D_OK;
+}
+
+int launch_centroid_points(hipStream_t s, const Grid &g, const float *xyz, const uint8_t *rgb, long long n,
+                           unsigned long long *grid, unsigned long long *counters) {
+    if (n <= 0) return TL3D_OK;
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(centroid_points_kernel, dim3(nb), dim3(256), 0, s, g, xyz, rgb, n, grid, counters);
+    TL3D_HIP(hipGetLastError());
+    return TL3D_OK;
+}
+
+int launch_bounds(hipStream_t s, const float *xyz, long long n, float *slab, int nblocks) {
+    hipLaunchKernelGGL(bounds_kernel, dim3(nblocks), dim3(256), 0, s, xyz, n, slab);
+    TL3D_HIP(hipGetLastError());
+    return TL3D_OK;
+}
+
+int launch_add_i32(hipStream_t s, int *dst, const int *src, size_t n) {
+    const size_t n4 = n / 4;     // n is a multiple of 1024 (bricks)
+    const unsigned nb = (unsigned)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(add_i32_kernel, dim3(nb ? nb : 1), dim3(256), 0, s, (int4 *)dst, (const int4 *)src, n4);
+    TL3D_HIP(hipGetLastError());
+    return TL3D_OK;
+}
+
+int launch_add_u64(hipStream_t s, unsigned long long *dst, const unsigned long long *src, size_t n) {
+    const size_t n2 = n / 2;
+    const unsigned nb = (unsigned)((n2 + 255) / 256 < 4096 ? (n2 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(add_u64_kernel, dim3(nb ? nb : 1), dim3(256), 0, s, (ulonglong2 *)dst, (const ulonglong2 *)src, n2);
+    TL3D_HIP(hipGetLastError());
+    return TL3D_OK;
+}
+
+}  // namespace tl3d

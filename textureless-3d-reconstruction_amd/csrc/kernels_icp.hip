@@ -1,0 +1,243 @@
+// kernels_icp.hip -- row a10: vertex/normal map and pairwise point-to-plane ICP (projective association).
+// The reference has no ICP (its poses come from SIFT + essential matrix, depth_to_reconstruction.py:144-215);
+// this replaces that pose source and returns the relative pose in the reference's chaining convention
+// (D2R:618-620).  Convention and f32 sequence = oracle/tl3d_oracle.c (orc_normals, icp_pass, solve6, se3_apply).
+//
+// Device-resident iteration: icp_reduce_kernel accumulates the 6x6 normal equations (21 + 6 + 3 sums, fp64)
+// per lane, reduces them with 64-lane wave shuffles, then across the 4 waves through LDS, and writes one
+// 32-double partial per workgroup; icp_solve_kernel sums the partials in block order (deterministic), solves
+// the damped system by Cholesky and updates T in device memory.  No host round trip inside the loop: the host
+// enqueues 2 x iters kernels and reads the state once.  Bytes per iteration and sampled pixel: 4 (source
+// depth) + 16 (target normal+depth gather) = 20 B.
+#include "tl3d_internal.h"
+
+namespace tl3d {
+
+__device__ __forceinline__ bool load_vertex(const Cam &cam, const float *__restrict__ depth, int u, int v, float sc,
+                                            float mind, float maxd, float p[3]) {
+    const float d = depth[(size_t)v * cam.W + u] * sc;
+    if (!(d > mind && d < maxd)) return false;
+    p[0] = (((float)u - cam.cx) / cam.fx) * d;
+    p[1] = (((float)v - cam.cy) / cam.fy) * d;
+    p[2] = d;
+    return true;
+}
+
+__global__ __launch_bounds__(256) void normals_kernel(Cam cam, const float *__restrict__ depth, float sc, float mind,
+                                                      float maxd, float jump, float4 *__restrict__ nmap) {
+    const int u = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int v = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (u >= cam.W || v >= cam.H) return;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    float p[3], l[3], r[3], up[3], dn[3];
+    bool ok = (u >= 1 && v >= 1 && u <= cam.W - 2 && v <= cam.H - 2);
+    ok = ok && load_vertex(cam, depth, u, v, sc, mind, maxd, p);
+    ok = ok && load_vertex(cam, depth, u - 1, v, sc, mind, maxd, l);
+    ok = ok && load_vertex(cam, depth, u + 1, v, sc, mind, maxd, r);
+    ok = ok && load_vertex(cam, depth, u, v - 1, sc, mind, maxd, up);
+    ok = ok && load_vertex(cam, depth, u, v + 1, sc, mind, maxd, dn);
+    if (ok) {
+        ok = fabsf(l[2] - p[2]) <= jump && fabsf(r[2] - p[2]) <= jump && fabsf(up[2] - p[2]) <= jump &&
+             fabsf(dn[2] - p[2]) <= jump;
+    }
+    if (ok) {
+        const float ax = r[0] - l[0], ay = r[1] - l[1], az = r[2] - l[2];
+        const float bx = dn[0] - up[0], by = dn[1] - up[1], bz = dn[2] - up[2];
+        float nx = fmaf(ay, bz, -(az * by));
+        float ny = fmaf(az, bx, -(ax * bz));
+        float nz = fmaf(ax, by, -(ay * bx));
+        const float len2 = fmaf(nx, nx, fmaf(ny, ny, nz * nz));
+        if (len2 > 1e-30f) {
+            const float inv = 1.0f / sqrtf(len2);
+            nx *= inv; ny *= inv; nz *= inv;
+            const float dotv = fmaf(nx, p[0], fmaf(ny, p[1], nz * p[2]));
+            if (dotv > 0.0f) { nx = -nx; ny = -ny; nz = -nz; }
+            o = make_float4(nx, ny, nz, p[2]);
+        }
+    }
+    nmap[(size_t)v * cam.W + u] = o;
+}
+
+__global__ __launch_bounds__(256) void icp_reduce_kernel(Cam cam, const float *__restrict__ depth_s, float sc, float mind,
+                                                         float maxd, const float4 *__restrict__ nmap_t, int stride, int Ws,
+                                                         int Hs, float md2, const IcpState *__restrict__ state,
+                                                         int final_pass, double *__restrict__ slab) {
+    if (!final_pass && state->done) return;
+    __shared__ double sm[4][ICP_SLAB];
+    float r[9], t[3];
+    r[0] = (float)state->T[0]; r[1] = (float)state->T[1]; r[2] = (float)state->T[2];  t[0] = (float)state->T[3];
+    r[3] = (float)state->T[4]; r[4] = (float)state->T[5]; r[5] = (float)state->T[6];  t[1] = (float)state->T[7];
+    r[6] = (float)state->T[8]; r[7] = (float)state->T[9]; r[8] = (float)state->T[10]; t[2] = (float)state->T[11];
+    const float wlim = (float)cam.W - 0.5f, hlim = (float)cam.H - 0.5f;
+    double acc[30];
+#pragma unroll
+    for (int i = 0; i < 30; ++i) acc[i] = 0.0;
+    const long long ns = (long long)Ws * Hs;
+    for (long long s = (long long)blockIdx.x * 256 + threadIdx.x; s < ns; s += (long long)gridDim.x * 256) {
+        const int vs = (int)(s / Ws), us = (int)(s - (long long)vs * Ws);
+        const int u = us * stride, v = vs * stride;
+        float ps[3];
+        if (!load_vertex(cam, depth_s, u, v, sc, mind, maxd, ps)) continue;
+        acc[29] += 1.0;
+        const float px = fmaf(r[0], ps[0], fmaf(r[1], ps[1], fmaf(r[2], ps[2], t[0])));
+        const float py = fmaf(r[3], ps[0], fmaf(r[4], ps[1], fmaf(r[5], ps[2], t[1])));
+        const float pz = fmaf(r[6], ps[0], fmaf(r[7], ps[1], fmaf(r[8], ps[2], t[2])));
+        if (!(pz > 0.0f)) continue;
+        const float inv = 1.0f / pz;
+        const float uf = fmaf(cam.fx * px, inv, cam.cx);
+        const float vf = fmaf(cam.fy * py, inv, cam.cy);
+        if (!(uf >= -0.5f && uf < wlim && vf >= -0.5f && vf < hlim)) continue;
+        int ut = (int)floorf(uf + 0.5f), vt = (int)floorf(vf + 0.5f);
+        ut = min(ut, cam.W - 1);
+        vt = min(vt, cam.H - 1);
+        const float4 nd = nmap_t[(size_t)vt * cam.W + ut];
+        const float dt = nd.w;
+        if (!(dt > 0.0f)) continue;
+        const float qx = (((float)ut - cam.cx) / cam.fx) * dt;
+        const float qy = (((float)vt - cam.cy) / cam.fy) * dt;
+        const float dx = px - qx, dy = py - qy, dz = pz - dt;
+        const float dist2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+        if (!(dist2 <= md2)) continue;
+        const float res = fmaf(dx, nd.x, fmaf(dy, nd.y, dz * nd.z));
+        const double J[6] = {(double)fmaf(py, nd.z, -(pz * nd.y)), (double)fmaf(pz, nd.x, -(px * nd.z)),
+                             (double)fmaf(px, nd.y, -(py * nd.x)), (double)nd.x, (double)nd.y, (double)nd.z};
+        const double rr = (double)res;
+        int m = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+#pragma unroll
+            for (int b = a; b < 6; ++b) { acc[m] += J[a] * J[b]; ++m; }
+            acc[21 + a] += J[a] * rr;
+        }
+        acc[27] += rr * rr;
+        acc[28] += 1.0;
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 30; ++i) {
+        double v = acc[i];
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d);
+        if (lane == 0) sm[wid][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < ICP_SLAB) {
+        const int i = threadIdx.x;
+        slab[(size_t)blockIdx.x * ICP_SLAB + i] = (i < 30) ? ((sm[0][i] + sm[1][i]) + sm[2][i]) + sm[3][i] : 0.0;
+    }
+}
+
+__device__ int solve6(const double *a21, const double *b, double damping, double x[6]) {
+    double A[6][6], L[6][6];
+    int m = 0;
+    double tr = 0.0;
+    for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 6; ++j) { A[i][j] = a21[m]; A[j][i] = a21[m]; ++m; }
+    for (int i = 0; i < 6; ++i) tr += A[i][i];
+    const double lam = damping * (tr / 6.0);
+    for (int i = 0; i < 6; ++i) A[i][i] += lam;
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) L[i][j] = 0.0;
+    for (int i = 0; i < 6; ++i) {
+        for (int j = 0; j <= i; ++j) {
+            double s = A[i][j];
+            for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
+            if (i == j) {
+                if (!(s > 1e-14 * (tr > 0 ? tr : 1.0))) return 1;
+                L[i][i] = sqrt(s);
+            } else {
+                L[i][j] = s / L[j][j];
+            }
+        }
+    }
+    double y[6];
+    for (int i = 0; i < 6; ++i) {
+        double s = -b[i];
+        for (int k = 0; k < i; ++k) s -= L[i][k] * y[k];
+        y[i] = s / L[i][i];
+    }
+    for (int i = 5; i >= 0; --i) {
+        double s = y[i];
+        for (int k = i + 1; k < 6; ++k) s -= L[k][i] * x[k];
+        x[i] = s / L[i][i];
+    }
+    return 0;
+}
+
+__device__ void se3_apply(const double x[6], double *T) {
+    const double wx = x[0], wy = x[1], wz = x[2];
+    const double th2 = wx * wx + wy * wy + wz * wz;
+    const double th = sqrt(th2);
+    double a, bq;
+    if (th < 1e-12) { a = 1.0; bq = 0.5; } else { a = sin(th) / th; bq = (1.0 - cos(th)) / th2; }
+    const double K[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+    double K2[9], dR[9], Tn[16];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double s = 0;
+            for (int k = 0; k < 3; ++k) s += K[3 * i + k] * K[3 * k + j];
+            K2[3 * i + j] = s;
+        }
+    for (int i = 0; i < 9; ++i) dR[i] = (i % 4 == 0 ? 1.0 : 0.0) + a * K[i] + bq * K2[i];
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 4; ++j) {
+            double s = 0;
+            for (int k = 0; k < 3; ++k) s += dR[3 * i + k] * T[4 * k + j];
+            Tn[4 * i + j] = s;
+        }
+        Tn[4 * i + 3] += x[3 + i];
+    }
+    Tn[12] = 0; Tn[13] = 0; Tn[14] = 0; Tn[15] = 1;
+    for (int i = 0; i < 16; ++i) T[i] = Tn[i];
+}
+
+__global__ __launch_bounds__(64) void icp_solve_kernel(const double *__restrict__ slab, int nblocks, IcpState *state,
+                                                       double damping, double eps, int final_pass) {
+    if (!final_pass && state->done) return;
+    __shared__ double sums[ICP_SLAB];
+    const int t = threadIdx.x;
+    if (t < ICP_SLAB) {
+        double s = 0.0;
+        for (int b = 0; b < nblocks; ++b) s += slab[(size_t)b * ICP_SLAB + t];
+        sums[t] = s;
+        state->sums[t] = s;
+    }
+    __syncthreads();
+    if (t != 0 || final_pass) return;
+    double x[6];
+    if (sums[28] < 6.0 || solve6(sums, sums + 21, damping, x)) {
+        state->done = 1;
+        state->status = 2;
+        return;
+    }
+    se3_apply(x, state->T);
+    state->iters_run += 1;
+    double mx = 0.0;
+    for (int i = 0; i < 6; ++i) mx = fmax(mx, fabs(x[i]));
+    if (mx < eps) {
+        state->done = 1;
+        state->status = 1;
+    }
+}
+
+int launch_normals(hipStream_t s, const Cam &cam, const float *depth, float scale, float mind, float maxd, float jump,
+                   float4 *nmap) {
+    dim3 grid((cam.W + 63) / 64, (cam.H + 3) / 4);
+    hipLaunchKernelGGL(normals_kernel, grid, dim3(256), 0, s, cam, depth, scale, mind, maxd, jump, nmap);
+    TL3D_HIP(hipGetLastError());
+    return TL3D_OK;
+}
+
+int launch_icp_iteration(hipStream_t s, const Cam &cam, const float *depth_src, float scale, float mind, float maxd,
+                         const float4 *nmap_tgt, int stride, float max_dist, double damping, double eps, int final_pass,
+                         double *slab, IcpState *state, int nblocks) {
+    const int Ws = (cam.W + stride - 1) / stride, Hs = (cam.H + stride - 1) / stride;
+    hipLaunchKernelGGL(icp_reduce_kernel, dim3(nblocks), dim3(256), 0, s, cam, depth_src, scale, mind, maxd, nmap_tgt, stride,
+                       Ws, Hs, max_dist * max_dist, state, final_pass, slab);
+    TL3D_HIP(hipGetLastError());
+    hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(64), 0, s, slab, nblocks, state, damping, eps, final_pass);
+    TL3D_HIP(hipGetLastError());
+    return TL3D_OK;
+}
+
+}  // namespace tl3d

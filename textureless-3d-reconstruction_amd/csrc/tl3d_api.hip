@@ -1,0 +1,758 @@
+// tl3d_api.hip -- the extern "C" surface declared in include/tl3d.h: context, frame slots, launch glue.
+#include <stdarg.h>
+#include <math.h>
+
+#include <new>
+#include <vector>
+
+#include "tl3d_internal.h"
+
+using namespace tl3d;
+
+static thread_local char g_err[512] = "";
+
+namespace tl3d {
+int set_err(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+}  // namespace tl3d
+
+#define REQUIRE(cond, code, ...)                           \
+    do {                                                   \
+        if (!(cond)) return set_err((code), __VA_ARGS__);  \
+    } while (0)
+
+static bool is_device_ptr(const void *p) {
+    if (!p) return false;
+    hipPointerAttribute_t at;
+    memset(&at, 0, sizeof(at));
+    hipError_t e = hipPointerGetAttributes(&at, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged;
+}
+
+static PoseF make_pose_f(const double R[9], const double t[3]) {
+    PoseF p;
+    for (int i = 0; i < 9; ++i) p.r[i] = (float)R[i];
+    for (int i = 0; i < 3; ++i) p.t[i] = (float)t[i];
+    return p;
+}
+
+static PoseD make_pose_d(const double R[9], const double t[3], bool no_pose) {
+    PoseD p;
+    memset(&p, 0, sizeof(p));
+    if (no_pose) {
+        p.r[0] = p.r[4] = p.r[8] = 1.0;
+        return p;
+    }
+    for (int i = 0; i < 9; ++i) p.r[i] = R[i];
+    for (int i = 0; i < 3; ++i) p.ct[i] = (R[0 + i] * t[0] + R[3 + i] * t[1]) + R[6 + i] * t[2];   // (R^T t)_i, D2R:376
+    return p;
+}
+
+static Frustum make_frustum(const Cam &c) {
+    // inside: aL <= x/z <= aR, aT <= y/z <= aB, widened by one pixel on every side
+    const double aL = (-1.5 - c.cxd) / c.fxd, aR = ((double)c.W + 0.5 - c.cxd) / c.fxd;
+    const double aT = (-1.5 - c.cyd) / c.fyd, aB = ((double)c.H + 0.5 - c.cyd) / c.fyd;
+    Frustum f;
+    double n;
+    n = sqrt(1.0 + aL * aL); f.lx = (float)(1.0 / n);  f.lz = (float)(-aL / n);
+    n = sqrt(1.0 + aR * aR); f.rx = (float)(-1.0 / n); f.rz = (float)(aR / n);
+    n = sqrt(1.0 + aT * aT); f.ty = (float)(1.0 / n);  f.tz = (float)(-aT / n);
+    n = sqrt(1.0 + aB * aB); f.by = (float)(-1.0 / n); f.bz = (float)(aB / n);
+    return f;
+}
+
+static int ensure_scratch_blocks(tl3d_ctx *ctx, size_t nblocks) {
+    if (nblocks <= ctx->scratch_blocks) return TL3D_OK;
+    if (ctx->block_counts) (void)hipFree(ctx->block_counts);
+    if (ctx->block_offsets) (void)hipFree(ctx->block_offsets);
+    ctx->block_counts = nullptr;
+    ctx->block_offsets = nullptr;
+    ctx->scratch_blocks = 0;
+    if (hipMalloc(&ctx->block_counts, nblocks * sizeof(unsigned)) != hipSuccess) return set_err(TL3D_E_NOMEM, "scratch alloc failed");
+    if (hipMalloc(&ctx->block_offsets, nblocks * sizeof(unsigned long long)) != hipSuccess) return set_err(TL3D_E_NOMEM, "scratch alloc failed");
+    ctx->scratch_blocks = nblocks;
+    return TL3D_OK;
+}
+
+static int check_slot(tl3d_ctx *ctx, int slot, bool need_loaded) {
+    REQUIRE(ctx != nullptr, TL3D_E_INVALID, "null ctx");
+    REQUIRE(slot >= 0 && slot < ctx->cfg.n_slots, TL3D_E_INVALID, "slot %d out of range [0,%d)", slot, ctx->cfg.n_slots);
+    if (need_loaded) REQUIRE(ctx->slots[slot].loaded, TL3D_E_STATE, "slot %d holds no frame", slot);
+    return TL3D_OK;
+}
+
+extern "C" {
+
+const char *tl3d_last_error(void) { return g_err; }
+int tl3d_version(void) { return TL3D_ABI_VERSION; }
+
+int tl3d_device_count(int *n) {
+    REQUIRE(n != nullptr, TL3D_E_INVALID, "null out pointer");
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) {
+        (void)hipGetLastError();
+        c = 0;
+    }
+    *n = c;
+    return TL3D_OK;
+}
+
+int tl3d_create(const tl3d_config *cfg, int device, tl3d_ctx **out) {
+    REQUIRE(cfg && out, TL3D_E_INVALID, "null argument");
+    REQUIRE(cfg->abi_version == TL3D_ABI_VERSION, TL3D_E_INVALID, "ABI version %d != %d", cfg->abi_version, TL3D_ABI_VERSION);
+    REQUIRE(cfg->width > 0 && cfg->height > 0 && cfg->width <= 32768 && cfg->height <= 32768, TL3D_E_INVALID,
+            "bad frame size %dx%d", cfg->width, cfg->height);
+    REQUIRE(cfg->fx > 0 && cfg->fy > 0, TL3D_E_INVALID, "focal lengths must be positive");
+    REQUIRE(cfg->n_slots >= 1 && cfg->n_slots <= (1 << 20), TL3D_E_INVALID, "n_slots %d out of range", cfg->n_slots);
+    if (cfg->channels) {
+        REQUIRE((cfg->channels & ~(TL3D_CH_TSDF | TL3D_CH_CENTROID)) == 0, TL3D_E_INVALID, "unknown channel bits 0x%x", cfg->channels);
+        REQUIRE(cfg->nx > 0 && cfg->ny > 0 && cfg->nz > 0 && cfg->nx % TL3D_BRICK == 0 && cfg->ny % TL3D_BRICK == 0 &&
+                    cfg->nz % TL3D_BRICK == 0,
+                TL3D_E_INVALID, "grid dims %dx%dx%d must be positive multiples of %d", cfg->nx, cfg->ny, cfg->nz, TL3D_BRICK);
+        REQUIRE((double)cfg->nx * cfg->ny * cfg->nz <= 4294967296.0, TL3D_E_INVALID, "grid larger than 2^32 voxels");
+        REQUIRE(cfg->voxel_size > 0, TL3D_E_INVALID, "voxel_size must be positive");
+        if (cfg->channels & TL3D_CH_TSDF) REQUIRE(cfg->sdf_trunc > 0, TL3D_E_INVALID, "sdf_trunc must be positive");
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        return set_err(TL3D_E_NODEVICE, "no HIP device visible (libtl3d has no CPU fallback)");
+    }
+    REQUIRE(device >= 0 && device < ndev, TL3D_E_INVALID, "device %d out of range [0,%d)", device, ndev);
+    TL3D_HIP(hipSetDevice(device));
+
+    tl3d_ctx *ctx = new (std::nothrow) tl3d_ctx();
+    REQUIRE(ctx != nullptr, TL3D_E_NOMEM, "host allocation failed");
+    memset(ctx, 0, sizeof(*ctx));
+    ctx->cfg = *cfg;
+    ctx->device = device;
+    ctx->slots = new (std::nothrow) Slot[cfg->n_slots];
+    if (!ctx->slots) { delete ctx; return set_err(TL3D_E_NOMEM, "host allocation failed"); }
+
+    Cam &c = ctx->cam;
+    c.W = cfg->width; c.H = cfg->height;
+    c.fxd = cfg->fx; c.fyd = cfg->fy; c.cxd = cfg->cx; c.cyd = cfg->cy;
+    c.fx = (float)cfg->fx; c.fy = (float)cfg->fy; c.cx = (float)cfg->cx; c.cy = (float)cfg->cy;
+    Grid &g = ctx->grid;
+    memset(&g, 0, sizeof(g));
+    int rc = TL3D_OK;
+    auto fail = [&](int code) { tl3d_destroy(ctx); return code; };
+
+    if (cfg->stream) {
+        ctx->stream = (hipStream_t)cfg->stream;
+        ctx->own_stream = false;
+    } else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return fail(set_err(TL3D_E_HIP, "stream create failed"));
+        ctx->own_stream = true;
+    }
+    if (cfg->channels) {
+        g.nx = cfg->nx; g.ny = cfg->ny; g.nz = cfg->nz;
+        g.nbx = cfg->nx / 8; g.nby = cfg->ny / 8; g.nbz = cfg->nz / 8;
+        g.oxd = cfg->origin[0]; g.oyd = cfg->origin[1]; g.ozd = cfg->origin[2]; g.vsd = cfg->voxel_size;
+        g.ox = (float)g.oxd; g.oy = (float)g.oyd; g.oz = (float)g.ozd; g.vs = (float)g.vsd;
+        g.trunc = (float)cfg->sdf_trunc;
+        g.inv_trunc = (cfg->channels & TL3D_CH_TSDF) ? 1.0f / g.trunc : 0.0f;
+        ctx->nvox = (size_t)g.nx * g.ny * g.nz;
+        if (cfg->channels & TL3D_CH_TSDF) {
+            if (cfg->ext_tsdf) {
+                ctx->tsdf = (int2 *)cfg->ext_tsdf;
+            } else {
+                if (hipMalloc(&ctx->tsdf, ctx->nvox * sizeof(int2)) != hipSuccess) return fail(set_err(TL3D_E_NOMEM, "TSDF grid alloc (%zu B) failed", ctx->nvox * 8));
+                ctx->own_tsdf = true;
+                if (hipMemsetAsync(ctx->tsdf, 0, ctx->nvox * sizeof(int2), ctx->stream) != hipSuccess) return fail(set_err(TL3D_E_HIP, "memset failed"));
+            }
+        }
+        if (cfg->channels & TL3D_CH_CENTROID) {
+            if (cfg->ext_centroid) {
+                ctx->centroid = (unsigned long long *)cfg->ext_centroid;
+            } else {
+                if (hipMalloc(&ctx->centroid, ctx->nvox * 32) != hipSuccess) return fail(set_err(TL3D_E_NOMEM, "centroid grid alloc (%zu B) failed", ctx->nvox * 32));
+                ctx->own_centroid = true;
+                if (hipMemsetAsync(ctx->centroid, 0, ctx->nvox * 32, ctx->stream) != hipSuccess) return fail(set_err(TL3D_E_HIP, "memset failed"));
+            }
+        }
+    }
+    if (hipMalloc(&ctx->d_counters, 16 * sizeof(unsigned long long)) != hipSuccess) return fail(set_err(TL3D_E_NOMEM, "alloc failed"));
+    if (hipMemsetAsync(ctx->d_counters, 0, 16 * sizeof(unsigned long long), ctx->stream) != hipSuccess) return fail(set_err(TL3D_E_HIP, "memset failed"));
+    if (hipMalloc(&ctx->icp_slab, (size_t)ICP_MAX_BLOCKS * ICP_SLAB * sizeof(double)) != hipSuccess) return fail(set_err(TL3D_E_NOMEM, "alloc failed"));
+    if (hipMalloc(&ctx->icp_state, sizeof(IcpState)) != hipSuccess) return fail(set_err(TL3D_E_NOMEM, "alloc failed"));
+    if (hipMalloc(&ctx->bounds_slab, 1024 * 6 * sizeof(float)) != hipSuccess) return fail(set_err(TL3D_E_NOMEM, "alloc failed"));
+    for (int i = 0; i < 2; ++i)
+        if (hipEventCreate(&ctx->ev[i]) != hipSuccess) return fail(set_err(TL3D_E_HIP, "event create failed"));
+    (void)rc;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(set_err(TL3D_E_HIP, "sync failed"));
+    *out = ctx;
+    return TL3D_OK;
+}
+
+int tl3d_destroy(tl3d_ctx *ctx) {
+    if (!ctx) return TL3D_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->slots) {
+        for (int i = 0; i < ctx->cfg.n_slots; ++i) {
+            if (ctx->slots[i].depth) (void)hipFree(ctx->slots[i].depth);
+            if (ctx->slots[i].bgr) (void)hipFree(ctx->slots[i].bgr);
+            if (ctx->slots[i].nmap) (void)hipFree(ctx->slots[i].nmap);
+        }
+        delete[] ctx->slots;
+    }
+    if (ctx->own_tsdf && ctx->tsdf) (void)hipFree(ctx->tsdf);
+    if (ctx->own_centroid && ctx->centroid) (void)hipFree(ctx->centroid);
+    if (ctx->stage_u16) (void)hipFree(ctx->stage_u16);
+    if (ctx->block_counts) (void)hipFree(ctx->block_counts);
+    if (ctx->block_offsets) (void)hipFree(ctx->block_offsets);
+    if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+    if (ctx->icp_slab) (void)hipFree(ctx->icp_slab);
+    if (ctx->icp_state) (void)hipFree(ctx->icp_state);
+    if (ctx->bounds_slab) (void)hipFree(ctx->bounds_slab);
+    for (int i = 0; i < 2; ++i)
+        if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->ktimers) {
+        for (int i = 0; i < ctx->n_ktimers; ++i) {
+            (void)hipEventDestroy(ctx->ktimers[i].a);
+            (void)hipEventDestroy(ctx->ktimers[i].b);
+        }
+        delete[] ctx->ktimers;
+    }
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return TL3D_OK;
+}
+
+int tl3d_sync(tl3d_ctx *ctx) {
+    REQUIRE(ctx != nullptr, TL3D_E_INVALID, "null ctx");
+    TL3D_HIP(hipSetDevice(ctx->device));
+    TL3D_HIP(hipStreamSynchronize(ctx->stream));
+    return TL3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------- frames
+int tl3d_upload_frame(tl3d_ctx *ctx, int slot, const void *depth_hd, int depth_kind, const uint8_t *bgr_hd) {
+    int rc = check_slot(ctx, slot, false);
+    if (rc) return rc;
+    REQUIRE(depth_hd != nullptr, TL3D_E_INVALID, "null depth");
+    REQUIRE(depth_kind == TL3D_DEPTH_F32_M || depth_kind == TL3D_DEPTH_U16_MM, TL3D_E_INVALID, "bad depth_kind %d", depth_kind);
+    TL3D_HIP(hipSetDevice(ctx->device));
+    Slot &s = ctx->slots[slot];
+    const size_t npx = (size_t)ctx->cam.W * ctx->cam.H;
+    if (!s.depth && hipMalloc(&s.depth, npx * sizeof(float)) != hipSuccess) return set_err(TL3D_E_NOMEM, "frame alloc failed");
+    if (depth_kind == TL3D_DEPTH_F32_M) {
+        TL3D_HIP(hipMemcpyAsync(s.depth, depth_hd, npx * sizeof(float), hipMemcpyDefault, ctx->stream));
+    } else {
+        if (!ctx->stage_u16 && hipMalloc(&ctx->stage_u16, npx * sizeof(uint16_t)) != hipSuccess) return set_err(TL3D_E_NOMEM, "staging alloc failed");
+        TL3D_HIP(hipMemcpyAsync(ctx->stage_u16, depth_hd, npx * sizeof(uint16_t), hipMemcpyDefault, ctx->stream));
+        rc = launch_u16_to_f32(ctx->stream, ctx->stage_u16, s.depth, npx);
+        if (rc) return rc;
+    }
+    if (bgr_hd) {
+        if (!s.bgr && hipMalloc(&s.bgr, npx * 3) != hipSuccess) return set_err(TL3D_E_NOMEM, "frame alloc failed");
+        TL3D_HIP(hipMemcpyAsync(s.bgr, bgr_hd, npx * 3, hipMemcpyDefault, ctx->stream));
+        s.has_color = true;
+    } else {
+        s.has_color = false;
+    }
+    s.loaded = true;
+    s.has_normals = false;
+    // pageable host sources are consumed before hipMemcpyAsync returns only for small copies; make the hand-over explicit
+    if (!is_device_ptr(depth_hd) || (bgr_hd && !is_device_ptr(bgr_hd))) TL3D_HIP(hipStreamSynchronize(ctx->stream));
+    return TL3D_OK;
+}
+
+int tl3d_download_depth(tl3d_ctx *ctx, int slot, float *out) {
+    int rc = check_slot(ctx, slot, true);
+    if (rc) return rc;
+    REQUIRE(out != nullptr, TL3D_E_INVALID, "null out");
+    TL3D_HIP(hipSetDevice(ctx->device));
+    TL3D_HIP(hipMemcpyAsync(out, ctx->slots[slot].depth, (size_t)ctx->cam.W * ctx->cam.H * sizeof(float), hipMemcpyDefault, ctx->stream));
+    TL3D_HIP(hipStreamSynchronize(ctx->stream));
+    return TL3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------- back-projection
+static int make_bp_args(tl3d_ctx *ctx, double scale, uint32_t flags, int subsample, double min_d, double max_d, BpArgs *a) {
+    REQUIRE(subsample >= 1, TL3D_E_INVALID, "subsample must be >= 1");
+    REQUIRE((flags & ~(TL3D_F_SCALE_F64 | TL3D_F_NO_POSE)) == 0, TL3D_E_INVALID, "unknown flags 0x%x", flags);
+    a->sub = subsample;
+    a->Ws = (ctx->cam.W + subsample - 1) / subsample;
+    a->Hs = (ctx->cam.H + subsample - 1) / subsample;
+    a->flags = flags;
+    a->scale = scale;
+    a->min_d = min_d;
+    a->max_d = max_d;
+    return TL3D_OK;
+}
+
+int tl3d_backproject(tl3d_ctx *ctx, int slot, const double R[9], const double t[3], double scale, uint32_t flags,
+                     int subsample, double min_depth, double max_depth, float *out_xyz, uint8_t *out_rgb, int64_t cap,
+                     int64_t *out_n) {
+    int rc = check_slot(ctx, slot, true);
+    if (rc) return rc;
+    REQUIRE(out_n != nullptr, TL3D_E_INVALID, "null out_n");
+    REQUIRE((flags & TL3D_F_NO_POSE) || (R && t), TL3D_E_INVALID, "pose required unless TL3D_F_NO_POSE");
+    BpArgs a;
+    rc = make_bp_args(ctx, scale, flags, subsample, min_depth, max_depth, &a);
+    if (rc) return rc;
+    TL3D_HIP(hipSetDevice(ctx->device));
+    const Slot &s = ctx->slots[slot];
+    const long long ns = (long long)a.Ws * a.Hs;
+    const int nblocks = (int)((ns + 255) / 256);
+    rc = ensure_scratch_blocks(ctx, (size_t)nblocks + 1);
+    if (rc) return rc;
+    rc = launch_bp_count(ctx->stream, ctx->cam, a, s.depth, ctx->block_counts, nblocks);
+    if (rc) return rc;
+    rc = launch_scan(ctx->stream, ctx->block_counts, ctx->block_offsets, nblocks, ctx->block_offsets + nblocks);
+    if (rc) return rc;
+    unsigned long long total = 0;
+    TL3D_HIP(hipMemcpyAsync(&total, ctx->block_offsets + nblocks, sizeof(total), hipMemcpyDeviceToHost, ctx->stream));
+    TL3D_HIP(hipStreamSynchronize(ctx->stream));
+    *out_n = (int64_t)total;
+    if (!out_xyz || !out_rgb) return TL3D_OK;                       // size query
+    if ((int64_t)total > cap) return set_err(TL3D_E_CAPACITY, "need %llu points, capacity %lld", total, (long long)cap);
+    if (total == 0) return TL3D_OK;
+    const PoseD p = make_pose_d(R, t, (flags & TL3D_F_NO_POSE) != 0);
+    const bool direct = is_device_ptr(out_xyz) && is_device_ptr(out_rgb);
+    float *dxyz = out_xyz;
+    uint8_t *drgb = out_rgb;
+    if (!direct) {
+        if (hipMalloc(&dxyz, total * 3 * sizeof(float)) != hipSuccess) return set_err(TL3D_E_NOMEM, "output staging alloc failed");
+        if (hipMalloc(&drgb, total * 3) != hipSuccess) { (void)hipFree(dxyz); return set_err(TL3D_E_NOMEM, "output staging alloc failed"); }
+    }
+    rc = launch_bp_write(ctx->stream, ctx->cam, a, p, s.depth, s.has_color ? s.bgr : nullptr, ctx->block_offsets, nblocks, dxyz, drgb, total);
+    hipError_t e = hipSuccess;
+    if (rc == TL3D_OK && !direct) {
+        e = hipMemcpyAsync(out_xyz, dxyz, total * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(out_rgb, drgb, total * 3, hipMemcpyDeviceToHost, ctx->stream);
+    }
+    hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    if (!direct) { (void)hipFree(dxyz); (void)hipFree(drgb); }
+    if (rc) return rc;
+    if (e != hipSuccess || e2 != hipSuccess) return set_err(TL3D_E_HIP, "back-projection copy/sync failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+    return TL3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------- centroid accumulation
+int tl3d_accumulate_centroid(tl3d_ctx *ctx, int slot, const double R[9], const double t[3], double scale, uint32_t flags,
+                             int subsample, double min_depth, double max_depth) {
+    int rc = check_slot(ctx, slot, true);
+    if (rc) return rc;
+    REQUIRE(ctx->centroid != nullptr, TL3D_E_STATE, "centroid channel not enabled");
+    REQUIRE((flags & TL3D_F_NO_POSE) || (R && t), TL3D_E_INVALID, "pose required unless TL3D_F_NO_POSE");
+    BpArgs a;
+    rc = make_bp_args(ctx, scale, flags, subsample, min_depth, max_depth, &a);
+    if (rc) return rc;
+    TL3D_HIP(hipSetDevice(ctx->device));
+    const Slot &s = ctx->slots[slot];
+    const PoseD p = make_pose_d(R, t, (flags & TL3D_F_NO_POSE) != 0);
+    rc = launch_centroid_frame(ctx->stream, ctx->cam, ctx->grid, a, p, s.depth, s.has_color ? s.bgr : nullptr, ctx->centroid, ctx->d_counters);
+    if (rc) return rc;
+    ctx->stats.centroid_launches++;
+    return TL3D_OK;
+}
+
+int tl3d_accumulate_points(tl3d_ctx *ctx, const float *xyz, const uint8_t *rgb, int64_t n) {
+    REQUIRE(ctx != nullptr, TL3D_E_INVALID, "null ctx");
+    REQUIRE(ctx->centroid != nullptr, TL3D_E_STATE, "centroid channel not enabled");
+    REQUIRE(n >= 0 && (n == 0 || (xyz && rgb)), TL3D_E_INVALID, "bad point list");
+    if (n == 0) return TL3D_OK;
+    TL3D_HIP(hipSetDevice(ctx->device));
+    const bool direct = is_device_ptr(xyz) && is_device_ptr(rgb);
+    const float *dxyz = xyz;
+    const uint8_t *drgb = rgb;
+    float *tx = nullptr;
+    uint8_t *tc = nullptr;
+    if (!direct) {
+        if (hipMalloc(&tx, (size_t)n * 12) != hipSuccess) return set_err(TL3D_E_NOMEM, "point staging alloc failed");
+        if (hipMalloc(&tc, (size_t)n * 3) != hipSuccess) { (void)hipFree(tx); return set_err(TL3D_E_NOMEM, "point staging alloc failed"); }
+        hipError_t e = hipMemcpyAsync(tx, xyz, (size_t)n * 12, hipMemcpyDefault, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(tc, rgb, (size_t)n * 3, hipMemcpyDefault, ctx->stream);
+        if (e != hipSuccess) { (void)hipFree(tx); (void)hipFree(tc); return set_err(TL3D_E_HIP, "point upload failed: %s", hipGetErrorString(e)); }
+        dxyz = tx;
+        drgb = tc;
+    }
+    int rc = launch_centroid_points(ctx->stream, ctx->grid, dxyz, drgb, n, ctx->centroid, ctx->d_counters);
+    if (!direct) {
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(tx);
+        (void)hipFree(tc);
+        if (rc == TL3D_OK && e != hipSuccess) return set_err(TL3D_E_HIP, "sync failed: %s", hipGetErrorString(e));
+    }
+    if (rc) return rc;
+    ctx->stats.centroid_launches++;
+    return TL3D_OK;
+}
+
+int tl3d_points_bounds(tl3d_ctx *ctx, const float *xyz, int64_t n, double out_min[3], double out_max[3]) {
+    REQUIRE(ctx && xyz && out_min && out_max, TL3D_E_INVALID, "null argument");
+    REQUIRE(n > 0, TL3D_E_INVALID, "empty point list has no bounds");
+    TL3D_HIP(hipSetDevice(ctx->device));
+    const bool direct = is_device_ptr(xyz);
+    const float *d = xyz;
+    float *tx = nullptr;
+    if (!direct) {
+        if (hipMalloc(&tx, (size_t)n * 12) != hipSuccess) return set_err(TL3D_E_NOMEM, "point staging alloc failed");
+        hipError_t e = hipMemcpyAsync(tx, xyz, (size_t)n * 12, hipMemcpyDefault, ctx->stream);
+        if (e != hipSuccess) { (void)hipFree(tx); return set_err(TL3D_E_HIP, "point upload failed"); }
+        d = tx;
+    }
+    int nb = (int)((n + 255) / 256);
+    if (nb > 1024) nb = 1024;
+    int rc = launch_bounds(ctx->stream, d, n, ctx->bounds_slab, nb);
+    std::vector<float> h((size_t)nb * 6);
+    hipError_t e = hipMemcpyAsync(h.data(), ctx->bounds_slab, h.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    if (tx) (void)hipFree(tx);
+    if (rc) return rc;
+    if (e != hipSuccess || e2 != hipSuccess) return set_err(TL3D_E_HIP, "bounds read-back failed");
+    for (int a = 0; a < 3; ++a) { out_min[a] = INFINITY; out_max[a] = -INFINITY; }
+    for (int b = 0; b < nb; ++b)
+        for (int a = 0; a < 3; ++a) {
+            out_min[a] = fmin(out_min[a], (double)h[(size_t)b * 6 + a]);
+            out_max[a] = fmax(out_max[a], (double)h[(size_t)b * 6 + 3 + a]);
+        }
+    return TL3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------- TSDF
+static int ktimer_begin(tl3d_ctx *ctx) {
+    if (!ctx->time_kernels) return -1;
+    if (!ctx->ktimers) {
+        ctx->n_ktimers = 1024;
+        ctx->ktimers = new (std::nothrow) tl3d_ctx::KTimer[ctx->n_ktimers];
+        if (!ctx->ktimers) return -1;
+        for (int i = 0; i < ctx->n_ktimers; ++i) {
+            (void)hipEventCreate(&ctx->ktimers[i].a);
+            (void)hipEventCreate(&ctx->ktimers[i].b);
+        }
+        ctx->ktimers_used = 0;
+    }
+    if (ctx->ktimers_used == ctx->n_ktimers) {          // drain
+        (void)hipStreamSynchronize(ctx->stream);
+        for (int i = 0; i < ctx->ktimers_used; ++i) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, ctx->ktimers[i].a, ctx->ktimers[i].b) == hipSuccess) {
+                ctx->stats.tsdf_kernel_ms += ms;
+                ctx->stats.tsdf_kernel_timed++;
+            }
+        }
+        ctx->ktimers_used = 0;
+    }
+    const int id = ctx->ktimers_used++;
+    (void)hipEventRecord(ctx->ktimers[id].a, ctx->stream);
+    return id;
+}
+
+int tl3d_integrate(tl3d_ctx *ctx, int slot, const double R[9], const double t[3], double scale) {
+    int rc = check_slot(ctx, slot, true);
+    if (rc) return rc;
+    REQUIRE(ctx->tsdf != nullptr, TL3D_E_STATE, "TSDF channel not enabled");
+    REQUIRE(R && t, TL3D_E_INVALID, "null pose");
+    TL3D_HIP(hipSetDevice(ctx->device));
+    const PoseF p = make_pose_f(R, t);
+    const Frustum fr = make_frustum(ctx->cam);
+    const int kt = ktimer_begin(ctx);
+    rc = launch_tsdf_integrate(ctx->stream, ctx->cam, ctx->grid, p, fr, ctx->slots[slot].depth, (float)scale,
+                               (float)ctx->cfg.min_depth, (float)ctx->cfg.max_depth, ctx->tsdf, ctx->d_counters, ctx->count_records);
+    if (kt >= 0) (void)hipEventRecord(ctx->ktimers[kt].b, ctx->stream);
+    if (rc) return rc;
+    ctx->stats.tsdf_launches++;
+    return TL3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------- normals + ICP
+int tl3d_build_normals(tl3d_ctx *ctx, int slot, double scale, double depth_jump) {
+    int rc = check_slot(ctx, slot, true);
+    if (rc) return rc;
+    TL3D_HIP(hipSetDevice(ctx->device));
+    Slot &s = ctx->slots[slot];
+    const size_t npx = (size_t)ctx->cam.W * ctx->cam.H;
+    if (!s.nmap && hipMalloc(&s.nmap, npx * sizeof(float4)) != hipSuccess) return set_err(TL3D_E_NOMEM, "normal map alloc failed");
+    rc = launch_normals(ctx->stream, ctx->cam, s.depth, (float)scale, (float)ctx->cfg.min_depth, (float)ctx->cfg.max_depth,
+                        (float)depth_jump, s.nmap);
+    if (rc) return rc;
+    s.has_normals = true;
+    return TL3D_OK;
+}
+
+int tl3d_download_normals(tl3d_ctx *ctx, int slot, float *out) {
+    int rc = check_slot(ctx, slot, true);
+    if (rc) return rc;
+    REQUIRE(out != nullptr, TL3D_E_INVALID, "null out");
+    REQUIRE(ctx->slots[slot].has_normals, TL3D_E_STATE, "slot %d has no normal map (call tl3d_build_normals)", slot);
+    TL3D_HIP(hipSetDevice(ctx->device));
+    TL3D_HIP(hipMemcpyAsync(out, ctx->slots[slot].nmap, (size_t)ctx->cam.W * ctx->cam.H * sizeof(float4), hipMemcpyDefault, ctx->stream));
+    TL3D_HIP(hipStreamSynchronize(ctx->stream));
+    return TL3D_OK;
+}
+
+int tl3d_icp_p2plane(tl3d_ctx *ctx, int slot_src, double scale_src, int slot_tgt, const double T_init[16],
+                     const tl3d_icp_params *prm, tl3d_icp_result *out) {
+    int rc = check_slot(ctx, slot_src, true);
+    if (rc) return rc;
+    rc = check_slot(ctx, slot_tgt, true);
+    if (rc) return rc;
+    REQUIRE(prm && out, TL3D_E_INVALID, "null argument");
+    REQUIRE(prm->iters >= 0 && prm->iters <= 1000, TL3D_E_INVALID, "iters out of range");
+    REQUIRE(prm->stride >= 1, TL3D_E_INVALID, "stride must be >= 1");
+    REQUIRE(prm->max_dist > 0, TL3D_E_INVALID, "max_dist must be positive");
+    REQUIRE(ctx->slots[slot_tgt].has_normals, TL3D_E_STATE, "target slot %d has no normal map (call tl3d_build_normals)", slot_tgt);
+    TL3D_HIP(hipSetDevice(ctx->device));
+    IcpState h;
+    memset(&h, 0, sizeof(h));
+    if (T_init) {
+        memcpy(h.T, T_init, sizeof(h.T));
+    } else {
+        h.T[0] = h.T[5] = h.T[10] = h.T[15] = 1.0;
+    }
+    TL3D_HIP(hipMemcpyAsync(ctx->icp_state, &h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
+    TL3D_HIP(hipStreamSynchronize(ctx->stream));      // h is a stack object
+    const int Ws = (ctx->cam.W + prm->stride - 1) / prm->stride, Hs = (ctx->cam.H + prm->stride - 1) / prm->stride;
+    long long nb = ((long long)Ws * Hs + 255) / 256;
+    if (nb > ICP_MAX_BLOCKS) nb = ICP_MAX_BLOCKS;
+    if (nb < 1) nb = 1;
+    const float mind = (float)ctx->cfg.min_depth, maxd = (float)ctx->cfg.max_depth;
+    for (int it = 0; it <= prm->iters; ++it) {
+        const int final_pass = (it == prm->iters);
+        rc = launch_icp_iteration(ctx->stream, ctx->cam, ctx->slots[slot_src].depth, (float)scale_src, mind, maxd,
+                                  ctx->slots[slot_tgt].nmap, prm->stride, (float)prm->max_dist, prm->damping, prm->eps,
+                                  final_pass, ctx->icp_slab, ctx->icp_state, (int)nb);
+        if (rc) return rc;
+    }
+    TL3D_HIP(hipMemcpyAsync(&h, ctx->icp_state, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    TL3D_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(out->T, h.T, sizeof(out->T));
+    out->n_corr = (int64_t)h.sums[28];
+    out->n_src = (int64_t)h.sums[29];
+    out->fitness = h.sums[29] > 0 ? h.sums[28] / h.sums[29] : 0.0;
+    out->rmse = h.sums[28] > 0 ? sqrt(h.sums[27] / h.sums[28]) : 0.0;
+    out->iters_run = h.iters_run;
+    out->status = h.status;
+    return TL3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------- grids
+static int grid_sel(tl3d_ctx *ctx, uint32_t channel, void **p, size_t *bytes) {
+    REQUIRE(ctx != nullptr, TL3D_E_INVALID, "null ctx");
+    if (channel == TL3D_CH_TSDF) {
+        REQUIRE(ctx->tsdf != nullptr, TL3D_E_STATE, "TSDF channel not enabled");
+        *p = ctx->tsdf;
+        *bytes = ctx->nvox * sizeof(int2);
+    } else if (channel == TL3D_CH_CENTROID) {
+        REQUIRE(ctx->centroid != nullptr, TL3D_E_STATE, "centroid channel not enabled");
+        *p = ctx->centroid;
+        *bytes = ctx->nvox * 32;
+    } else {
+        return set_err(TL3D_E_INVALID, "channel must be exactly one of TL3D_CH_TSDF / TL3D_CH_CENTROID");
+    }
+    return TL3D_OK;
+}
+
+int tl3d_grid_reset(tl3d_ctx *ctx) {
+    REQUIRE(ctx != nullptr, TL3D_E_INVALID, "null ctx");
+    TL3D_HIP(hipSetDevice(ctx->device));
+    if (ctx->tsdf) TL3D_HIP(hipMemsetAsync(ctx->tsdf, 0, ctx->nvox * sizeof(int2), ctx->stream));
+    if (ctx->centroid) TL3D_HIP(hipMemsetAsync(ctx->centroid, 0, ctx->nvox * 32, ctx->stream));
+    return TL3D_OK;
+}
+
+int tl3d_grid_device_ptr(tl3d_ctx *ctx, uint32_t channel, void **ptr, size_t *bytes) {
+    REQUIRE(ptr && bytes, TL3D_E_INVALID, "null out pointer");
+    return grid_sel(ctx, channel, ptr, bytes);
+}
+
+int tl3d_grid_download(tl3d_ctx *ctx, uint32_t channel, void *out, size_t bytes) {
+    void *p;
+    size_t nb;
+    int rc = grid_sel(ctx, channel, &p, &nb);
+    if (rc) return rc;
+    REQUIRE(out && bytes == nb, TL3D_E_INVALID, "buffer is %zu B, grid channel is %zu B", bytes, nb);
+    TL3D_HIP(hipSetDevice(ctx->device));
+    TL3D_HIP(hipMemcpyAsync(out, p, nb, hipMemcpyDefault, ctx->stream));
+    TL3D_HIP(hipStreamSynchronize(ctx->stream));
+    return TL3D_OK;
+}
+
+int tl3d_grid_upload(tl3d_ctx *ctx, uint32_t channel, const void *in, size_t bytes) {
+    void *p;
+    size_t nb;
+    int rc = grid_sel(ctx, channel, &p, &nb);
+    if (rc) return rc;
+    REQUIRE(in && bytes == nb, TL3D_E_INVALID, "buffer is %zu B, grid channel is %zu B", bytes, nb);
+    TL3D_HIP(hipSetDevice(ctx->device));
+    TL3D_HIP(hipMemcpyAsync(p, in, nb, hipMemcpyDefault, ctx->stream));
+    TL3D_HIP(hipStreamSynchronize(ctx->stream));
+    return TL3D_OK;
+}
+
+int tl3d_grid_add(tl3d_ctx *ctx, uint32_t channel, const void *other, size_t bytes) {
+    void *p;
+    size_t nb;
+    int rc = grid_sel(ctx, channel, &p, &nb);
+    if (rc) return rc;
+    REQUIRE(other && bytes == nb, TL3D_E_INVALID, "buffer is %zu B, grid channel is %zu B", bytes, nb);
+    TL3D_HIP(hipSetDevice(ctx->device));
+    const void *src = other;
+    void *tmp = nullptr;
+    if (!is_device_ptr(other)) {
+        if (hipMalloc(&tmp, nb) != hipSuccess) return set_err(TL3D_E_NOMEM, "grid staging alloc failed");
+        hipError_t e = hipMemcpyAsync(tmp, other, nb, hipMemcpyDefault, ctx->stream);
+        if (e != hipSuccess) { (void)hipFree(tmp); return set_err(TL3D_E_HIP, "grid upload failed"); }
+        src = tmp;
+    }
+    if (channel == TL3D_CH_TSDF)
+        rc = launch_add_i32(ctx->stream, (int *)p, (const int *)src, nb / 4);
+    else
+        rc = launch_add_u64(ctx->stream, (unsigned long long *)p, (const unsigned long long *)src, nb / 8);
+    if (tmp) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(tmp);
+    }
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------- extraction
+int tl3d_extract(tl3d_ctx *ctx, int mode, int min_count, int min_weight, double max_abs_tsdf, float *out_xyz,
+                 uint8_t *out_rgb, int64_t cap, int64_t *out_n) {
+    REQUIRE(ctx && out_n, TL3D_E_INVALID, "null argument");
+    REQUIRE(mode == TL3D_EXTRACT_CENTROID || mode == TL3D_EXTRACT_TSDF, TL3D_E_INVALID, "bad mode %d", mode);
+    if (mode == TL3D_EXTRACT_CENTROID) REQUIRE(ctx->centroid != nullptr, TL3D_E_STATE, "centroid channel not enabled");
+    if (mode == TL3D_EXTRACT_TSDF) REQUIRE(ctx->tsdf != nullptr, TL3D_E_STATE, "TSDF channel not enabled");
+    TL3D_HIP(hipSetDevice(ctx->device));
+    const int nblocks = (int)((ctx->nvox + EXTRACT_CHUNK - 1) / EXTRACT_CHUNK);
+    int rc = ensure_scratch_blocks(ctx, (size_t)nblocks + 1);
+    if (rc) return rc;
+    rc = launch_extract_count(ctx->stream, ctx->grid, mode, min_count, min_weight, max_abs_tsdf, ctx->tsdf, ctx->centroid, ctx->block_counts, nblocks);
+    if (rc) return rc;
+    rc = launch_scan(ctx->stream, ctx->block_counts, ctx->block_offsets, nblocks, ctx->block_offsets + nblocks);
+    if (rc) return rc;
+    unsigned long long total = 0;
+    TL3D_HIP(hipMemcpyAsync(&total, ctx->block_offsets + nblocks, sizeof(total), hipMemcpyDeviceToHost, ctx->stream));
+    TL3D_HIP(hipStreamSynchronize(ctx->stream));
+    *out_n = (int64_t)total;
+    if (!out_xyz || !out_rgb) return TL3D_OK;
+    if ((int64_t)total > cap) return set_err(TL3D_E_CAPACITY, "need %llu points, capacity %lld", total, (long long)cap);
+    if (total == 0) return TL3D_OK;
+    const bool direct = is_device_ptr(out_xyz) && is_device_ptr(out_rgb);
+    float *dxyz = out_xyz;
+    uint8_t *drgb = out_rgb;
+    if (!direct) {
+        if (hipMalloc(&dxyz, total * 12) != hipSuccess) return set_err(TL3D_E_NOMEM, "output staging alloc failed");
+        if (hipMalloc(&drgb, total * 3) != hipSuccess) { (void)hipFree(dxyz); return set_err(TL3D_E_NOMEM, "output staging alloc failed"); }
+    }
+    rc = launch_extract_write(ctx->stream, ctx->grid, mode, min_count, min_weight, max_abs_tsdf, ctx->tsdf, ctx->centroid,
+                              ctx->block_offsets, nblocks, dxyz, drgb, total);
+    hipError_t e = hipSuccess;
+    if (rc == TL3D_OK && !direct) {
+        e = hipMemcpyAsync(out_xyz, dxyz, total * 12, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(out_rgb, drgb, total * 3, hipMemcpyDeviceToHost, ctx->stream);
+    }
+    hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    if (!direct) { (void)hipFree(dxyz); (void)hipFree(drgb); }
+    if (rc) return rc;
+    if (e != hipSuccess || e2 != hipSuccess) return set_err(TL3D_E_HIP, "extract copy/sync failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+    return TL3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------- outlier filter
+int tl3d_statistical_outlier(tl3d_ctx *ctx, const float *xyz, int64_t n, int nb_neighbors, double std_ratio,
+                             double cell_size, uint8_t *keep_out, int64_t *out_kept) {
+    REQUIRE(ctx && keep_out && out_kept, TL3D_E_INVALID, "null argument");
+    REQUIRE(n >= 0 && (n == 0 || xyz), TL3D_E_INVALID, "bad point list");
+    REQUIRE(nb_neighbors >= 1 && nb_neighbors <= 64, TL3D_E_INVALID, "nb_neighbors must be in [1,64]");
+    REQUIRE(cell_size > 0, TL3D_E_INVALID, "cell_size must be positive");
+    *out_kept = 0;
+    if (n == 0) return TL3D_OK;
+    TL3D_HIP(hipSetDevice(ctx->device));
+    const bool din = is_device_ptr(xyz), dout = is_device_ptr(keep_out);
+    float *tx = nullptr;
+    uint8_t *tk = nullptr;
+    const float *dx = xyz;
+    uint8_t *dk = keep_out;
+    if (!din) {
+        if (hipMalloc(&tx, (size_t)n * 12) != hipSuccess) return set_err(TL3D_E_NOMEM, "staging alloc failed");
+        if (hipMemcpyAsync(tx, xyz, (size_t)n * 12, hipMemcpyDefault, ctx->stream) != hipSuccess) { (void)hipFree(tx); return set_err(TL3D_E_HIP, "upload failed"); }
+        dx = tx;
+    }
+    if (!dout) {
+        if (hipMalloc(&tk, (size_t)n) != hipSuccess) { if (tx) (void)hipFree(tx); return set_err(TL3D_E_NOMEM, "staging alloc failed"); }
+        dk = tk;
+    }
+    long long kept = 0;
+    int rc = sor_run(ctx, dx, n, nb_neighbors, std_ratio, cell_size, dk, &kept);
+    if (rc == TL3D_OK && !dout) {
+        if (hipMemcpyAsync(keep_out, dk, (size_t)n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = set_err(TL3D_E_HIP, "download failed");
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    if (tx) (void)hipFree(tx);
+    if (tk) (void)hipFree(tk);
+    if (rc) return rc;
+    *out_kept = kept;
+    return TL3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------- measurement
+int tl3d_set_profile(tl3d_ctx *ctx, int count_records, int time_kernels) {
+    REQUIRE(ctx != nullptr, TL3D_E_INVALID, "null ctx");
+    ctx->count_records = count_records != 0;
+    ctx->time_kernels = time_kernels != 0;
+    return TL3D_OK;
+}
+
+int tl3d_get_stats(tl3d_ctx *ctx, tl3d_stats *out) {
+    REQUIRE(ctx && out, TL3D_E_INVALID, "null argument");
+    TL3D_HIP(hipSetDevice(ctx->device));
+    unsigned long long h[16];
+    TL3D_HIP(hipMemcpyAsync(h, ctx->d_counters, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    TL3D_HIP(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < ctx->ktimers_used; ++i) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ctx->ktimers[i].a, ctx->ktimers[i].b) == hipSuccess) {
+            ctx->stats.tsdf_kernel_ms += ms;
+            ctx->stats.tsdf_kernel_timed++;
+        }
+    }
+    ctx->ktimers_used = 0;
+    ctx->stats.centroid_points = h[0];
+    ctx->stats.centroid_dropped = h[1];
+    ctx->stats.tsdf_records_read = h[2];
+    ctx->stats.tsdf_records_written = h[3];
+    ctx->stats.tsdf_bricks_visited = h[4];
+    *out = ctx->stats;
+    return TL3D_OK;
+}
+
+int tl3d_reset_stats(tl3d_ctx *ctx) {
+    REQUIRE(ctx != nullptr, TL3D_E_INVALID, "null ctx");
+    TL3D_HIP(hipSetDevice(ctx->device));
+    TL3D_HIP(hipStreamSynchronize(ctx->stream));
+    TL3D_HIP(hipMemsetAsync(ctx->d_counters, 0, 16 * sizeof(unsigned long long), ctx->stream));
+    memset(&ctx->stats, 0, sizeof(ctx->stats));
+    ctx->ktimers_used = 0;
+    return TL3D_OK;
+}
+
+int tl3d_event_record(tl3d_ctx *ctx, int which) {
+    REQUIRE(ctx != nullptr && (which == 0 || which == 1), TL3D_E_INVALID, "bad argument");
+    TL3D_HIP(hipSetDevice(ctx->device));
+    TL3D_HIP(hipEventRecord(ctx->ev[which], ctx->stream));
+    return TL3D_OK;
+}
+
+int tl3d_event_elapsed_ms(tl3d_ctx *ctx, float *ms) {
+    REQUIRE(ctx && ms, TL3D_E_INVALID, "null argument");
+    TL3D_HIP(hipSetDevice(ctx->device));
+    TL3D_HIP(hipEventSynchronize(ctx->ev[1]));
+    TL3D_HIP(hipEventElapsedTime(ms, ctx->ev[0], ctx->ev[1]));
+    return TL3D_OK;
+}
+
+}  // extern "C"

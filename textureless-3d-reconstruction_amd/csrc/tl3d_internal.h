@@ -1,0 +1,157 @@
+// tl3d_internal.h -- shared declarations of libtl3d.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/tl3d.h"
+
+namespace tl3d {
+
+// ---- parameter blocks passed to kernels by value ---------------------------------------------
+struct Cam {
+    int W, H;
+    float fx, fy, cx, cy;        // f32 path (TSDF, normals, ICP)
+    double fxd, fyd, cxd, cyd;   // fp64 path (reference-exact back-projection)
+};
+
+struct Grid {
+    int nx, ny, nz;              // voxels
+    int nbx, nby, nbz;           // bricks (8^3 voxels)
+    float ox, oy, oz, vs;        // f32 origin / voxel size (TSDF path)
+    double oxd, oyd, ozd, vsd;   // fp64 (centroid path, Open3D index semantics)
+    float trunc, inv_trunc;
+};
+
+struct PoseF {                   // world->camera, f32 (or src->tgt for ICP)
+    float r[9];
+    float t[3];
+};
+
+struct PoseD {                   // fp64 R (row-major) and ct = R^T t, for the back-projection path
+    double r[9];
+    double ct[3];
+};
+
+struct BpArgs {                  // back-projection arguments common to count / write / centroid kernels
+    int sub, Ws, Hs;             // stride and subsampled extent (ceil)
+    unsigned flags;
+    double scale, min_d, max_d;
+};
+
+// frustum side planes for brick culling: inside iff nx*x + nz*z >= -rad (left/right), ny*y + nz*z >= -rad
+struct Frustum {
+    float lx, lz, rx, rz, ty, tz, by, bz;
+};
+
+struct IcpState {                // lives in device memory for the whole ICP run (no host round trips)
+    double T[16];
+    double sums[32];             // last reduced sums: a[21] b[6] e cnt nsrc
+    int done;                    // set on convergence or failure: remaining iteration kernels exit at once
+    int status;
+    int iters_run;
+    int pad;
+};
+
+struct Slot {
+    float *depth = nullptr;      // [H][W] f32
+    uint8_t *bgr = nullptr;      // [H][W][3]
+    float4 *nmap = nullptr;      // [H][W] (nx,ny,nz,d), lazily allocated
+    bool has_color = false;
+    bool loaded = false;
+    bool has_normals = false;
+};
+
+constexpr int ICP_MAX_BLOCKS = 1024;
+constexpr int ICP_SLAB = 32;     // doubles per block partial
+
+}  // namespace tl3d
+
+struct tl3d_ctx {
+    tl3d_config cfg;
+    int device;
+    hipStream_t stream;
+    bool own_stream;
+    tl3d::Cam cam;
+    tl3d::Grid grid;
+    size_t nvox;
+    tl3d::Slot *slots;
+    int2 *tsdf;                  // [nvox] {sum_q, weight}
+    unsigned long long *centroid;// [nvox][4]
+    bool own_tsdf, own_centroid;
+    // scratch
+    uint16_t *stage_u16;         // u16 depth staging
+    unsigned *block_counts;      // compaction counts
+    unsigned long long *block_offsets;
+    size_t scratch_blocks;
+    unsigned long long *d_counters;   // device counters [16]
+    double *icp_slab;            // [ICP_MAX_BLOCKS][ICP_SLAB]
+    tl3d::IcpState *icp_state;
+    float *bounds_slab;
+    // stats / profiling
+    tl3d_stats stats;
+    bool count_records, time_kernels;
+    hipEvent_t ev[2];
+    hipEvent_t kev0, kev1;
+    struct KTimer { hipEvent_t a, b; };
+    KTimer *ktimers;
+    int n_ktimers, ktimers_used;
+};
+
+namespace tl3d {
+
+int set_err(int code, const char *fmt, ...);
+
+#define TL3D_HIP(x)                                                                          \
+    do {                                                                                     \
+        hipError_t e__ = (x);                                                                \
+        if (e__ != hipSuccess) return tl3d::set_err(TL3D_E_HIP, "%s failed: %s (%s:%d)", #x, \
+                                                    hipGetErrorString(e__), __FILE__, __LINE__); \
+    } while (0)
+
+// ---- device helpers ---------------------------------------------------------------------------
+__device__ __forceinline__ size_t brick_base(int bx, int by, int bz, int nbx, int nby) {
+    return (((size_t)bz * (size_t)nby + (size_t)by) * (size_t)nbx + (size_t)bx) << 9;
+}
+__device__ __forceinline__ size_t vox_index(int i, int j, int k, int nbx, int nby) {
+    return brick_base(i >> 3, j >> 3, k >> 3, nbx, nby) + (size_t)(((k & 7) << 6) | ((j & 7) << 3) | (i & 7));
+}
+
+// ---- kernel launchers (one per .hip file) -----------------------------------------------------
+// frames
+int launch_u16_to_f32(hipStream_t s, const uint16_t *in, float *out, size_t n);
+// back-projection
+int launch_bp_count(hipStream_t s, const Cam &cam, const BpArgs &a, const float *depth, unsigned *block_counts, int nblocks);
+int launch_scan(hipStream_t s, const unsigned *counts, unsigned long long *offsets, int n, unsigned long long *total);
+int launch_bp_write(hipStream_t s, const Cam &cam, const BpArgs &a, const PoseD &p, const float *depth, const uint8_t *bgr,
+                    const unsigned long long *offsets, int nblocks, float *xyz, uint8_t *rgb, unsigned long long cap);
+// centroid
+int launch_centroid_frame(hipStream_t s, const Cam &cam, const Grid &g, const BpArgs &a, const PoseD &p, const float *depth,
+                          const uint8_t *bgr, unsigned long long *grid, unsigned long long *counters);
+int launch_centroid_points(hipStream_t s, const Grid &g, const float *xyz, const uint8_t *rgb, long long n,
+                           unsigned long long *grid, unsigned long long *counters);
+int launch_bounds(hipStream_t s, const float *xyz, long long n, float *slab, int nblocks);
+// tsdf
+int launch_tsdf_integrate(hipStream_t s, const Cam &cam, const Grid &g, const PoseF &p, const Frustum &fr, const float *depth,
+                          float scale, float mind, float maxd, int2 *grid, unsigned long long *counters, bool count);
+// normals + icp
+int launch_normals(hipStream_t s, const Cam &cam, const float *depth, float scale, float mind, float maxd, float jump, float4 *nmap);
+int launch_icp_iteration(hipStream_t s, const Cam &cam, const float *depth_src, float scale, float mind, float maxd,
+                         const float4 *nmap_tgt, int stride, float max_dist, double damping, double eps, int final_pass,
+                         double *slab, IcpState *state, int nblocks);
+// extraction
+int launch_extract_count(hipStream_t s, const Grid &g, int mode, int min_count, int min_weight, double max_abs,
+                         const int2 *tsdf, const unsigned long long *cen, unsigned *block_counts, int nblocks);
+int launch_extract_write(hipStream_t s, const Grid &g, int mode, int min_count, int min_weight, double max_abs,
+                         const int2 *tsdf, const unsigned long long *cen, const unsigned long long *offsets, int nblocks,
+                         float *xyz, uint8_t *rgb, unsigned long long cap);
+// grids
+int launch_add_i32(hipStream_t s, int *dst, const int *src, size_t n);
+int launch_add_u64(hipStream_t s, unsigned long long *dst, const unsigned long long *src, size_t n);
+// outlier filter
+int sor_run(tl3d_ctx *ctx, const float *xyz_dev, long long n, int k, double std_ratio, double cell, uint8_t *keep_dev, long long *kept);
+
+constexpr int EXTRACT_CHUNK = 2048;   // records per block in the extraction kernels
+
+}  // namespace tl3d

@@ -1,0 +1,270 @@
+"""FusionContext: one GPU's device-resident pipeline state (frame slots + grids) behind the C-ABI.
+
+This is the object the reference-shaped classes in dense.py / pipeline.py drive.  It owns no numerics:
+every method is one call into libtl3d.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _cabi as abi
+
+
+@dataclass
+class GridSpec:
+    dims: Tuple[int, int, int]
+    origin: Tuple[float, float, float]
+    voxel_size: float = 0.005          # depth_to_reconstruction.py:64
+    sdf_trunc: float = 0.02            # 4 voxels at the reference voxel size
+    channels: int = abi.CH_TSDF | abi.CH_CENTROID
+
+    @property
+    def nvox(self) -> int:
+        return int(self.dims[0]) * int(self.dims[1]) * int(self.dims[2])
+
+    @staticmethod
+    def cube(n: int, voxel_size: float, centre=(0.0, 0.0, 0.0), sdf_trunc: Optional[float] = None,
+             channels: int = abi.CH_TSDF | abi.CH_CENTROID) -> "GridSpec":
+        half = 0.5 * n * voxel_size
+        return GridSpec((n, n, n), tuple(float(c) - half for c in centre), voxel_size,
+                        4.0 * voxel_size if sdf_trunc is None else sdf_trunc, channels)
+
+
+class FusionContext:
+    def __init__(self, width: int, height: int, fx: float, fy: float, cx: float, cy: float,
+                 min_depth: float = 0.1, max_depth: float = 50.0, n_slots: int = 2,
+                 grid: Optional[GridSpec] = None, device: int = 0, ext_tsdf=None, ext_centroid=None, stream=None):
+        self._h = None
+        lib = abi.load()
+        if abi.device_count() <= 0:
+            raise RuntimeError("libtl3d: no HIP device visible; the MI355X path has no CPU fallback")
+        cfg = abi.Config()
+        cfg.abi_version = abi.ABI_VERSION
+        cfg.width, cfg.height = int(width), int(height)
+        cfg.fx, cfg.fy, cfg.cx, cfg.cy = float(fx), float(fy), float(cx), float(cy)
+        cfg.min_depth, cfg.max_depth = float(min_depth), float(max_depth)
+        cfg.n_slots = int(n_slots)
+        if grid is not None:
+            cfg.channels = int(grid.channels)
+            cfg.nx, cfg.ny, cfg.nz = (int(d) for d in grid.dims)
+            cfg.origin = (C.c_double * 3)(*[float(o) for o in grid.origin])
+            cfg.voxel_size = float(grid.voxel_size)
+            cfg.sdf_trunc = float(grid.sdf_trunc)
+        cfg.ext_tsdf = abi.ptr(ext_tsdf)
+        cfg.ext_centroid = abi.ptr(ext_centroid)
+        cfg.stream = abi.ptr(stream)
+        self._keep = (ext_tsdf, ext_centroid)
+        h = C.c_void_p()
+        abi.check(lib.tl3d_create(C.byref(cfg), int(device), C.byref(h)))
+        self._h, self._lib = h, lib
+        self.width, self.height = int(width), int(height)
+        self.fx, self.fy, self.cx, self.cy = float(fx), float(fy), float(cx), float(cy)
+        self.min_depth, self.max_depth = float(min_depth), float(max_depth)
+        self.grid = grid
+        self.device = int(device)
+        self.n_slots = int(n_slots)
+
+    # ---- lifetime --------------------------------------------------------------------------
+    def close(self):
+        if self._h is not None:
+            self._lib.tl3d_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def sync(self):
+        abi.check(self._lib.tl3d_sync(self._h))
+
+    # ---- frames ----------------------------------------------------------------------------
+    def upload(self, slot: int, depth, bgr=None):
+        """depth: float32 [H,W] metres / relative units, or uint16 [H,W] millimetres (16-bit PNG, D2R:85-90)."""
+        if isinstance(depth, np.ndarray):
+            if depth.dtype == np.uint16:
+                kind = abi.DEPTH_U16_MM
+            else:
+                depth = np.ascontiguousarray(depth, dtype=np.float32)
+                kind = abi.DEPTH_F32_M
+            depth = np.ascontiguousarray(depth)
+            assert depth.shape == (self.height, self.width), f"depth {depth.shape} != {(self.height, self.width)}"
+        else:                                   # torch tensor (host or device)
+            import torch
+            kind = abi.DEPTH_U16_MM if depth.dtype in (torch.uint16, torch.int16) else abi.DEPTH_F32_M
+            assert tuple(depth.shape) == (self.height, self.width)
+        if bgr is not None:
+            if isinstance(bgr, np.ndarray):
+                bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+            assert tuple(bgr.shape) == (self.height, self.width, 3), f"colour {tuple(bgr.shape)}"
+        abi.check(self._lib.tl3d_upload_frame(self._h, int(slot), abi.ptr(depth), kind, abi.ptr(bgr)))
+
+    def download_depth(self, slot: int) -> np.ndarray:
+        out = np.empty((self.height, self.width), np.float32)
+        abi.check(self._lib.tl3d_download_depth(self._h, int(slot), abi.ptr(out)))
+        return out
+
+    # ---- a4/a5 -----------------------------------------------------------------------------
+    @staticmethod
+    def _pose_args(pose, flags):
+        if pose is None:
+            return abi.d9(np.eye(3)), abi.d3(np.zeros(3)), flags | abi.F_NO_POSE
+        r, t = pose
+        return abi.d9(r), abi.d3(t), flags
+
+    def backproject(self, slot: int, pose=None, scale=1.0, subsample: int = 1, min_depth=None, max_depth=None,
+                    scale_f64: bool = False):
+        r, t, flags = self._pose_args(pose, abi.F_SCALE_F64 if scale_f64 else 0)
+        mn = self.min_depth if min_depth is None else float(min_depth)
+        mx = self.max_depth if max_depth is None else float(max_depth)
+        cap = -(-self.height // subsample) * -(-self.width // subsample)
+        xyz = np.empty((cap, 3), np.float32)
+        rgb = np.empty((cap, 3), np.uint8)
+        n = C.c_int64(0)
+        abi.check(self._lib.tl3d_backproject(self._h, int(slot), abi.ptr(r), abi.ptr(t), float(scale), flags,
+                                             int(subsample), mn, mx, abi.ptr(xyz), abi.ptr(rgb), cap, C.byref(n)))
+        return xyz[:n.value], rgb[:n.value]
+
+    # ---- fusion ----------------------------------------------------------------------------
+    def accumulate_centroid(self, slot: int, pose=None, scale=1.0, subsample: int = 1, min_depth=None, max_depth=None,
+                            scale_f64: bool = False):
+        r, t, flags = self._pose_args(pose, abi.F_SCALE_F64 if scale_f64 else 0)
+        mn = self.min_depth if min_depth is None else float(min_depth)
+        mx = self.max_depth if max_depth is None else float(max_depth)
+        abi.check(self._lib.tl3d_accumulate_centroid(self._h, int(slot), abi.ptr(r), abi.ptr(t), float(scale), flags,
+                                                     int(subsample), mn, mx))
+
+    def accumulate_points(self, xyz, rgb):
+        if isinstance(xyz, np.ndarray):
+            xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+            rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        n = int(xyz.shape[0])
+        abi.check(self._lib.tl3d_accumulate_points(self._h, abi.ptr(xyz), abi.ptr(rgb), n))
+
+    def points_bounds(self, xyz):
+        if isinstance(xyz, np.ndarray):
+            xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        mn, mx = np.zeros(3), np.zeros(3)
+        abi.check(self._lib.tl3d_points_bounds(self._h, abi.ptr(xyz), int(xyz.shape[0]), abi.ptr(mn), abi.ptr(mx)))
+        return mn, mx
+
+    def integrate(self, slot: int, pose, scale=1.0):
+        r, t = pose
+        abi.check(self._lib.tl3d_integrate(self._h, int(slot), abi.ptr(abi.d9(r)), abi.ptr(abi.d3(t)), float(scale)))
+
+    # ---- ICP -------------------------------------------------------------------------------
+    def build_normals(self, slot: int, scale=1.0, depth_jump=0.05):
+        abi.check(self._lib.tl3d_build_normals(self._h, int(slot), float(scale), float(depth_jump)))
+
+    def download_normals(self, slot: int) -> np.ndarray:
+        out = np.empty((self.height, self.width, 4), np.float32)
+        abi.check(self._lib.tl3d_download_normals(self._h, int(slot), abi.ptr(out)))
+        return out
+
+    def icp(self, slot_src: int, slot_tgt: int, T_init=None, iters=10, stride=4, max_dist=0.05, damping=1e-6,
+            eps=1e-9, scale_src=1.0):
+        """Point-to-plane ICP; returns T (src camera -> tgt camera) and statistics.  With src = previous frame and
+        tgt = current frame, (T[:3,:3], T[:3,3]) is (R_rel, t_rel) of depth_to_reconstruction.py:618-620."""
+        T0 = np.ascontiguousarray(np.eye(4) if T_init is None else np.asarray(T_init, np.float64).reshape(4, 4))
+        prm = abi.IcpParams(int(iters), int(stride), float(max_dist), float(damping), float(eps))
+        res = abi.IcpResult()
+        abi.check(self._lib.tl3d_icp_p2plane(self._h, int(slot_src), float(scale_src), int(slot_tgt), abi.ptr(T0),
+                                             C.byref(prm), C.byref(res)))
+        return dict(T=np.array(res.T).reshape(4, 4), fitness=res.fitness, rmse=res.rmse, n_corr=res.n_corr,
+                    n_src=res.n_src, iters_run=res.iters_run, status=res.status)
+
+    # ---- grids -----------------------------------------------------------------------------
+    def reset(self):
+        abi.check(self._lib.tl3d_grid_reset(self._h))
+
+    def grid_ptr(self, channel: int):
+        p, nb = C.c_void_p(), C.c_size_t()
+        abi.check(self._lib.tl3d_grid_device_ptr(self._h, int(channel), C.byref(p), C.byref(nb)))
+        return p.value, nb.value
+
+    def download_grid(self, channel: int) -> np.ndarray:
+        _, nb = self.grid_ptr(channel)
+        if channel == abi.CH_TSDF:
+            out = np.empty((nb // 8, 2), np.int32)
+        else:
+            out = np.empty((nb // 32, 4), np.uint64)
+        abi.check(self._lib.tl3d_grid_download(self._h, int(channel), abi.ptr(out), nb))
+        return out
+
+    def upload_grid(self, channel: int, arr):
+        _, nb = self.grid_ptr(channel)
+        if isinstance(arr, np.ndarray):
+            arr = np.ascontiguousarray(arr)
+            assert arr.nbytes == nb
+        abi.check(self._lib.tl3d_grid_upload(self._h, int(channel), abi.ptr(arr), nb))
+
+    def add_grid(self, channel: int, arr):
+        _, nb = self.grid_ptr(channel)
+        if isinstance(arr, np.ndarray):
+            arr = np.ascontiguousarray(arr)
+            assert arr.nbytes == nb
+        abi.check(self._lib.tl3d_grid_add(self._h, int(channel), abi.ptr(arr), nb))
+
+    def grid_tensor(self, channel: int):
+        """Zero-copy torch view of a grid channel (for torch.distributed all_reduce over RCCL)."""
+        import torch
+        p, nb = self.grid_ptr(channel)
+        dt, item, typestr = (torch.int32, 4, "<i4") if channel == abi.CH_TSDF else (torch.int64, 8, "<i8")
+
+        class _Iface:
+            __cuda_array_interface__ = {"shape": (nb // item,), "typestr": typestr, "data": (p, False), "version": 2}
+        t = torch.as_tensor(_Iface(), device=torch.device("cuda", self.device))
+        assert t.data_ptr() == p and t.dtype == dt
+        return t
+
+    def extract(self, mode: int = abi.EXTRACT_CENTROID, min_count: int = 1, min_weight: int = 0,
+                max_abs_tsdf: float = 1.0):
+        n = C.c_int64(0)
+        abi.check(self._lib.tl3d_extract(self._h, int(mode), int(min_count), int(min_weight), float(max_abs_tsdf),
+                                         None, None, 0, C.byref(n)))
+        xyz = np.empty((n.value, 3), np.float32)
+        rgb = np.empty((n.value, 3), np.uint8)
+        if n.value:
+            abi.check(self._lib.tl3d_extract(self._h, int(mode), int(min_count), int(min_weight), float(max_abs_tsdf),
+                                             abi.ptr(xyz), abi.ptr(rgb), n.value, C.byref(n)))
+        return xyz, rgb
+
+    def statistical_outlier(self, xyz, nb_neighbors=20, std_ratio=2.0, cell_size=None):
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        keep = np.zeros(len(xyz), np.uint8)
+        kept = C.c_int64(0)
+        cell = float(cell_size if cell_size is not None else (self.grid.voxel_size * 2 if self.grid else 0.01))
+        abi.check(self._lib.tl3d_statistical_outlier(self._h, abi.ptr(xyz), len(xyz), int(nb_neighbors), float(std_ratio),
+                                                     cell, abi.ptr(keep), C.byref(kept)))
+        return keep.astype(bool)
+
+    # ---- measurement -----------------------------------------------------------------------
+    def set_profile(self, count_records=False, time_kernels=False):
+        abi.check(self._lib.tl3d_set_profile(self._h, int(count_records), int(time_kernels)))
+
+    def stats(self) -> dict:
+        s = abi.Stats()
+        abi.check(self._lib.tl3d_get_stats(self._h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in abi.Stats._fields_}
+
+    def reset_stats(self):
+        abi.check(self._lib.tl3d_reset_stats(self._h))
+
+    def event_record(self, which: int):
+        abi.check(self._lib.tl3d_event_record(self._h, int(which)))
+
+    def event_elapsed_ms(self) -> float:
+        ms = C.c_float(0)
+        abi.check(self._lib.tl3d_event_elapsed_ms(self._h, C.byref(ms)))
+        return ms.value
