@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""bench.py -- depth frames/sec fused into the TSDF (1080x1920), 1/2/4/8 MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one batch of --frames-per-step synthetic frames per GPU: each frame
+(already resident in HBM) is integrated into that GPU's 512^3 TSDF grid with one tsdf_integrate launch
+(F = 1 frame per sweep).  With N > 1 the frames shard across ranks (weak scaling: per-GPU batch fixed) and the
+per-GPU grids are summed once with an RCCL all-reduce inside the timed region.  Rank 0 prints ONE JSON line.
+
+roofline: algorithmic bytes per launch are COUNTED by the kernel (8 B x (records read + records written),
+SURVEY.md section 8d) plus the frame's depth bytes; time is hipEvent time on the launching stream over the
+timed region.  cpu_baseline: the C oracle (oracle/tl3d_oracle.c, OpenMP) on the host cores, bounded sample.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames-per-step", type=int, default=32)
+    ap.add_argument("--resident-frames", type=int, default=32, help="distinct synthetic frames kept in HBM per GPU")
+    ap.add_argument("--grid", type=int, default=512)
+    ap.add_argument("--voxel", type=float, default=0.005)
+    ap.add_argument("--width", type=int, default=1080)
+    ap.add_argument("--height", type=int, default=1920)
+    ap.add_argument("--centroid", action="store_true", help="also accumulate the voxel-centroid channel each frame")
+    ap.add_argument("--icp", action="store_true", help="also run frame-to-frame ICP each frame (poses still analytic)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=2)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import tl3d
+    from tl3d import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    H, W = args.height, args.width
+    sx = W / 1080.0
+    cam = dict(width=W, height=H, fx=1719.0 * sx, fy=1719.0 * sx, cx=W / 2.0, cy=H / 2.0)
+    n = args.grid
+    F = args.frames_per_step
+    n_res = min(args.resident_frames, F * max(1, args.steps))
+    total_frames_rank = F * args.steps
+    deg = 360.0 / max(1, world * n_res)
+    scene = synth.object_scene(with_room=True)
+    poses = synth.orbit_poses(n_res, 1.0, deg, start_deg=rank * n_res * deg)
+    channels = tl3d.CH_TSDF | (tl3d.CH_CENTROID if args.centroid else 0)
+    spec = tl3d.GridSpec.cube(n, args.voxel, centre=(0.0, -0.1, 0.0), channels=channels)
+    # one explicit stream shared by torch (frame synthesis, RCCL) and the library, so every hand-over is ordered
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
+    ctx = tl3d.FusionContext(W, H, cam["fx"], cam["fy"], cam["cx"], cam["cy"], min_depth=0.1, max_depth=50.0,
+                             n_slots=n_res, grid=spec, device=local_rank, stream=stream.cuda_stream)
+
+    t_gen = time.perf_counter()
+    host_keep = []
+    for i, p in enumerate(poses):
+        d, c = synth.render(scene, p, W, H, cam["fx"], cam["fy"], cam["cx"], cam["cy"], xp=torch, device=dev)
+        d, c = d.contiguous(), c.contiguous()
+        ctx.upload(i, d, c)
+        stream.synchronize()                      # the tensors are freed right after: finish the copy first
+        if rank == 0 and i < args.cpu_frames:
+            host_keep.append((d.cpu().numpy(), p))
+        del d, c
+    torch.cuda.synchronize(dev)
+    t_gen = time.perf_counter() - t_gen
+    if args.icp:
+        for i in range(n_res):
+            ctx.build_normals(i)
+
+    def step(s):
+        for j in range(F):
+            k = (s * F + j) % n_res
+            if args.icp:
+                kp = (k - 1) % n_res
+                r_rel, t_rel = synth.relative_pose(poses[kp], poses[k])
+                T0 = np.eye(4)
+                T0[:3, :3], T0[:3, 3] = r_rel, t_rel.ravel()
+                ctx.icp(kp, k, T_init=T0, iters=5, stride=4, max_dist=0.05)
+            ctx.integrate(k, poses[k])
+            if args.centroid:
+                ctx.accumulate_centroid(k, poses[k], subsample=2)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for s in range(args.warmup):
+        step(s)
+    if dist is not None and args.warmup > 0:
+        dist.all_reduce(ctx.grid_tensor(tl3d.CH_TSDF))          # warm the communicator
+    ctx.reset()
+    barrier()
+    ctx.event_record(0)
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        step(s)
+    ctx.event_record(1)
+    if dist is not None:
+        dist.all_reduce(ctx.grid_tensor(tl3d.CH_TSDF))
+        if args.centroid:
+            dist.all_reduce(ctx.grid_tensor(tl3d.CH_CENTROID))
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    dev_ms = ctx.event_elapsed_ms()
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # ---- roofline of the dominant kernel (tsdf_integrate), rank 0 ----------------------------------------
+    roof = None
+    if rank == 0:
+        launches = total_frames_rank
+        ctx.reset_stats()
+        ctx.set_profile(count_records=True, time_kernels=False)
+        for j in range(n_res):
+            ctx.integrate(j, poses[j])
+        st = ctx.stats()
+        rec_per_launch = (st["tsdf_records_read"] + st["tsdf_records_written"]) / max(1, st["tsdf_launches"])
+        bricks_per_launch = st["tsdf_bricks_visited"] / max(1, st["tsdf_launches"])
+        free_per_launch = st["tsdf_bricks_free"] / max(1, st["tsdf_launches"])
+        ctx.reset_stats()
+        ctx.set_profile(count_records=False, time_kernels=True)
+        for s in range(args.steps):
+            for j in range(F):
+                ctx.integrate((s * F + j) % n_res, poses[(s * F + j) % n_res])
+        st2 = ctx.stats()
+        ctx.set_profile(False, False)
+        k_ms = st2["tsdf_kernel_ms"] / max(1, st2["tsdf_kernel_timed"])
+        bytes_launch = 8.0 * rec_per_launch + 4.0 * H * W      # voxel records + the depth frame read once
+        region_ms = dev_ms / launches
+        pure = not (args.centroid or args.icp)
+        dur_ms = region_ms if pure else k_ms
+        achieved = bytes_launch / (dur_ms * 1e-3) / 1e9
+        traffic = None
+        pj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pj):
+            try:
+                with open(pj) as f:
+                    tj = json.load(f)
+                if tj.get("grid") == n and tj.get("width") == W and tj.get("height") == H:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roof = {"bound": "hbm", "kernel": "tsdf_integrate_kernel", "achieved": round(achieved, 1), "peak": 8000.0,
+                "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
+                "bytes_per_launch": int(bytes_launch), "records_per_launch": int(rec_per_launch),
+                "dense_sweep_bytes": int(16.0 * n ** 3 + 4.0 * H * W), "bricks_visited_per_launch": int(bricks_per_launch),
+                "free_space_bricks_per_launch": int(free_per_launch),
+                "ms_per_launch_region": round(region_ms, 4), "ms_per_launch_events": round(k_ms, 4),
+                "launches": launches, "frames_per_sweep": 1}
+
+    # ---- CPU baseline: the oracle on the host cores, bounded sample, rank 0 at N=1 only --------------------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import c_oracle
+        orc = c_oracle.Oracle(W, H, cam["fx"], cam["fy"], cam["cx"], cam["cy"], 0.1, 50.0, dims=spec.dims,
+                              origin=spec.origin, voxel_size=spec.voxel_size, sdf_trunc=spec.sdf_trunc)
+        orc.tsdf_integrate(host_keep[0][0], host_keep[0][1][0], host_keep[0][1][1])     # page in the 1 GiB grid
+        tc = time.perf_counter()
+        for d, p in host_keep:
+            orc.tsdf_integrate(d, p[0], p[1])
+        tc = time.perf_counter() - tc
+        cpu = {"value": round(len(host_keep) / tc, 3), "unit": "frames/s", "cores": orc.threads, "kind": "port",
+               "sample": f"{len(host_keep)} of the same {W}x{H} frames into the same {n}^3 grid, "
+                         f"oracle/tl3d_oracle.c orc_tsdf_integrate with OpenMP over z-slabs, {tc:.1f} s wall"}
+        # the reference's own per-frame work (numpy back-projection, its default subsample=2) for context
+        from oracle import ref_numpy
+        tb = time.perf_counter()
+        ref_numpy.backproject(host_keep[0][0], np.zeros((H, W, 3), np.uint8), cam["fx"], cam["fy"], cam["cx"], cam["cy"],
+                              pose=host_keep[0][1], subsample=2)
+        cpu["reference_numpy_backproject_s2_fps"] = round(1.0 / (time.perf_counter() - tb), 2)
+        del orc
+
+    if rank == 0:
+        total = world * total_frames_rank
+        out = {
+            "metric": "depth frames/sec fused into TSDF (1080x1920)",
+            "value": round(total / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{W}x{H} ray-cast orbit (sphere-union object in a closed room, radius 1 m) "
+                                   f"integrated into a {n}^3 TSDF @ {args.voxel * 1e3:g} mm, 8 B/voxel, "
+                                   f"1 frame per sweep; frames resident in HBM",
+                       "frames_per_step_per_gpu": F, "resident_frames_per_gpu": n_res, "grid": n,
+                       "voxel_m": args.voxel, "centroid_channel": bool(args.centroid), "icp_in_loop": bool(args.icp),
+                       "parallelism": f"frame-shard x{world}" + (" + RCCL all-reduce of the grid" if world > 1 else ""),
+                       "setup_s": round(t_gen, 1)},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

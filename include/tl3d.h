@@ -106,6 +106,7 @@ typedef struct tl3d_stats {
     uint64_t tsdf_records_read;      /* voxel records loaded by tl3d_integrate kernels (counting mode) */
     uint64_t tsdf_records_written;
     uint64_t tsdf_bricks_visited;    /* bricks that passed culling                                      */
+    uint64_t tsdf_bricks_free;       /* of those: free-space bricks (streaming update, no depth lookups) */
     uint64_t centroid_launches;
     uint64_t centroid_points;        /* points accumulated                                              */
     uint64_t centroid_dropped;       /* valid points that fell outside the grid                         */

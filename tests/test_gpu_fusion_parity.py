@@ -140,3 +140,34 @@ def test_normals_and_icp_match_oracle():
     r_rel, t_rel = synth.relative_pose(poses[0], poses[1])
     T_true = np.eye(4); T_true[:3, :3] = r_rel; T_true[:3, 3] = t_rel.ravel()
     assert np.linalg.norm(res["T"] - T_true) < 5e-3
+
+
+def test_tsdf_culling_is_conservative_for_arbitrary_views():
+    """Brick culling (frustum + depth tiles) must never drop a voxel the per-voxel rule updates: random poses with the
+    camera inside / outside / grazing the grid, invalid-depth holes, depth discontinuities, tiny and huge depths."""
+    from tl3d import synth
+    rng = np.random.default_rng(5)
+    cam = dict(width=200, height=152, fx=150.0, fy=160.0, cx=101.3, cy=70.7)
+    ctx, orc = make_pair(cam=cam, dims=(64, 48, 56), voxel=0.05, centre=(0.1, -0.1, 0.3), trunc=0.12, n_slots=1)
+    scene = synth.object_scene(with_room=True)
+    with ctx:
+        for trial in range(24):
+            eye = rng.uniform([-1.6, -1.2, -1.6], [1.6, 0.3, 1.6])
+            tgt = rng.uniform(-0.5, 0.5, size=3)
+            pose = synth.look_at(eye, tgt)
+            depth, _ = synth.render(scene, pose, want_color=False, **cam)
+            depth = depth.copy()
+            if trial % 3 == 0:       # holes and out-of-range stripes
+                depth[rng.random(depth.shape) < 0.2] = 0.0
+                depth[:, 50:60] = 80.0
+            if trial % 4 == 1:       # foreground occluder: sharp discontinuity
+                depth[40:90, 60:140] = 0.25
+            if trial % 5 == 2:
+                depth[:] = np.nan
+                depth[70:80, 90:100] = 0.9
+            ctx.upload(0, depth, None)
+            ctx.integrate(0, pose)
+            orc.tsdf_integrate(depth, pose[0], pose[1])
+        g = ctx.download_grid(tl3d.CH_TSDF)
+    assert orc.tsdf[:, 1].sum() > 100000
+    assert np.array_equal(g, orc.tsdf)

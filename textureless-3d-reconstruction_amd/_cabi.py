@@ -56,7 +56,7 @@ class IcpParams(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("tsdf_launches", C.c_uint64), ("tsdf_records_read", C.c_uint64), ("tsdf_records_written", C.c_uint64),
-                ("tsdf_bricks_visited", C.c_uint64), ("centroid_launches", C.c_uint64), ("centroid_points", C.c_uint64),
+                ("tsdf_bricks_visited", C.c_uint64), ("tsdf_bricks_free", C.c_uint64), ("centroid_launches", C.c_uint64), ("centroid_points", C.c_uint64),
                 ("centroid_dropped", C.c_uint64), ("tsdf_kernel_ms", C.c_double), ("tsdf_kernel_timed", C.c_uint64)]
 
 

@@ -3,12 +3,26 @@
 // (oracle/tl3d_oracle.c: orc_tsdf_integrate) and both sides evaluate the same f32 sequence, so the integer
 // grid {sum of rint(tsdf*32767), weight} is bit-identical.
 //
-// Mapping: one 64-lane wave per 8x8x8 brick (4 KB of records, contiguous).  Each lane owns 4 x 16 B = 8 voxels;
-// a wave-instruction touches 1 KB contiguous.  Bricks whose bounding sphere is outside the (1-pixel widened)
-// view frustum are skipped before any record is touched.  Records are loaded only by lanes that update and
-// stored only when changed, so HBM traffic = 16 B x (lanes that update); the depth gathers (8.3 MB frame) are
-// served by L2 / Infinity Cache.  Algorithmic bytes per launch = 8 B x (records read + records written), counted
-// by the kernel itself in counting mode (SURVEY.md section 8d "counted, never estimated").
+// Launches per frame, all on the ctx stream:
+//   1. depth_tiles_kernel     32x32-pixel tiles -> (min, max, all-valid) of the valid scaled depth   4 B/pixel read
+//   2. tile_pyramid_kernel    1 block: 2x2 reductions of the tiles up to a single tile
+//   3. brick_cull_kernel      one thread per 8^3 brick classifies it from <= 16 pyramid lookups:
+//        SKIP   outside the view, no valid depth under it, or more than trunc behind every surface it can see
+//        FREE   wholly inside the image, every pixel under it valid, and at least trunc in front of every
+//               surface: every voxel gets exactly tsdf = 1 (q = 32767), so no depth lookup is needed
+//        MIXED  everything else (near a surface, on the image border, straddling the camera plane)
+//      and appends it to a compact list (MIXED from the front, FREE from the back).
+//   4. tsdf_integrate_kernel  one 64-lane wave per listed brick (4 KB of records, contiguous; a lane owns
+//        4 x 16 B = 8 voxels, a wave-instruction moves 1 KB).  FREE bricks are a pure streaming
+//        read-modify-write; MIXED bricks run the per-voxel rule (project, gather depth, truncate) and load /
+//        store only the 16-B pairs that change.
+// Every classification is conservative with respect to the per-voxel rule, so the result is the oracle's bit
+// for bit whatever the view.  The list balances the work (a static brick->block map leaves most of the chip idle:
+// the frustum covers a fraction of the grid).
+// Algorithmic bytes per launch = 8 B x (records read + written), counted by the kernel in counting mode
+// ("counted, never estimated"), + 4 B x H x W for the depth frame.
+#include <stdlib.h>
+
 #include "tl3d_internal.h"
 
 namespace tl3d {
@@ -17,61 +31,237 @@ struct TsdfConst {
     float mind, maxd, sc, wlim, hlim;
 };
 
-__device__ __forceinline__ bool tsdf_voxel(const Cam &cam, const Grid &g, const TsdfConst &c, const float *__restrict__ depth,
-                                           float xc, float yc, float zc, int &q) {
-    if (!(zc > 0.0f)) return false;
-    const float inv = 1.0f / zc;
-    const float uf = fmaf(cam.fx * xc, inv, cam.cx);
-    const float vf = fmaf(cam.fy * yc, inv, cam.cy);
-    if (!(uf >= -0.5f && uf < c.wlim && vf >= -0.5f && vf < c.hlim)) return false;
-    int u = (int)floorf(uf + 0.5f), v = (int)floorf(vf + 0.5f);
-    u = min(u, cam.W - 1);
-    v = min(v, cam.H - 1);
-    const float d = depth[(size_t)v * cam.W + u] * c.sc;
-    if (!(d > c.mind && d < c.maxd)) return false;
-    const float sdf = d - zc;
-    if (!(sdf >= -g.trunc)) return false;
-    const float tsdf = fminf(1.0f, sdf * g.inv_trunc);
-    q = (int)rintf(tsdf * 32767.0f);
-    return true;
+constexpr int TILE = 32;
+constexpr int TILE_SHIFT = 5;
+constexpr int MAX_LEVELS = 12;
+constexpr unsigned FREE_FLAG = 0x80000000u;
+
+struct Pyramid {
+    int nlev;
+    int ntx[MAX_LEVELS], nty[MAX_LEVELS], off[MAX_LEVELS];     // per level: tiles in x / y, offset into the float4 array
+};
+
+// tile = (dmin, dmax, allvalid ? 1 : 0, unused)
+
+// ---- 1. depth tiles --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void depth_tiles_kernel(Cam cam, TsdfConst c, const float *__restrict__ depth, int ntx,
+                                                          float4 *__restrict__ tiles, unsigned *__restrict__ list_counts) {
+    __shared__ float smin[4], smax[4];
+    __shared__ int sbad[4];
+    const int tx = blockIdx.x, ty = blockIdx.y;
+    if (tx == 0 && ty == 0 && threadIdx.x < 2) list_counts[threadIdx.x] = 0u;   // reset the brick-list cursors
+    const int lx = threadIdx.x & 31, ly0 = threadIdx.x >> 5;        // 32 x 8 threads, 4 rows each
+    float mn = INFINITY, mx = -INFINITY;
+    int bad = 0;
+    const int u = tx * TILE + lx;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int v = ty * TILE + ly0 + r * 8;
+        if (u < cam.W && v < cam.H) {
+            const float d = depth[(size_t)v * cam.W + u] * c.sc;
+            if (d > c.mind && d < c.maxd) {
+                mn = fminf(mn, d);
+                mx = fmaxf(mx, d);
+            } else {
+                bad = 1;
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        mn = fminf(mn, __shfl_down(mn, d));
+        mx = fmaxf(mx, __shfl_down(mx, d));
+        bad |= __shfl_down(bad, d);
+    }
+    if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = mn; smax[threadIdx.x >> 6] = mx; sbad[threadIdx.x >> 6] = bad; }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        tiles[ty * ntx + tx] = make_float4(fminf(fminf(smin[0], smin[1]), fminf(smin[2], smin[3])),
+                                           fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3])),
+                                           (sbad[0] | sbad[1] | sbad[2] | sbad[3]) ? 0.0f : 1.0f, 0.0f);
 }
 
-template <bool COUNT>
-__global__ __launch_bounds__(256) void tsdf_integrate_kernel(Cam cam, Grid g, PoseF pose, Frustum fr, TsdfConst c,
-                                                             const float *__restrict__ depth, int2 *__restrict__ grid,
-                                                             unsigned long long *__restrict__ counters) {
-    const int lane = threadIdx.x & 63;
-    const int wid = threadIdx.x >> 6;
-    // XCD-aware block remap: blocks that share an XCD (blockIdx % 8) walk one contiguous eighth of each window of
-    // bricks, so the depth tiles they gather stay in that XCD's L2.  Speed only; any placement is correct.
-    const int nblk = gridDim.x;
-    const int per = nblk >> 3;                                   // launcher guarantees nblk % 8 == 0
-    const int vblock = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    const int nbricks = g.nbx * g.nby * g.nbz;
-    const float rad = 6.9282032f * g.vs * 1.01f;                 // half diagonal of a brick: 4*sqrt(3)*voxel, +1 %
-    unsigned nread = 0, nwritten = 0, nvisited = 0;
+// ---- 2. pyramid ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void tile_pyramid_kernel(Pyramid py, float4 *__restrict__ tiles) {
+    for (int L = 1; L < py.nlev; ++L) {
+        const int n = py.ntx[L] * py.nty[L];
+        const float4 *__restrict__ src = tiles + py.off[L - 1];
+        float4 *__restrict__ dst = tiles + py.off[L];
+        for (int i = threadIdx.x; i < n; i += 1024) {
+            const int x = i % py.ntx[L], y = i / py.ntx[L];
+            float4 r = make_float4(INFINITY, -INFINITY, 1.0f, 0.0f);
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const int sx = 2 * x + dx, sy = 2 * y + dy;
+                    if (sx < py.ntx[L - 1] && sy < py.nty[L - 1]) {
+                        const float4 s = src[sy * py.ntx[L - 1] + sx];
+                        r.x = fminf(r.x, s.x);
+                        r.y = fmaxf(r.y, s.y);
+                        r.z = fminf(r.z, s.z);
+                    }
+                }
+            dst[i] = r;
+        }
+        __syncthreads();        // level L complete (and visible to the block) before level L+1 reads it
+    }
+}
 
-    for (int brick0 = vblock * 4; brick0 < nbricks; brick0 += nblk * 4) {
-        const int brick = __builtin_amdgcn_readfirstlane(brick0 + wid);
-        if (brick >= nbricks) break;
+// ---- 3. brick classification ------------------------------------------------------------------------------
+// Margins: 1.5 px on projected bounds, 1 % of a voxel on depths, 0.1 % on the truncation distance.
+__global__ __launch_bounds__(256) void brick_cull_kernel(Cam cam, Grid g, PoseF pose, Frustum fr, Pyramid py,
+                                                         const float4 *__restrict__ tiles, unsigned *__restrict__ list,
+                                                         unsigned *__restrict__ list_counts) {
+    const int nbricks = g.nbx * g.nby * g.nbz;
+    const int brick = blockIdx.x * 256 + threadIdx.x;
+    int cls = 0;                                                  // 0 skip, 1 mixed, 2 free
+    if (brick < nbricks) {
         const int bx = brick % g.nbx;
         const int by = (brick / g.nbx) % g.nby;
         const int bz = brick / (g.nbx * g.nby);
-        {   // conservative frustum cull on the brick's bounding sphere
-            const float wx = fmaf((float)(bx * 8 + 4), g.vs, g.ox);
-            const float wy = fmaf((float)(by * 8 + 4), g.vs, g.oy);
-            const float wz = fmaf((float)(bz * 8 + 4), g.vs, g.oz);
-            const float bxc = pose.r[0] * wx + pose.r[1] * wy + pose.r[2] * wz + pose.t[0];
-            const float byc = pose.r[3] * wx + pose.r[4] * wy + pose.r[5] * wz + pose.t[1];
-            const float bzc = pose.r[6] * wx + pose.r[7] * wy + pose.r[8] * wz + pose.t[2];
-            if (bzc + rad <= 0.0f) continue;
-            if (fr.lx * bxc + fr.lz * bzc < -rad) continue;
-            if (fr.rx * bxc + fr.rz * bzc < -rad) continue;
-            if (fr.ty * byc + fr.tz * bzc < -rad) continue;
-            if (fr.by * byc + fr.bz * bzc < -rad) continue;
+        const float rad = 6.9282032f * g.vs * 1.01f;                 // half diagonal of a brick, +1 %
+        const float wx = fmaf((float)(bx * 8 + 4), g.vs, g.ox);
+        const float wy = fmaf((float)(by * 8 + 4), g.vs, g.oy);
+        const float wz = fmaf((float)(bz * 8 + 4), g.vs, g.oz);
+        const float cxm = pose.r[0] * wx + pose.r[1] * wy + pose.r[2] * wz + pose.t[0];
+        const float cym = pose.r[3] * wx + pose.r[4] * wy + pose.r[5] * wz + pose.t[1];
+        const float czm = pose.r[6] * wx + pose.r[7] * wy + pose.r[8] * wz + pose.t[2];
+        const bool in_view = (czm + rad > 0.0f) && (fr.lx * cxm + fr.lz * czm >= -rad) && (fr.rx * cxm + fr.rz * czm >= -rad) &&
+                             (fr.ty * cym + fr.tz * czm >= -rad) && (fr.by * cym + fr.bz * czm >= -rad);
+        if (in_view) {
+            cls = 1;
+            if (czm - rad > 1e-3f) {
+                // all 8 corners are in front of the camera: the voxel centres project inside the corners' pixel box
+                const float h = 4.0f * g.vs;
+                float umin = INFINITY, umax = -INFINITY, vmin = INFINITY, vmax = -INFINITY, zmin = INFINITY, zmax = -INFINITY;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float sx = (k & 1) ? h : -h, sy = (k & 2) ? h : -h, sz = (k & 4) ? h : -h;
+                    const float x = cxm + pose.r[0] * sx + pose.r[1] * sy + pose.r[2] * sz;
+                    const float y = cym + pose.r[3] * sx + pose.r[4] * sy + pose.r[5] * sz;
+                    const float z = czm + pose.r[6] * sx + pose.r[7] * sy + pose.r[8] * sz;
+                    const float iz = 1.0f / z;
+                    const float u = cam.fx * x * iz + cam.cx, v = cam.fy * y * iz + cam.cy;
+                    umin = fminf(umin, u); umax = fmaxf(umax, u);
+                    vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
+                    zmin = fminf(zmin, z); zmax = fmaxf(zmax, z);
+                }
+                umin -= 1.5f; umax += 1.5f; vmin -= 1.5f; vmax += 1.5f;
+                if (umax < 0.0f || vmax < 0.0f || umin > (float)(cam.W - 1) || vmin > (float)(cam.H - 1)) {
+                    cls = 0;
+                } else {
+                    const bool inside = umin >= 0.0f && vmin >= 0.0f && umax <= (float)(cam.W - 1) && vmax <= (float)(cam.H - 1);
+                    const int pu0 = max(0, (int)floorf(umin)), pu1 = min(cam.W - 1, (int)ceilf(umax));
+                    const int pv0 = max(0, (int)floorf(vmin)), pv1 = min(cam.H - 1, (int)ceilf(vmax));
+                    // finest level at which the pixel box spans at most 4 tiles per axis: 16 independent lookups
+                    int L = 0;
+                    while (L < py.nlev - 1 && (((pu1 >> (TILE_SHIFT + L)) - (pu0 >> (TILE_SHIFT + L))) > 3 ||
+                                               ((pv1 >> (TILE_SHIFT + L)) - (pv0 >> (TILE_SHIFT + L))) > 3))
+                        ++L;
+                    const int tu0 = pu0 >> (TILE_SHIFT + L), tu1 = pu1 >> (TILE_SHIFT + L);
+                    const int tv0 = pv0 >> (TILE_SHIFT + L), tv1 = pv1 >> (TILE_SHIFT + L);
+                    const float4 *__restrict__ lv = tiles + py.off[L];
+                    const int nt = py.ntx[L];
+                    float4 a = make_float4(INFINITY, -INFINITY, 1.0f, 0.0f);
+#pragma unroll
+                    for (int dv = 0; dv < 4; ++dv)
+#pragma unroll
+                        for (int du = 0; du < 4; ++du) {
+                            const float4 b = lv[min(tv0 + dv, tv1) * nt + min(tu0 + du, tu1)];   // clamped: repeats are harmless
+                            a.x = fminf(a.x, b.x);
+                            a.y = fmaxf(a.y, b.y);
+                            a.z = fminf(a.z, b.z);
+                        }
+                    const float m = 0.01f * g.vs;
+                    if (!(a.y > -INFINITY) || (zmin - m > a.y + g.trunc)) {
+                        cls = 0;        // no valid depth under the brick, or the brick is > trunc behind all it can see
+                    } else if (inside && a.z > 0.5f && (a.x - (zmax + m) >= g.trunc * 1.001f)) {
+                        cls = 2;        // every voxel: in image, valid depth, sdf >= trunc  =>  tsdf == 1 exactly
+                    }
+                }
+            }
         }
-        if (COUNT) ++nvisited;
+    }
+    const int lane = threadIdx.x & 63;
+    const unsigned long long mm = __ballot(cls == 1), mf = __ballot(cls == 2);
+    unsigned bm = 0, bf = 0;
+    if (lane == 0) {
+        if (mm) bm = atomicAdd(list_counts + 0, (unsigned)__popcll(mm));
+        if (mf) bf = atomicAdd(list_counts + 1, (unsigned)__popcll(mf));
+    }
+    bm = __shfl(bm, 0);
+    bf = __shfl(bf, 0);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (cls == 1) list[bm + __popcll(mm & below)] = (unsigned)brick;
+    if (cls == 2) list[(unsigned)nbricks - 1u - (bf + __popcll(mf & below))] = (unsigned)brick | FREE_FLAG;
+}
+
+// ---- 4. integration --------------------------------------------------------------------------------------
+// Per-voxel rule, split in two so that a wave can issue all its depth gathers before it needs any of them.
+// project(): camera-space voxel centre -> clamped pixel address + "could update" flag (no memory access).
+// finish():  depth value -> quantised tsdf + final flag.  Together they are exactly orc_tsdf_integrate's sequence.
+__device__ __forceinline__ bool tsdf_project(const Cam &cam, const TsdfConst &c, float xc, float yc, float zc, int &pix) {
+    bool ok = zc > 0.0f;
+    const float inv = 1.0f / zc;
+    const float uf = fmaf(cam.fx * xc, inv, cam.cx);
+    const float vf = fmaf(cam.fy * yc, inv, cam.cy);
+    ok = ok && (uf >= -0.5f && uf < c.wlim && vf >= -0.5f && vf < c.hlim);
+    int u = (int)floorf(uf + 0.5f), v = (int)floorf(vf + 0.5f);
+    u = min(max(u, 0), cam.W - 1);          // always a legal address, so the gather needs no branch
+    v = min(max(v, 0), cam.H - 1);
+    pix = v * cam.W + u;
+    return ok;
+}
+
+__device__ __forceinline__ bool tsdf_finish(const Grid &g, const TsdfConst &c, bool ok, float draw, float zc, int &q) {
+    const float d = draw * c.sc;
+    ok = ok && (d > c.mind && d < c.maxd);
+    const float sdf = d - zc;
+    ok = ok && (sdf >= -g.trunc);
+    const float tsdf = fminf(1.0f, sdf * g.inv_trunc);
+    q = (int)rintf(tsdf * 32767.0f);
+    return ok;
+}
+
+// DBG: timing experiments only (TL3D_DEBUG_ONLY=1 -> MIXED bricks only, 2 -> FREE bricks only); results incomplete.
+template <bool COUNT, int DBG>
+__global__ __launch_bounds__(256) void tsdf_integrate_kernel(Cam cam, Grid g, PoseF pose, TsdfConst c,
+                                                             const float *__restrict__ depth,
+                                                             const unsigned *__restrict__ list,
+                                                             const unsigned *__restrict__ list_counts,
+                                                             int2 *__restrict__ grid, unsigned long long *__restrict__ counters) {
+    const int lane = threadIdx.x & 63;
+    const int wid = threadIdx.x >> 6;
+    unsigned nmixed = list_counts[0], nfree = list_counts[1];
+    if (DBG == 1) nfree = 0;
+    const unsigned nlist = nmixed + nfree;
+    const unsigned nbricks = (unsigned)(g.nbx * g.nby * g.nbz);
+    unsigned nread = 0, nwritten = 0;
+    for (unsigned li0 = blockIdx.x * 4; li0 < nlist; li0 += gridDim.x * 4) {
+        const unsigned li = li0 + wid;
+        if (li >= nlist) break;
+        if (DBG == 2 && li < nmixed) continue;
+        // MIXED entries sit at the front of the list, FREE entries at the back (filled downwards)
+        const unsigned e = __builtin_amdgcn_readfirstlane(list[li < nmixed ? li : nbricks - 1u - (li - nmixed)]);
+        const int brick = (int)(e & ~FREE_FLAG);
         int4 *__restrict__ recs = reinterpret_cast<int4 *>(grid + ((size_t)brick << 9));
+        if (e & FREE_FLAG) {
+            int4 r0 = recs[lane], r1 = recs[64 + lane], r2 = recs[128 + lane], r3 = recs[192 + lane];
+            r0.x += 32767; r0.y += 1; r0.z += 32767; r0.w += 1;
+            r1.x += 32767; r1.y += 1; r1.z += 32767; r1.w += 1;
+            r2.x += 32767; r2.y += 1; r2.z += 32767; r2.w += 1;
+            r3.x += 32767; r3.y += 1; r3.z += 32767; r3.w += 1;
+            recs[lane] = r0; recs[64 + lane] = r1; recs[128 + lane] = r2; recs[192 + lane] = r3;
+            if (COUNT) { nread += 8; nwritten += 8; }
+            continue;
+        }
+        const int bx = brick % g.nbx;
+        const int by = (brick / g.nbx) % g.nby;
+        const int bz = brick / (g.nbx * g.nby);
+        // phase 1: project the lane's 8 voxels, issue the 8 depth gathers back to back
+        float zc[8], dv[8];
+        bool ok[8];
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int pr = it * 64 + lane;
@@ -83,21 +273,32 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(Cam cam, Grid g, Po
             const float ax = fmaf(pose.r[1], py, fmaf(pose.r[2], pz, pose.t[0]));
             const float ay = fmaf(pose.r[4], py, fmaf(pose.r[5], pz, pose.t[1]));
             const float az = fmaf(pose.r[7], py, fmaf(pose.r[8], pz, pose.t[2]));
-            const float px0 = fmaf((float)i + 0.5f, g.vs, g.ox);
-            const float px1 = fmaf((float)(i + 1) + 0.5f, g.vs, g.ox);
-            int q0 = 0, q1 = 0;
-            const bool u0 = tsdf_voxel(cam, g, c, depth, fmaf(pose.r[0], px0, ax), fmaf(pose.r[3], px0, ay),
-                                       fmaf(pose.r[6], px0, az), q0);
-            const bool u1 = tsdf_voxel(cam, g, c, depth, fmaf(pose.r[0], px1, ax), fmaf(pose.r[3], px1, ay),
-                                       fmaf(pose.r[6], px1, az), q1);
-            if (u0 | u1) {
-                int4 rec = recs[pr];
-                if (u0) { rec.x += q0; rec.y += 1; }
-                if (u1) { rec.z += q1; rec.w += 1; }
-                recs[pr] = rec;
-                if (COUNT) { nread += 2; nwritten += 2; }
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const float px = fmaf((float)(i + hh) + 0.5f, g.vs, g.ox);
+                const float xc = fmaf(pose.r[0], px, ax), yc = fmaf(pose.r[3], px, ay);
+                zc[2 * it + hh] = fmaf(pose.r[6], px, az);
+                int pix;
+                ok[2 * it + hh] = tsdf_project(cam, c, xc, yc, zc[2 * it + hh], pix);
+                dv[2 * it + hh] = depth[pix];
             }
         }
+        // phase 2: decide; phase 3: load the 16-B pairs that change; phase 4: add and store them
+        int q[8];
+#pragma unroll
+        for (int e8 = 0; e8 < 8; ++e8) ok[e8] = tsdf_finish(g, c, ok[e8], dv[e8], zc[e8], q[e8]);
+        int4 rec[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+            if (ok[2 * it] | ok[2 * it + 1]) rec[it] = recs[it * 64 + lane];
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+            if (ok[2 * it] | ok[2 * it + 1]) {
+                if (ok[2 * it]) { rec[it].x += q[2 * it]; rec[it].y += 1; }
+                if (ok[2 * it + 1]) { rec[it].z += q[2 * it + 1]; rec[it].w += 1; }
+                recs[it * 64 + lane] = rec[it];
+                if (COUNT) { nread += 2; nwritten += 2; }
+            }
     }
     if (COUNT) {
 #pragma unroll
@@ -108,27 +309,101 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(Cam cam, Grid g, Po
         if (lane == 0) {
             atomicAdd(counters + 2, (unsigned long long)nread);
             atomicAdd(counters + 3, (unsigned long long)nwritten);
-            atomicAdd(counters + 4, (unsigned long long)nvisited);
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            atomicAdd(counters + 4, (unsigned long long)nlist);
+            atomicAdd(counters + 5, (unsigned long long)nfree);
         }
     }
 }
 
-int launch_tsdf_integrate(hipStream_t s, const Cam &cam, const Grid &g, const PoseF &p, const Frustum &fr, const float *depth,
-                          float scale, float mind, float maxd, int2 *grid, unsigned long long *counters, bool count) {
+static Pyramid make_pyramid(const Cam &cam) {
+    Pyramid p;
+    memset(&p, 0, sizeof(p));
+    int nx = (cam.W + TILE - 1) / TILE, ny = (cam.H + TILE - 1) / TILE, off = 0, L = 0;
+    for (;;) {
+        p.ntx[L] = nx; p.nty[L] = ny; p.off[L] = off;
+        off += nx * ny;
+        ++L;
+        if ((nx == 1 && ny == 1) || L == MAX_LEVELS) break;
+        nx = (nx + 1) / 2;
+        ny = (ny + 1) / 2;
+    }
+    p.nlev = L;
+    return p;
+}
+
+static size_t pyramid_tiles(const Pyramid &p) { return (size_t)p.off[p.nlev - 1] + (size_t)p.ntx[p.nlev - 1] * p.nty[p.nlev - 1]; }
+
+size_t tsdf_scratch_bytes(const Cam &cam, const Grid &g) {
+    const Pyramid p = make_pyramid(cam);
+    const size_t nbricks = (size_t)g.nbx * g.nby * g.nbz;
+    return 256 + pyramid_tiles(p) * sizeof(float4) + (nbricks + 64) * sizeof(unsigned);
+}
+
+struct TsdfScratch {
+    unsigned *list_counts;       // [0] mixed, [1] free
+    float4 *tiles;
+    unsigned *list;
+    Pyramid py;
+};
+
+static TsdfScratch carve(const Cam &cam, void *scratch) {
+    TsdfScratch t;
+    t.py = make_pyramid(cam);
+    // scratch layout: [list_counts (256 B)] [tile pyramid] [brick list]
+    t.list_counts = reinterpret_cast<unsigned *>(scratch);
+    t.tiles = reinterpret_cast<float4 *>(reinterpret_cast<char *>(scratch) + 256);
+    t.list = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(scratch) + 256 + pyramid_tiles(t.py) * sizeof(float4));
+    return t;
+}
+
+static TsdfConst make_const(const Cam &cam, float scale, float mind, float maxd) {
     TsdfConst c;
     c.mind = mind;
     c.maxd = maxd;
     c.sc = scale;
     c.wlim = (float)cam.W - 0.5f;
     c.hlim = (float)cam.H - 0.5f;
+    return c;
+}
+
+// depth tiles + pyramid + brick classification -> compact brick list in scratch
+int launch_tsdf_prepare(hipStream_t s, const Cam &cam, const Grid &g, const PoseF &p, const Frustum &fr, const float *depth,
+                        float scale, float mind, float maxd, void *scratch) {
+    const TsdfConst c = make_const(cam, scale, mind, maxd);
+    const TsdfScratch t = carve(cam, scratch);
+    const int nbricks = g.nbx * g.nby * g.nbz;
+    hipLaunchKernelGGL(depth_tiles_kernel, dim3(t.py.ntx[0], t.py.nty[0]), dim3(256), 0, s, cam, c, depth, t.py.ntx[0], t.tiles,
+                       t.list_counts);
+    TL3D_HIP(hipGetLastError());
+    if (t.py.nlev > 1) {
+        hipLaunchKernelGGL(tile_pyramid_kernel, dim3(1), dim3(1024), 0, s, t.py, t.tiles);
+        TL3D_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(brick_cull_kernel, dim3((nbricks + 255) / 256), dim3(256), 0, s, cam, g, p, fr, t.py, t.tiles, t.list,
+                       t.list_counts);
+    TL3D_HIP(hipGetLastError());
+    return TL3D_OK;
+}
+
+// the dominant kernel: read-modify-write of the listed bricks
+int launch_tsdf_update(hipStream_t s, const Cam &cam, const Grid &g, const PoseF &p, const float *depth, float scale, float mind,
+                       float maxd, int2 *grid, void *scratch, unsigned long long *counters, bool count) {
+    const TsdfConst c = make_const(cam, scale, mind, maxd);
+    const TsdfScratch t = carve(cam, scratch);
     const int nbricks = g.nbx * g.nby * g.nbz;
     int nblk = (nbricks + 3) / 4;
     if (nblk > 2048) nblk = 2048;
-    nblk = (nblk + 7) & ~7;
+    static const int dbg = getenv("TL3D_DEBUG_ONLY") ? atoi(getenv("TL3D_DEBUG_ONLY")) : 0;
     if (count)
-        hipLaunchKernelGGL(tsdf_integrate_kernel<true>, dim3(nblk), dim3(256), 0, s, cam, g, p, fr, c, depth, grid, counters);
+        hipLaunchKernelGGL((tsdf_integrate_kernel<true, 0>), dim3(nblk), dim3(256), 0, s, cam, g, p, c, depth, t.list, t.list_counts, grid, counters);
+    else if (dbg == 1)
+        hipLaunchKernelGGL((tsdf_integrate_kernel<false, 1>), dim3(nblk), dim3(256), 0, s, cam, g, p, c, depth, t.list, t.list_counts, grid, counters);
+    else if (dbg == 2)
+        hipLaunchKernelGGL((tsdf_integrate_kernel<false, 2>), dim3(nblk), dim3(256), 0, s, cam, g, p, c, depth, t.list, t.list_counts, grid, counters);
     else
-        hipLaunchKernelGGL(tsdf_integrate_kernel<false>, dim3(nblk), dim3(256), 0, s, cam, g, p, fr, c, depth, grid, counters);
+        hipLaunchKernelGGL((tsdf_integrate_kernel<false, 0>), dim3(nblk), dim3(256), 0, s, cam, g, p, c, depth, t.list, t.list_counts, grid, counters);
     TL3D_HIP(hipGetLastError());
     return TL3D_OK;
 }

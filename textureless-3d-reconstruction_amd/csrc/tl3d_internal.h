@@ -82,6 +82,7 @@ struct tl3d_ctx {
     bool own_tsdf, own_centroid;
     // scratch
     uint16_t *stage_u16;         // u16 depth staging
+    void *tsdf_scratch;          // depth tiles + compact brick list of the current frame
     unsigned *block_counts;      // compaction counts
     unsigned long long *block_offsets;
     size_t scratch_blocks;
@@ -133,8 +134,11 @@ int launch_centroid_points(hipStream_t s, const Grid &g, const float *xyz, const
                            unsigned long long *grid, unsigned long long *counters);
 int launch_bounds(hipStream_t s, const float *xyz, long long n, float *slab, int nblocks);
 // tsdf
-int launch_tsdf_integrate(hipStream_t s, const Cam &cam, const Grid &g, const PoseF &p, const Frustum &fr, const float *depth,
-                          float scale, float mind, float maxd, int2 *grid, unsigned long long *counters, bool count);
+size_t tsdf_scratch_bytes(const Cam &cam, const Grid &g);
+int launch_tsdf_prepare(hipStream_t s, const Cam &cam, const Grid &g, const PoseF &p, const Frustum &fr, const float *depth,
+                        float scale, float mind, float maxd, void *scratch);
+int launch_tsdf_update(hipStream_t s, const Cam &cam, const Grid &g, const PoseF &p, const float *depth, float scale, float mind,
+                       float maxd, int2 *grid, void *scratch, unsigned long long *counters, bool count);
 // normals + icp
 int launch_normals(hipStream_t s, const Cam &cam, const float *depth, float scale, float mind, float maxd, float jump, float4 *nmap);
 int launch_icp_iteration(hipStream_t s, const Cam &cam, const float *depth_src, float scale, float mind, float maxd,
