@@ -6,7 +6,8 @@
 // Launches per frame, all on the ctx stream:
 //   1. depth_tiles_kernel     32x32-pixel tiles -> (min, max, all-valid) of the valid scaled depth   4 B/pixel read
 //   2. tile_pyramid_kernel    1 block: 2x2 reductions of the tiles up to a single tile
-//   3. brick_cull_kernel      one thread per 8^3 brick classifies it from <= 16 pyramid lookups:
+//   3. brick_cull_kernel      one lane per 8^3 brick (one wave per 4x4x4-brick cell) classifies it from <= 16
+//                             pyramid lookups:
 //        SKIP   outside the view, no valid depth under it, or more than trunc behind every surface it can see
 //        FREE   wholly inside the image, every pixel under it valid, and at least trunc in front of every
 //               surface: every voxel gets exactly tsdf = 1 (q = 32767), so no depth lookup is needed
@@ -109,92 +110,112 @@ __global__ __launch_bounds__(1024) void tile_pyramid_kernel(Pyramid py, float4 *
 }
 
 // ---- 3. brick classification ------------------------------------------------------------------------------
+// One wave per cell of 4x4x4 bricks, one lane per brick.  A cell whose bounding sphere misses the view exits after
+// a handful of instructions (most of the grid); the four waves of a workgroup pool their survivors so the two list
+// cursors see one atomic per workgroup, not per wave (same-address returning atomics retire at ~90 per microsecond).
 // Margins: 1.5 px on projected bounds, 1 % of a voxel on depths, 0.1 % on the truncation distance.
+__device__ __forceinline__ bool sphere_in_view(const Frustum &fr, float x, float y, float z, float rad) {
+    return (z + rad > 0.0f) && (fr.lx * x + fr.lz * z >= -rad) && (fr.rx * x + fr.rz * z >= -rad) &&
+           (fr.ty * y + fr.tz * z >= -rad) && (fr.by * y + fr.bz * z >= -rad);
+}
+
 __global__ __launch_bounds__(256) void brick_cull_kernel(Cam cam, Grid g, PoseF pose, Frustum fr, Pyramid py,
                                                          const float4 *__restrict__ tiles, unsigned *__restrict__ list,
                                                          unsigned *__restrict__ list_counts) {
-    const int nbricks = g.nbx * g.nby * g.nbz;
-    const int brick = blockIdx.x * 256 + threadIdx.x;
+    __shared__ unsigned s_cnt[4][2];
+    __shared__ unsigned s_base[2];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int ncx = (g.nbx + 3) >> 2, ncy = (g.nby + 3) >> 2, ncz = (g.nbz + 3) >> 2;
+    const int cell = blockIdx.x * 4 + wid;
+    const unsigned nbricks = (unsigned)(g.nbx * g.nby * g.nbz);
     int cls = 0;                                                  // 0 skip, 1 mixed, 2 free
-    if (brick < nbricks) {
-        const int bx = brick % g.nbx;
-        const int by = (brick / g.nbx) % g.nby;
-        const int bz = brick / (g.nbx * g.nby);
-        const float rad = 6.9282032f * g.vs * 1.01f;                 // half diagonal of a brick, +1 %
-        const float wx = fmaf((float)(bx * 8 + 4), g.vs, g.ox);
-        const float wy = fmaf((float)(by * 8 + 4), g.vs, g.oy);
-        const float wz = fmaf((float)(bz * 8 + 4), g.vs, g.oz);
-        const float cxm = pose.r[0] * wx + pose.r[1] * wy + pose.r[2] * wz + pose.t[0];
-        const float cym = pose.r[3] * wx + pose.r[4] * wy + pose.r[5] * wz + pose.t[1];
-        const float czm = pose.r[6] * wx + pose.r[7] * wy + pose.r[8] * wz + pose.t[2];
-        const bool in_view = (czm + rad > 0.0f) && (fr.lx * cxm + fr.lz * czm >= -rad) && (fr.rx * cxm + fr.rz * czm >= -rad) &&
-                             (fr.ty * cym + fr.tz * czm >= -rad) && (fr.by * cym + fr.bz * czm >= -rad);
-        if (in_view) {
-            cls = 1;
-            if (czm - rad > 1e-3f) {
-                // all 8 corners are in front of the camera: the voxel centres project inside the corners' pixel box
-                const float h = 4.0f * g.vs;
-                float umin = INFINITY, umax = -INFINITY, vmin = INFINITY, vmax = -INFINITY, zmin = INFINITY, zmax = -INFINITY;
+    int brick = 0;
+    if (cell < ncx * ncy * ncz) {
+        const int ccx = cell % ncx, ccy = (cell / ncx) % ncy, ccz = cell / (ncx * ncy);
+        const float crad = 27.712812f * g.vs * 1.01f;               // half diagonal of a 32^3-voxel cell, +1 %
+        const float qx = fmaf((float)(ccx * 32 + 16), g.vs, g.ox), qy = fmaf((float)(ccy * 32 + 16), g.vs, g.oy);
+        const float qz = fmaf((float)(ccz * 32 + 16), g.vs, g.oz);
+        const float ex = pose.r[0] * qx + pose.r[1] * qy + pose.r[2] * qz + pose.t[0];
+        const float ey = pose.r[3] * qx + pose.r[4] * qy + pose.r[5] * qz + pose.t[1];
+        const float ez = pose.r[6] * qx + pose.r[7] * qy + pose.r[8] * qz + pose.t[2];
+        const int bx = ccx * 4 + (lane & 3), by = ccy * 4 + ((lane >> 2) & 3), bz = ccz * 4 + (lane >> 4);
+        if (sphere_in_view(fr, ex, ey, ez, crad) && bx < g.nbx && by < g.nby && bz < g.nbz) {
+            brick = (bz * g.nby + by) * g.nbx + bx;
+            const float rad = 6.9282032f * g.vs * 1.01f;             // half diagonal of a brick, +1 %
+            const float wx = fmaf((float)(bx * 8 + 4), g.vs, g.ox);
+            const float wy = fmaf((float)(by * 8 + 4), g.vs, g.oy);
+            const float wz = fmaf((float)(bz * 8 + 4), g.vs, g.oz);
+            const float cxm = pose.r[0] * wx + pose.r[1] * wy + pose.r[2] * wz + pose.t[0];
+            const float cym = pose.r[3] * wx + pose.r[4] * wy + pose.r[5] * wz + pose.t[1];
+            const float czm = pose.r[6] * wx + pose.r[7] * wy + pose.r[8] * wz + pose.t[2];
+            if (sphere_in_view(fr, cxm, cym, czm, rad)) {
+                cls = 1;
+                if (czm - rad > 1e-3f) {
+                    // all 8 corners are in front of the camera: the voxel centres project inside the corners' pixel box
+                    const float h = 4.0f * g.vs;
+                    float umin = INFINITY, umax = -INFINITY, vmin = INFINITY, vmax = -INFINITY, zmin = INFINITY, zmax = -INFINITY;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const float sx = (k & 1) ? h : -h, sy = (k & 2) ? h : -h, sz = (k & 4) ? h : -h;
-                    const float x = cxm + pose.r[0] * sx + pose.r[1] * sy + pose.r[2] * sz;
-                    const float y = cym + pose.r[3] * sx + pose.r[4] * sy + pose.r[5] * sz;
-                    const float z = czm + pose.r[6] * sx + pose.r[7] * sy + pose.r[8] * sz;
-                    const float iz = 1.0f / z;
-                    const float u = cam.fx * x * iz + cam.cx, v = cam.fy * y * iz + cam.cy;
-                    umin = fminf(umin, u); umax = fmaxf(umax, u);
-                    vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
-                    zmin = fminf(zmin, z); zmax = fmaxf(zmax, z);
-                }
-                umin -= 1.5f; umax += 1.5f; vmin -= 1.5f; vmax += 1.5f;
-                if (umax < 0.0f || vmax < 0.0f || umin > (float)(cam.W - 1) || vmin > (float)(cam.H - 1)) {
-                    cls = 0;
-                } else {
-                    const bool inside = umin >= 0.0f && vmin >= 0.0f && umax <= (float)(cam.W - 1) && vmax <= (float)(cam.H - 1);
-                    const int pu0 = max(0, (int)floorf(umin)), pu1 = min(cam.W - 1, (int)ceilf(umax));
-                    const int pv0 = max(0, (int)floorf(vmin)), pv1 = min(cam.H - 1, (int)ceilf(vmax));
-                    // finest level at which the pixel box spans at most 4 tiles per axis: 16 independent lookups
-                    int L = 0;
-                    while (L < py.nlev - 1 && (((pu1 >> (TILE_SHIFT + L)) - (pu0 >> (TILE_SHIFT + L))) > 3 ||
-                                               ((pv1 >> (TILE_SHIFT + L)) - (pv0 >> (TILE_SHIFT + L))) > 3))
-                        ++L;
-                    const int tu0 = pu0 >> (TILE_SHIFT + L), tu1 = pu1 >> (TILE_SHIFT + L);
-                    const int tv0 = pv0 >> (TILE_SHIFT + L), tv1 = pv1 >> (TILE_SHIFT + L);
-                    const float4 *__restrict__ lv = tiles + py.off[L];
-                    const int nt = py.ntx[L];
-                    float4 a = make_float4(INFINITY, -INFINITY, 1.0f, 0.0f);
+                    for (int k = 0; k < 8; ++k) {
+                        const float sx = (k & 1) ? h : -h, sy = (k & 2) ? h : -h, sz = (k & 4) ? h : -h;
+                        const float x = cxm + pose.r[0] * sx + pose.r[1] * sy + pose.r[2] * sz;
+                        const float y = cym + pose.r[3] * sx + pose.r[4] * sy + pose.r[5] * sz;
+                        const float z = czm + pose.r[6] * sx + pose.r[7] * sy + pose.r[8] * sz;
+                        const float iz = __builtin_amdgcn_rcpf(z);     // 1 ulp; the 1.5 px margin absorbs it
+                        const float u = cam.fx * x * iz + cam.cx, v = cam.fy * y * iz + cam.cy;
+                        umin = fminf(umin, u); umax = fmaxf(umax, u);
+                        vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
+                        zmin = fminf(zmin, z); zmax = fmaxf(zmax, z);
+                    }
+                    umin -= 1.5f; umax += 1.5f; vmin -= 1.5f; vmax += 1.5f;
+                    if (umax < 0.0f || vmax < 0.0f || umin > (float)(cam.W - 1) || vmin > (float)(cam.H - 1)) {
+                        cls = 0;
+                    } else {
+                        const bool inside = umin >= 0.0f && vmin >= 0.0f && umax <= (float)(cam.W - 1) && vmax <= (float)(cam.H - 1);
+                        const int pu0 = max(0, (int)floorf(umin)), pu1 = min(cam.W - 1, (int)ceilf(umax));
+                        const int pv0 = max(0, (int)floorf(vmin)), pv1 = min(cam.H - 1, (int)ceilf(vmax));
+                        // finest level at which the pixel box spans at most 4 tiles per axis: 16 independent lookups
+                        int L = 0;
+                        while (L < py.nlev - 1 && (((pu1 >> (TILE_SHIFT + L)) - (pu0 >> (TILE_SHIFT + L))) > 3 ||
+                                                   ((pv1 >> (TILE_SHIFT + L)) - (pv0 >> (TILE_SHIFT + L))) > 3))
+                            ++L;
+                        const int tu0 = pu0 >> (TILE_SHIFT + L), tu1 = pu1 >> (TILE_SHIFT + L);
+                        const int tv0 = pv0 >> (TILE_SHIFT + L), tv1 = pv1 >> (TILE_SHIFT + L);
+                        const float4 *__restrict__ lv = tiles + py.off[L];
+                        const int nt = py.ntx[L];
+                        float4 a = make_float4(INFINITY, -INFINITY, 1.0f, 0.0f);
 #pragma unroll
-                    for (int dv = 0; dv < 4; ++dv)
+                        for (int dv = 0; dv < 4; ++dv)
 #pragma unroll
-                        for (int du = 0; du < 4; ++du) {
-                            const float4 b = lv[min(tv0 + dv, tv1) * nt + min(tu0 + du, tu1)];   // clamped: repeats are harmless
-                            a.x = fminf(a.x, b.x);
-                            a.y = fmaxf(a.y, b.y);
-                            a.z = fminf(a.z, b.z);
+                            for (int du = 0; du < 4; ++du) {
+                                const float4 b = lv[min(tv0 + dv, tv1) * nt + min(tu0 + du, tu1)];   // clamped: repeats are harmless
+                                a.x = fminf(a.x, b.x);
+                                a.y = fmaxf(a.y, b.y);
+                                a.z = fminf(a.z, b.z);
+                            }
+                        const float m = 0.01f * g.vs;
+                        if (!(a.y > -INFINITY) || (zmin - m > a.y + g.trunc)) {
+                            cls = 0;        // no valid depth under the brick, or the brick is > trunc behind all it can see
+                        } else if (inside && a.z > 0.5f && (a.x - (zmax + m) >= g.trunc * 1.001f)) {
+                            cls = 2;        // every voxel: in image, valid depth, sdf >= trunc  =>  tsdf == 1 exactly
                         }
-                    const float m = 0.01f * g.vs;
-                    if (!(a.y > -INFINITY) || (zmin - m > a.y + g.trunc)) {
-                        cls = 0;        // no valid depth under the brick, or the brick is > trunc behind all it can see
-                    } else if (inside && a.z > 0.5f && (a.x - (zmax + m) >= g.trunc * 1.001f)) {
-                        cls = 2;        // every voxel: in image, valid depth, sdf >= trunc  =>  tsdf == 1 exactly
                     }
                 }
             }
         }
     }
-    const int lane = threadIdx.x & 63;
     const unsigned long long mm = __ballot(cls == 1), mf = __ballot(cls == 2);
-    unsigned bm = 0, bf = 0;
-    if (lane == 0) {
-        if (mm) bm = atomicAdd(list_counts + 0, (unsigned)__popcll(mm));
-        if (mf) bf = atomicAdd(list_counts + 1, (unsigned)__popcll(mf));
+    if (lane == 0) { s_cnt[wid][0] = (unsigned)__popcll(mm); s_cnt[wid][1] = (unsigned)__popcll(mf); }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const unsigned tot = s_cnt[0][threadIdx.x] + s_cnt[1][threadIdx.x] + s_cnt[2][threadIdx.x] + s_cnt[3][threadIdx.x];
+        s_base[threadIdx.x] = tot ? atomicAdd(list_counts + threadIdx.x, tot) : 0u;
     }
-    bm = __shfl(bm, 0);
-    bf = __shfl(bf, 0);
+    __syncthreads();
+    unsigned bm = s_base[0], bf = s_base[1];
+    for (int w = 0; w < wid; ++w) { bm += s_cnt[w][0]; bf += s_cnt[w][1]; }
     const unsigned long long below = (1ull << lane) - 1ull;
     if (cls == 1) list[bm + __popcll(mm & below)] = (unsigned)brick;
-    if (cls == 2) list[(unsigned)nbricks - 1u - (bf + __popcll(mf & below))] = (unsigned)brick | FREE_FLAG;
+    if (cls == 2) list[nbricks - 1u - (bf + __popcll(mf & below))] = (unsigned)brick | FREE_FLAG;
 }
 
 // ---- 4. integration --------------------------------------------------------------------------------------
@@ -373,7 +394,6 @@ int launch_tsdf_prepare(hipStream_t s, const Cam &cam, const Grid &g, const Pose
                         float scale, float mind, float maxd, void *scratch) {
     const TsdfConst c = make_const(cam, scale, mind, maxd);
     const TsdfScratch t = carve(cam, scratch);
-    const int nbricks = g.nbx * g.nby * g.nbz;
     hipLaunchKernelGGL(depth_tiles_kernel, dim3(t.py.ntx[0], t.py.nty[0]), dim3(256), 0, s, cam, c, depth, t.py.ntx[0], t.tiles,
                        t.list_counts);
     TL3D_HIP(hipGetLastError());
@@ -381,7 +401,8 @@ int launch_tsdf_prepare(hipStream_t s, const Cam &cam, const Grid &g, const Pose
         hipLaunchKernelGGL(tile_pyramid_kernel, dim3(1), dim3(1024), 0, s, t.py, t.tiles);
         TL3D_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(brick_cull_kernel, dim3((nbricks + 255) / 256), dim3(256), 0, s, cam, g, p, fr, t.py, t.tiles, t.list,
+    const int ncells = ((g.nbx + 3) / 4) * ((g.nby + 3) / 4) * ((g.nbz + 3) / 4);
+    hipLaunchKernelGGL(brick_cull_kernel, dim3((ncells + 3) / 4), dim3(256), 0, s, cam, g, p, fr, t.py, t.tiles, t.list,
                        t.list_counts);
     TL3D_HIP(hipGetLastError());
     return TL3D_OK;
@@ -393,8 +414,10 @@ int launch_tsdf_update(hipStream_t s, const Cam &cam, const Grid &g, const PoseF
     const TsdfConst c = make_const(cam, scale, mind, maxd);
     const TsdfScratch t = carve(cam, scratch);
     const int nbricks = g.nbx * g.nby * g.nbz;
+    // 6 workgroups per CU: leaves wave slots for the next frame's prep kernels, which run concurrently
+    static const int max_blk = getenv("TL3D_UPDATE_BLOCKS") ? atoi(getenv("TL3D_UPDATE_BLOCKS")) : 1536;
     int nblk = (nbricks + 3) / 4;
-    if (nblk > 2048) nblk = 2048;
+    if (nblk > max_blk) nblk = max_blk;
     static const int dbg = getenv("TL3D_DEBUG_ONLY") ? atoi(getenv("TL3D_DEBUG_ONLY")) : 0;
     if (count)
         hipLaunchKernelGGL((tsdf_integrate_kernel<true, 0>), dim3(nblk), dim3(256), 0, s, cam, g, p, c, depth, t.list, t.list_counts, grid, counters);

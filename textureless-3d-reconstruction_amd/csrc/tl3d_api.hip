@@ -170,7 +170,17 @@ int tl3d_create(const tl3d_config *cfg, int device, tl3d_ctx **out) {
                 ctx->own_tsdf = true;
                 if (hipMemsetAsync(ctx->tsdf, 0, ctx->nvox * sizeof(int2), ctx->stream) != hipSuccess) return fail(set_err(TL3D_E_HIP, "memset failed"));
             }
-            if (hipMalloc(&ctx->tsdf_scratch, tsdf_scratch_bytes(ctx->cam, g)) != hipSuccess) return fail(set_err(TL3D_E_NOMEM, "TSDF scratch alloc failed"));
+            {   // the prep kernels are short and latency-bound: give them dispatch priority over the streaming update
+                int lo = 0, hi = 0;
+                (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+                if (hipStreamCreateWithPriority(&ctx->prep_stream, hipStreamNonBlocking, hi) != hipSuccess) return fail(set_err(TL3D_E_HIP, "stream create failed"));
+            }
+            for (int b = 0; b < 2; ++b) {
+                if (hipMalloc(&ctx->tsdf_scratch[b], tsdf_scratch_bytes(ctx->cam, g)) != hipSuccess) return fail(set_err(TL3D_E_NOMEM, "TSDF scratch alloc failed"));
+                if (hipEventCreateWithFlags(&ctx->ev_prep[b], hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&ctx->ev_upd[b], hipEventDisableTiming) != hipSuccess)
+                    return fail(set_err(TL3D_E_HIP, "event create failed"));
+            }
         }
         if (cfg->channels & TL3D_CH_CENTROID) {
             if (cfg->ext_centroid) {
@@ -204,13 +214,20 @@ int tl3d_destroy(tl3d_ctx *ctx) {
             if (ctx->slots[i].depth) (void)hipFree(ctx->slots[i].depth);
             if (ctx->slots[i].bgr) (void)hipFree(ctx->slots[i].bgr);
             if (ctx->slots[i].nmap) (void)hipFree(ctx->slots[i].nmap);
+            if (ctx->slots[i].ev_upload) (void)hipEventDestroy(ctx->slots[i].ev_upload);
         }
         delete[] ctx->slots;
     }
     if (ctx->own_tsdf && ctx->tsdf) (void)hipFree(ctx->tsdf);
     if (ctx->own_centroid && ctx->centroid) (void)hipFree(ctx->centroid);
     if (ctx->stage_u16) (void)hipFree(ctx->stage_u16);
-    if (ctx->tsdf_scratch) (void)hipFree(ctx->tsdf_scratch);
+    if (ctx->prep_stream) (void)hipStreamSynchronize(ctx->prep_stream);
+    for (int b = 0; b < 2; ++b) {
+        if (ctx->tsdf_scratch[b]) (void)hipFree(ctx->tsdf_scratch[b]);
+        if (ctx->ev_prep[b]) (void)hipEventDestroy(ctx->ev_prep[b]);
+        if (ctx->ev_upd[b]) (void)hipEventDestroy(ctx->ev_upd[b]);
+    }
+    if (ctx->prep_stream) (void)hipStreamDestroy(ctx->prep_stream);
     if (ctx->block_counts) (void)hipFree(ctx->block_counts);
     if (ctx->block_offsets) (void)hipFree(ctx->block_offsets);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
@@ -234,6 +251,7 @@ int tl3d_destroy(tl3d_ctx *ctx) {
 int tl3d_sync(tl3d_ctx *ctx) {
     REQUIRE(ctx != nullptr, TL3D_E_INVALID, "null ctx");
     TL3D_HIP(hipSetDevice(ctx->device));
+    if (ctx->prep_stream) TL3D_HIP(hipStreamSynchronize(ctx->prep_stream));
     TL3D_HIP(hipStreamSynchronize(ctx->stream));
     return TL3D_OK;
 }
@@ -265,6 +283,8 @@ int tl3d_upload_frame(tl3d_ctx *ctx, int slot, const void *depth_hd, int depth_k
     }
     s.loaded = true;
     s.has_normals = false;
+    if (!s.ev_upload) TL3D_HIP(hipEventCreateWithFlags(&s.ev_upload, hipEventDisableTiming));
+    TL3D_HIP(hipEventRecord(s.ev_upload, ctx->stream));       // the prep stream waits on this, not on the whole main stream
     // pageable host sources are consumed before hipMemcpyAsync returns only for small copies; make the hand-over explicit
     if (!is_device_ptr(depth_hd) || (bgr_hd && !is_device_ptr(bgr_hd))) TL3D_HIP(hipStreamSynchronize(ctx->stream));
     return TL3D_OK;
@@ -462,12 +482,21 @@ int tl3d_integrate(tl3d_ctx *ctx, int slot, const double R[9], const double t[3]
     const PoseF p = make_pose_f(R, t);
     const Frustum fr = make_frustum(ctx->cam);
     const float mind = (float)ctx->cfg.min_depth, maxd = (float)ctx->cfg.max_depth;
-    rc = launch_tsdf_prepare(ctx->stream, ctx->cam, ctx->grid, p, fr, ctx->slots[slot].depth, (float)scale, mind, maxd, ctx->tsdf_scratch);
+    const int b = (int)(ctx->tsdf_seq++ & 1u);
+    Slot &sl = ctx->slots[slot];
+    // prep (tiles, pyramid, classification) on the side stream: needs the slot's upload and a free scratch buffer
+    if (sl.ev_upload) TL3D_HIP(hipStreamWaitEvent(ctx->prep_stream, sl.ev_upload, 0));
+    if (ctx->upd_recorded[b]) TL3D_HIP(hipStreamWaitEvent(ctx->prep_stream, ctx->ev_upd[b], 0));
+    rc = launch_tsdf_prepare(ctx->prep_stream, ctx->cam, ctx->grid, p, fr, sl.depth, (float)scale, mind, maxd, ctx->tsdf_scratch[b]);
     if (rc) return rc;
+    TL3D_HIP(hipEventRecord(ctx->ev_prep[b], ctx->prep_stream));
+    TL3D_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_prep[b], 0));
     const int kt = ktimer_begin(ctx);                 // event pair around the dominant kernel only
-    rc = launch_tsdf_update(ctx->stream, ctx->cam, ctx->grid, p, ctx->slots[slot].depth, (float)scale, mind, maxd, ctx->tsdf,
-                            ctx->tsdf_scratch, ctx->d_counters, ctx->count_records);
+    rc = launch_tsdf_update(ctx->stream, ctx->cam, ctx->grid, p, sl.depth, (float)scale, mind, maxd, ctx->tsdf,
+                            ctx->tsdf_scratch[b], ctx->d_counters, ctx->count_records);
     if (kt >= 0) (void)hipEventRecord(ctx->ktimers[kt].b, ctx->stream);
+    TL3D_HIP(hipEventRecord(ctx->ev_upd[b], ctx->stream));
+    ctx->upd_recorded[b] = true;
     if (rc) return rc;
     ctx->stats.tsdf_launches++;
     return TL3D_OK;

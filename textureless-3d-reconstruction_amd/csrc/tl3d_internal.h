@@ -58,6 +58,7 @@ struct Slot {
     float *depth = nullptr;      // [H][W] f32
     uint8_t *bgr = nullptr;      // [H][W][3]
     float4 *nmap = nullptr;      // [H][W] (nx,ny,nz,d), lazily allocated
+    hipEvent_t ev_upload = nullptr;   // recorded on the main stream after the slot's last upload
     bool has_color = false;
     bool loaded = false;
     bool has_normals = false;
@@ -82,7 +83,14 @@ struct tl3d_ctx {
     bool own_tsdf, own_centroid;
     // scratch
     uint16_t *stage_u16;         // u16 depth staging
-    void *tsdf_scratch;          // depth tiles + compact brick list of the current frame
+    // TSDF integration is double-buffered over two streams: the tile/pyramid/cull kernels of frame i+1 run on
+    // prep_stream while the update kernel of frame i streams the grid on the main stream.
+    hipStream_t prep_stream;
+    void *tsdf_scratch[2];       // depth tiles + compact brick list, one per in-flight frame
+    hipEvent_t ev_prep[2];       // prep of the frame using scratch b is done (recorded on prep_stream)
+    hipEvent_t ev_upd[2];        // update of the frame using scratch b is done (recorded on the main stream)
+    bool upd_recorded[2];
+    unsigned tsdf_seq;
     unsigned *block_counts;      // compaction counts
     unsigned long long *block_offsets;
     size_t scratch_blocks;

@@ -1,0 +1,195 @@
+"""File formats either side of the hot path, cv2-free.
+
+Loader rules follow depth_to_reconstruction.py:80-119 and :439-477; the depth producer whose
+files these are is depth_processor.py:905-921 (`<id>_depth.npy`, `<id>_depth.png` u16 mm).
+PLY writers follow depth_to_reconstruction.py:673-703 / depth_enhanced_reconstruction.py:1283-1311.
+OpenCV is not installed in the build image: images are decoded with PIL, and the bilinear resize
+restates cv2.INTER_LINEAR (half-pixel centres, replicated border) in numpy -- that restatement is
+parity-unpinned (no cv2 to check it against, no reference fixture).
+"""
+from __future__ import annotations
+
+from pathlib import Path
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+IMAGE_SUFFIXES = (".png", ".jpg", ".jpeg")
+
+
+# ---------------------------------------------------------------------------------------------
+# depth files
+# ---------------------------------------------------------------------------------------------
+class DepthImageLoader:
+    """Same static interface as the reference class (D2R:76-119)."""
+
+    @staticmethod
+    def load_depth(filepath, raw_u16: bool = False) -> Optional[np.ndarray]:
+        """.npy -> float32 as stored; .png (16-bit) -> millimetres / 1000 -> metres (D2R:82-90).
+
+        raw_u16=True returns the uint16 millimetre image untouched so the device does the /1000
+        (tl3d_upload_frame, TL3D_DEPTH_U16_MM) -- bit-identical to the host conversion.
+        """
+        filepath = Path(filepath)
+        if filepath.suffix == ".npy":
+            return np.load(str(filepath)).astype(np.float32)
+        if filepath.suffix == ".png":
+            from PIL import Image
+            try:
+                with Image.open(str(filepath)) as im:
+                    arr = np.array(im)
+            except Exception:
+                return None
+            if arr.ndim == 3:                       # cv2.IMREAD_ANYDEPTH yields one channel
+                arr = arr[..., 0]
+            if raw_u16 and arr.dtype == np.uint16:
+                return arr
+            return arr.astype(np.float32) / 1000.0
+        if filepath.suffix in (".exr", ".EXR"):
+            # the reference reads EXR through OpenCV (D2R:92-95); no EXR decoder exists in this image
+            print(f"  Warning: EXR depth is not supported without OpenCV: {filepath.name}")
+            return None
+        return None
+
+    @staticmethod
+    def find_matching_depth(rgb_name: str, depth_folder) -> Optional[Path]:
+        """First existing of <stem>_depth.npy, <stem>_depth.png, <stem>.npy, <stem>.png, depth_<stem>.npy,
+        depth_<stem>.png (D2R:105-112)."""
+        depth_folder = Path(depth_folder)
+        stem = Path(rgb_name).stem
+        for name in (f"{stem}_depth.npy", f"{stem}_depth.png", f"{stem}.npy", f"{stem}.png",
+                     f"depth_{stem}.npy", f"depth_{stem}.png"):
+            cand = depth_folder / name
+            if cand.exists():
+                return cand
+        return None
+
+
+def read_image_bgr(path) -> Optional[np.ndarray]:
+    """uint8 [H,W,3] in BGR order, what cv2.imread returns (alpha dropped, grey replicated)."""
+    from PIL import Image
+    try:
+        with Image.open(str(path)) as im:
+            rgb = np.array(im.convert("RGB"), dtype=np.uint8)
+    except Exception:
+        return None
+    return np.ascontiguousarray(rgb[..., ::-1])
+
+
+def resize_bilinear(img: np.ndarray, width: int, height: int) -> np.ndarray:
+    """cv2.resize(img, (width, height), interpolation=cv2.INTER_LINEAR) for a float32 single-channel image
+    (D2R:465-467): source coordinate (x + 0.5) * scale - 0.5, weights in float32, border replicated."""
+    src = np.asarray(img, dtype=np.float32)
+    sh, sw = src.shape
+
+    def taps(dn, sn):
+        scale = np.float64(sn) / np.float64(dn)
+        f = ((np.arange(dn, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+        i0 = np.floor(f).astype(np.int64)
+        w = (f - i0.astype(np.float32)).astype(np.float32)
+        lo = i0 < 0
+        i0[lo], w[lo] = 0, 0.0
+        hi = i0 >= sn - 1
+        i0[hi], w[hi] = sn - 1, 0.0
+        return i0, np.minimum(i0 + 1, sn - 1), w
+
+    x0, x1, wx = taps(width, sw)
+    y0, y1, wy = taps(height, sh)
+    rows = src[:, x0] * (np.float32(1.0) - wx)[None, :] + src[:, x1] * wx[None, :]
+    out = rows[y0, :] * (np.float32(1.0) - wy)[:, None] + rows[y1, :] * wy[:, None]
+    return out.astype(np.float32)
+
+
+def load_data(rgb_folder, depth_folder, verbose: bool = True):
+    """RGB images sorted by name (.png/.jpg/.jpeg) each with its depth map, resized to the RGB size if needed
+    (D2R:439-477).  Returns (images_bgr, depths_f32, names)."""
+    rgb_path, depth_path = Path(rgb_folder), Path(depth_folder)
+    files = sorted(f for f in rgb_path.iterdir() if f.suffix.lower() in IMAGE_SUFFIXES)
+    if verbose:
+        print(f"Found {len(files)} RGB images")
+    images, depths, names = [], [], []
+    for f in files:
+        img = read_image_bgr(f)
+        if img is None:
+            continue
+        dfile = DepthImageLoader.find_matching_depth(f.name, depth_path)
+        if dfile is None:
+            if verbose:
+                print(f"  Warning: No depth found for {f.name}")
+            continue
+        depth = DepthImageLoader.load_depth(dfile)
+        if depth is None:
+            continue
+        if depth.shape[:2] != img.shape[:2]:
+            depth = resize_bilinear(depth, img.shape[1], img.shape[0])
+        images.append(img)
+        depths.append(depth)
+        names.append(f.name)
+        if verbose:
+            print(f"  Loaded: {f.name} with depth")
+    if verbose:
+        print(f"Loaded {len(images)} image-depth pairs")
+    return images, depths, names
+
+
+def save_depth_like_processor(depth_m: np.ndarray, out_dir, frame_id: str):
+    """Write `<id>_depth.npy` and `<id>_depth.png` = (depth*1000).astype(uint16), the pair depth_processor.py:905-921
+    produces (used by the synthetic-dataset writer and the plumbing test)."""
+    from PIL import Image
+    out_dir = Path(out_dir)
+    out_dir.mkdir(parents=True, exist_ok=True)
+    np.save(str(out_dir / f"{frame_id}_depth.npy"), depth_m.astype(np.float32))
+    mm = np.clip(depth_m * 1000.0, 0, 65535).astype(np.uint16)
+    Image.fromarray(mm).save(str(out_dir / f"{frame_id}_depth.png"))
+
+
+# ---------------------------------------------------------------------------------------------
+# PLY
+# ---------------------------------------------------------------------------------------------
+_HEADER_TAIL = ["property uchar red", "property uchar green", "property uchar blue", "end_header"]
+
+
+def write_ply_ascii(path, points, colors):
+    """The reference's fallback writer byte for byte (D2R:689-701): `float` xyz printed with Python's str() of the
+    numpy scalar, colours as integers."""
+    with open(path, "w") as f:
+        f.write("ply\nformat ascii 1.0\n")
+        f.write(f"element vertex {len(points)}\n")
+        f.write("property float x\nproperty float y\nproperty float z\n")
+        f.write("\n".join(_HEADER_TAIL) + "\n")
+        for p, c in zip(points, colors):
+            f.write(f"{p[0]} {p[1]} {p[2]} {int(c[0])} {int(c[1])} {int(c[2])}\n")
+
+
+def write_ply_binary(path, points, colors, double_xyz: bool = True):
+    """binary_little_endian PLY, vertices only.  double_xyz=True is the layout Open3D's write_point_cloud emits for
+    the reference (D2R:684-687: points are Vector3dVector, i.e. fp64) -- from Open3D's source as remembered, not
+    verifiable in this image."""
+    pts = np.asarray(points)
+    col = np.asarray(colors, dtype=np.uint8)
+    ft, fname = ("<f8", "double") if double_xyz else ("<f4", "float")
+    rec = np.empty(len(pts), dtype=[("x", ft), ("y", ft), ("z", ft), ("r", "u1"), ("g", "u1"), ("b", "u1")])
+    if len(pts):
+        rec["x"], rec["y"], rec["z"] = pts[:, 0], pts[:, 1], pts[:, 2]
+        rec["r"], rec["g"], rec["b"] = col[:, 0], col[:, 1], col[:, 2]
+    header = "\n".join(["ply", "format binary_little_endian 1.0", f"element vertex {len(pts)}",
+                        f"property {fname} x", f"property {fname} y", f"property {fname} z"] + _HEADER_TAIL) + "\n"
+    with open(path, "wb") as f:
+        f.write(header.encode("ascii"))
+        f.write(rec.tobytes())
+
+
+def save_reconstruction(points, colors, output_path, ascii: bool = False) -> bool:
+    """DepthToReconstructionPipeline.save_reconstruction (D2R:673-703): empty input prints `No points to save` and
+    writes nothing; parent directories are created; prints `Saved to <path>`."""
+    if len(points) == 0:
+        print("No points to save")
+        return False
+    filepath = Path(output_path)
+    filepath.parent.mkdir(parents=True, exist_ok=True)
+    if ascii:
+        write_ply_ascii(filepath, points, colors)
+    else:
+        write_ply_binary(filepath, points, colors)
+    print(f"Saved to {filepath}")
+    return True
