@@ -98,6 +98,7 @@ typedef struct tl3d_icp_params {
     double max_dist;            /* correspondence gate |p-q| (metres)                              */
     double damping;             /* Levenberg factor: A += damping * trace(A)/6 * I                 */
     double eps;                 /* stop when |update|_inf < eps                                    */
+    double eig_rel;             /* drop directions with eigenvalue < eig_rel * largest (unobservable DOFs) */
 } tl3d_icp_params;
 
 /* per-launch statistics of the fusion kernels, for roofline accounting */

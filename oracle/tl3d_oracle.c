@@ -46,7 +46,7 @@ typedef struct orc_cfg {
 
 typedef struct orc_icp_params {
     int32_t iters, stride;
-    double max_dist, damping, eps;
+    double max_dist, damping, eps, eig_rel;
 } orc_icp_params;
 
 typedef struct orc_icp_result {
@@ -379,7 +379,8 @@ void orc_normals(const orc_cfg *c, const float *depth, double scale, double dept
  *    p = R p_s + t (f32, R,t = (float)T); project to the target image (nearest pixel); (n, d_t) = nmap_t there;
  *    q = back-projected target vertex; gate |p-q|^2 <= max_dist^2; r = (p-q).n; J = [p x n, n];
  *    A += J J^T, b += J r, e += r^2  (fp64 sums of fp64 products of the f32 values).
- * Solve (A + damping*trace(A)/6*I) x = -b by Cholesky; T <- [exp(w) | tau] * T.  A final pass evaluates fitness/rmse at T.
+ * Solve (A + damping*trace(A)/6*I) x = -b by eigen-decomposition with a relative eigenvalue cutoff (solve6);
+ * T <- [exp(w) | tau] * T.  A final pass evaluates fitness/rmse at T.
  * ------------------------------------------------------------------------------------------------ */
 typedef struct { double a[21], b[6], e; int64_t cnt, nsrc; } icp_sums;
 
@@ -435,41 +436,63 @@ static void icp_pass(const orc_cfg *c, const float *depth_s, float sc, const flo
         }
 }
 
-/* Cholesky solve of the damped 6x6 system; returns 0 on success */
-static int solve6(const double a21[21], const double b[6], double damping, double x[6]) {
-    double A[6][6], L[6][6];
+/* Solve (A + damping*trace(A)/6*I) x = -b through the eigen-decomposition of the symmetric 6x6 matrix (cyclic Jacobi,
+ * fixed 12 sweeps), dropping directions whose eigenvalue is below eig_rel * (largest eigenvalue): degrees of freedom
+ * the geometry does not observe (a plane slides, a cylinder spins, a sphere-on-plane rotates about its axis) are left
+ * at the caller's prior instead of drifting (hard part H3).  Returns 0 on success. */
+static int solve6(const double a21[21], const double b[6], double damping, double eig_rel, double x[6]) {
+    double A[6][6], V[6][6];
     int m = 0;
     double tr = 0.0;
     for (int i = 0; i < 6; ++i)
         for (int j = i; j < 6; ++j) { A[i][j] = A[j][i] = a21[m++]; }
     for (int i = 0; i < 6; ++i) tr += A[i][i];
+    if (!(tr > 0.0)) return 1;
     const double lam = damping * (tr / 6.0);
-    for (int i = 0; i < 6; ++i) A[i][i] += lam;
-    memset(L, 0, sizeof(L));
     for (int i = 0; i < 6; ++i) {
-        for (int j = 0; j <= i; ++j) {
-            double s = A[i][j];
-            for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
-            if (i == j) {
-                if (!(s > 1e-14 * (tr > 0 ? tr : 1.0))) return 1;
-                L[i][i] = sqrt(s);
-            } else {
-                L[i][j] = s / L[j][j];
+        A[i][i] += lam;
+        for (int j = 0; j < 6; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+    }
+    for (int sweep = 0; sweep < 12; ++sweep) {
+        for (int p = 0; p < 5; ++p)
+            for (int q = p + 1; q < 6; ++q) {
+                const double apq = A[p][q];
+                if (fabs(apq) < 1e-300) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < 6; ++k) {
+                    const double akp = A[k][p], akq = A[k][q];
+                    A[k][p] = c * akp - sn * akq;
+                    A[k][q] = sn * akp + c * akq;
+                }
+                for (int k = 0; k < 6; ++k) {
+                    const double apk = A[p][k], aqk = A[q][k];
+                    A[p][k] = c * apk - sn * aqk;
+                    A[q][k] = sn * apk + c * aqk;
+                }
+                for (int k = 0; k < 6; ++k) {
+                    const double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - sn * vkq;
+                    V[k][q] = sn * vkp + c * vkq;
+                }
             }
-        }
     }
-    double y[6];
-    for (int i = 0; i < 6; ++i) {
-        double s = -b[i];
-        for (int k = 0; k < i; ++k) s -= L[i][k] * y[k];
-        y[i] = s / L[i][i];
+    double lmax = 0.0;
+    for (int i = 0; i < 6; ++i) if (A[i][i] > lmax) lmax = A[i][i];
+    if (!(lmax > 0.0)) return 1;
+    for (int i = 0; i < 6; ++i) x[i] = 0.0;
+    int used = 0;
+    for (int e = 0; e < 6; ++e) {
+        const double l = A[e][e];
+        if (!(l > eig_rel * lmax) || !(l > 0.0)) continue;
+        double proj = 0.0;
+        for (int k = 0; k < 6; ++k) proj += V[k][e] * b[k];
+        const double coef = -proj / l;
+        for (int k = 0; k < 6; ++k) x[k] += coef * V[k][e];
+        ++used;
     }
-    for (int i = 5; i >= 0; --i) {
-        double s = y[i];
-        for (int k = i + 1; k < 6; ++k) s -= L[k][i] * x[k];
-        x[i] = s / L[i][i];
-    }
-    return 0;
+    return used == 0;
 }
 
 /* T <- [exp(w) | tau] * T */
@@ -510,7 +533,7 @@ int orc_icp(const orc_cfg *c, const float *depth_s, double scale_s, const float 
     for (int it = 0; it < prm->iters; ++it) {
         icp_pass(c, depth_s, (float)scale_s, nmap_t, T, prm->stride, (float)prm->max_dist, &s);
         double x[6];
-        if (s.cnt < 6 || solve6(s.a, s.b, prm->damping, x)) { status = 2; break; }
+        if (s.cnt < 6 || solve6(s.a, s.b, prm->damping, prm->eig_rel, x)) { status = 2; break; }
         se3_apply(x, T);
         ++iters_run;
         double mx = 0;

@@ -51,7 +51,7 @@ class IcpResult(C.Structure):
 
 class IcpParams(C.Structure):
     _fields_ = [("iters", C.c_int32), ("stride", C.c_int32),
-                ("max_dist", C.c_double), ("damping", C.c_double), ("eps", C.c_double)]
+                ("max_dist", C.c_double), ("damping", C.c_double), ("eps", C.c_double), ("eig_rel", C.c_double)]
 
 
 class Stats(C.Structure):

@@ -6,7 +6,7 @@
 // Device-resident iteration: icp_reduce_kernel accumulates the 6x6 normal equations (21 + 6 + 3 sums, fp64)
 // per lane, reduces them with 64-lane wave shuffles, then across the 4 waves through LDS, and writes one
 // 32-double partial per workgroup; icp_solve_kernel sums the partials in block order (deterministic), solves
-// the damped system by Cholesky and updates T in device memory.  No host round trip inside the loop: the host
+// the damped system by a 6x6 Jacobi eigen-decomposition (unobservable directions dropped) and updates T in device memory.  No host round trip inside the loop: the host
 // enqueues 2 x iters kernels and reads the state once.  Bytes per iteration and sampled pixel: 4 (source
 // depth) + 16 (target normal+depth gather) = 20 B.
 #include "tl3d_internal.h"
@@ -127,41 +127,60 @@ __global__ __launch_bounds__(256) void icp_reduce_kernel(Cam cam, const float *_
     }
 }
 
-__device__ int solve6(const double *a21, const double *b, double damping, double x[6]) {
-    double A[6][6], L[6][6];
+// Same algorithm as oracle/tl3d_oracle.c: solve6 (cyclic Jacobi, 12 sweeps, relative eigenvalue cutoff).
+__device__ int solve6(const double *a21, const double *b, double damping, double eig_rel, double x[6]) {
+    double A[6][6], V[6][6];
     int m = 0;
     double tr = 0.0;
     for (int i = 0; i < 6; ++i)
         for (int j = i; j < 6; ++j) { A[i][j] = a21[m]; A[j][i] = a21[m]; ++m; }
     for (int i = 0; i < 6; ++i) tr += A[i][i];
+    if (!(tr > 0.0)) return 1;
     const double lam = damping * (tr / 6.0);
-    for (int i = 0; i < 6; ++i) A[i][i] += lam;
-    for (int i = 0; i < 6; ++i)
-        for (int j = 0; j < 6; ++j) L[i][j] = 0.0;
     for (int i = 0; i < 6; ++i) {
-        for (int j = 0; j <= i; ++j) {
-            double s = A[i][j];
-            for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
-            if (i == j) {
-                if (!(s > 1e-14 * (tr > 0 ? tr : 1.0))) return 1;
-                L[i][i] = sqrt(s);
-            } else {
-                L[i][j] = s / L[j][j];
+        A[i][i] += lam;
+        for (int j = 0; j < 6; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+    }
+    for (int sweep = 0; sweep < 12; ++sweep) {
+        for (int p = 0; p < 5; ++p)
+            for (int q = p + 1; q < 6; ++q) {
+                const double apq = A[p][q];
+                if (fabs(apq) < 1e-300) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < 6; ++k) {
+                    const double akp = A[k][p], akq = A[k][q];
+                    A[k][p] = c * akp - sn * akq;
+                    A[k][q] = sn * akp + c * akq;
+                }
+                for (int k = 0; k < 6; ++k) {
+                    const double apk = A[p][k], aqk = A[q][k];
+                    A[p][k] = c * apk - sn * aqk;
+                    A[q][k] = sn * apk + c * aqk;
+                }
+                for (int k = 0; k < 6; ++k) {
+                    const double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - sn * vkq;
+                    V[k][q] = sn * vkp + c * vkq;
+                }
             }
-        }
     }
-    double y[6];
-    for (int i = 0; i < 6; ++i) {
-        double s = -b[i];
-        for (int k = 0; k < i; ++k) s -= L[i][k] * y[k];
-        y[i] = s / L[i][i];
+    double lmax = 0.0;
+    for (int i = 0; i < 6; ++i) if (A[i][i] > lmax) lmax = A[i][i];
+    if (!(lmax > 0.0)) return 1;
+    for (int i = 0; i < 6; ++i) x[i] = 0.0;
+    int used = 0;
+    for (int e = 0; e < 6; ++e) {
+        const double l = A[e][e];
+        if (!(l > eig_rel * lmax) || !(l > 0.0)) continue;
+        double proj = 0.0;
+        for (int k = 0; k < 6; ++k) proj += V[k][e] * b[k];
+        const double coef = -proj / l;
+        for (int k = 0; k < 6; ++k) x[k] += coef * V[k][e];
+        ++used;
     }
-    for (int i = 5; i >= 0; --i) {
-        double s = y[i];
-        for (int k = i + 1; k < 6; ++k) s -= L[k][i] * x[k];
-        x[i] = s / L[i][i];
-    }
-    return 0;
+    return used == 0;
 }
 
 __device__ void se3_apply(const double x[6], double *T) {
@@ -192,7 +211,7 @@ __device__ void se3_apply(const double x[6], double *T) {
 }
 
 __global__ __launch_bounds__(64) void icp_solve_kernel(const double *__restrict__ slab, int nblocks, IcpState *state,
-                                                       double damping, double eps, int final_pass) {
+                                                       double damping, double eps, double eig_rel, int final_pass) {
     if (!final_pass && state->done) return;
     __shared__ double sums[ICP_SLAB];
     const int t = threadIdx.x;
@@ -205,7 +224,7 @@ __global__ __launch_bounds__(64) void icp_solve_kernel(const double *__restrict_
     __syncthreads();
     if (t != 0 || final_pass) return;
     double x[6];
-    if (sums[28] < 6.0 || solve6(sums, sums + 21, damping, x)) {
+    if (sums[28] < 6.0 || solve6(sums, sums + 21, damping, eig_rel, x)) {
         state->done = 1;
         state->status = 2;
         return;
@@ -229,13 +248,13 @@ int launch_normals(hipStream_t s, const Cam &cam, const float *depth, float scal
 }
 
 int launch_icp_iteration(hipStream_t s, const Cam &cam, const float *depth_src, float scale, float mind, float maxd,
-                         const float4 *nmap_tgt, int stride, float max_dist, double damping, double eps, int final_pass,
+                         const float4 *nmap_tgt, int stride, float max_dist, double damping, double eps, double eig_rel, int final_pass,
                          double *slab, IcpState *state, int nblocks) {
     const int Ws = (cam.W + stride - 1) / stride, Hs = (cam.H + stride - 1) / stride;
     hipLaunchKernelGGL(icp_reduce_kernel, dim3(nblocks), dim3(256), 0, s, cam, depth_src, scale, mind, maxd, nmap_tgt, stride,
                        Ws, Hs, max_dist * max_dist, state, final_pass, slab);
     TL3D_HIP(hipGetLastError());
-    hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(64), 0, s, slab, nblocks, state, damping, eps, final_pass);
+    hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(64), 0, s, slab, nblocks, state, damping, eps, eig_rel, final_pass);
     TL3D_HIP(hipGetLastError());
     return TL3D_OK;
 }

@@ -557,7 +557,7 @@ int tl3d_icp_p2plane(tl3d_ctx *ctx, int slot_src, double scale_src, int slot_tgt
     for (int it = 0; it <= prm->iters; ++it) {
         const int final_pass = (it == prm->iters);
         rc = launch_icp_iteration(ctx->stream, ctx->cam, ctx->slots[slot_src].depth, (float)scale_src, mind, maxd,
-                                  ctx->slots[slot_tgt].nmap, prm->stride, (float)prm->max_dist, prm->damping, prm->eps,
+                                  ctx->slots[slot_tgt].nmap, prm->stride, (float)prm->max_dist, prm->damping, prm->eps, prm->eig_rel,
                                   final_pass, ctx->icp_slab, ctx->icp_state, (int)nb);
         if (rc) return rc;
     }

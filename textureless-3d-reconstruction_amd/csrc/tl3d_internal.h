@@ -150,7 +150,7 @@ int launch_tsdf_update(hipStream_t s, const Cam &cam, const Grid &g, const PoseF
 // normals + icp
 int launch_normals(hipStream_t s, const Cam &cam, const float *depth, float scale, float mind, float maxd, float jump, float4 *nmap);
 int launch_icp_iteration(hipStream_t s, const Cam &cam, const float *depth_src, float scale, float mind, float maxd,
-                         const float4 *nmap_tgt, int stride, float max_dist, double damping, double eps, int final_pass,
+                         const float4 *nmap_tgt, int stride, float max_dist, double damping, double eps, double eig_rel, int final_pass,
                          double *slab, IcpState *state, int nblocks);
 // extraction
 int launch_extract_count(hipStream_t s, const Grid &g, int mode, int min_count, int min_weight, double max_abs,

@@ -173,11 +173,11 @@ class FusionContext:
         return out
 
     def icp(self, slot_src: int, slot_tgt: int, T_init=None, iters=10, stride=4, max_dist=0.05, damping=1e-6,
-            eps=1e-9, scale_src=1.0):
+            eps=1e-9, scale_src=1.0, eig_rel=1e-4):
         """Point-to-plane ICP; returns T (src camera -> tgt camera) and statistics.  With src = previous frame and
         tgt = current frame, (T[:3,:3], T[:3,3]) is (R_rel, t_rel) of depth_to_reconstruction.py:618-620."""
         T0 = np.ascontiguousarray(np.eye(4) if T_init is None else np.asarray(T_init, np.float64).reshape(4, 4))
-        prm = abi.IcpParams(int(iters), int(stride), float(max_dist), float(damping), float(eps))
+        prm = abi.IcpParams(int(iters), int(stride), float(max_dist), float(damping), float(eps), float(eig_rel))
         res = abi.IcpResult()
         abi.check(self._lib.tl3d_icp_p2plane(self._h, int(slot_src), float(scale_src), int(slot_tgt), abi.ptr(T0),
                                              C.byref(prm), C.byref(res)))

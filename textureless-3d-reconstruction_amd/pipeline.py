@@ -1,0 +1,184 @@
+"""DepthToReconstructionPipeline: the reference's orchestration (depth_to_reconstruction.py:423-703) with the
+SfM pose front end replaced by on-device point-to-plane ICP and the vstack + Open3D merge replaced by on-device
+voxel fusion.
+
+Kept from the reference: load_data()'s file rules and messages, cam0 = (I, 0), the pose chain
+R_c = R_rel R_prev, t_c = R_rel t_prev + t_rel (D2R:618-620), frames whose registration fails are skipped and
+do not extend the pose list (D2R:598-615), subsample_factor / voxel_size semantics, the progress lines
+(`Camera i: n points`, `Final reconstruction: ...`), save_reconstruction().
+Not kept (out of scope): SIFT / essential-matrix poses; the sparse
+triangulation that feeds estimate_scale -- depth is taken as metric (scale = config.depth_scale), which is
+what D2R itself falls back to (D2R:555-558).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from . import _cabi as abi
+from . import fileio
+from .config import ReconstructionConfig
+from .dense import DenseReconstructor
+from .fusion import FusionContext, GridSpec
+
+
+def compose(r_rel, t_rel, r_prev, t_prev):
+    """D2R:619-620."""
+    r_rel = np.asarray(r_rel, np.float64)
+    return r_rel @ np.asarray(r_prev, np.float64), r_rel @ np.asarray(t_prev, np.float64).reshape(3, 1) + np.asarray(t_rel, np.float64).reshape(3, 1)
+
+
+def plan_grid(bounds_min, bounds_max, voxel_size, grid_dim, channels=abi.CH_TSDF | abi.CH_CENTROID, trunc_voxels=4.0):
+    """Grid with Open3D's voxel origin (min_bound - voxel/2) covering the bounds, capped at grid_dim^3; when the
+    scene is larger than the cap the grid is centred on it and points outside are dropped (and counted)."""
+    v = float(voxel_size)
+    mn, mx = np.asarray(bounds_min, np.float64), np.asarray(bounds_max, np.float64)
+    origin = mn - 0.5 * v
+    dims = np.floor((mx - origin) / v).astype(np.int64) + 1
+    dims = ((dims + 7) // 8) * 8
+    clipped = False
+    for a in range(3):
+        if dims[a] > grid_dim:
+            centre = 0.5 * (mn[a] + mx[a])
+            origin[a] = centre - 0.5 * grid_dim * v
+            dims[a] = grid_dim
+            clipped = True
+    return GridSpec(tuple(int(d) for d in dims), tuple(float(o) for o in origin), v, trunc_voxels * v, channels), clipped
+
+
+class DepthToReconstructionPipeline:
+    def __init__(self, config: ReconstructionConfig = None):
+        self.config = config or ReconstructionConfig()
+        self.dense = DenseReconstructor(self.config)
+        self.images: List[np.ndarray] = []
+        self.image_names: List[str] = []
+        self.depths: List[np.ndarray] = []
+        self.camera_poses: List[Tuple[np.ndarray, np.ndarray]] = []
+        self.frame_index: List[int] = []          # which loaded frame each pose belongs to
+        self.icp_log: List[dict] = []
+        self.stats: dict = {}
+
+    # ---- a2 --------------------------------------------------------------------------------------
+    def load_data(self, rgb_folder: str, depth_folder: str) -> int:
+        self.images, self.depths, self.image_names = fileio.load_data(rgb_folder, depth_folder)
+        return len(self.images)
+
+    def set_frames(self, images, depths, names=None):
+        """Same state load_data() leaves, from arrays already in memory."""
+        self.images, self.depths = list(images), list(depths)
+        self.image_names = list(names) if names is not None else [f"frame_{i:04d}" for i in range(len(self.images))]
+        return len(self.images)
+
+    # ---- poses: ICP replaces detect_and_match / compute_pose ---------------------------------------
+    def _register(self, ctx: FusionContext, scale: float, init_poses=None):
+        cfg = self.config
+        n = len(self.depths)
+        poses = [(np.eye(3), np.zeros((3, 1)))]
+        index = [0]
+        prev = 0
+        ctx.build_normals(0, scale=scale)
+        T_guess = np.eye(4)
+        for i in range(1, n):
+            print(f"\nProcessing image {i}...")
+            ctx.build_normals(i, scale=scale)
+            if init_poses is not None:
+                r0, t0 = init_poses[prev]
+                r1, t1 = init_poses[i]
+                rr = np.asarray(r1) @ np.asarray(r0).T
+                T_guess = np.eye(4)
+                T_guess[:3, :3], T_guess[:3, 3] = rr, (np.asarray(t1).reshape(3) - rr @ np.asarray(t0).reshape(3))
+            res = ctx.icp(prev, i, T_init=T_guess, iters=cfg.icp_iters, stride=cfg.icp_stride, max_dist=cfg.icp_max_dist,
+                          damping=cfg.icp_damping, scale_src=scale, eig_rel=cfg.icp_eig_rel)
+            self.icp_log.append(dict(frame=i, against=prev, **{k: res[k] for k in ("fitness", "rmse", "n_corr", "iters_run", "status")}))
+            if res["status"] == 2 or res["n_corr"] < 8:
+                # mirrors the reference's skip rule (<8 matches / pose None, D2R:598-615): pose list not extended
+                print(f"  Skipping - registration failed (correspondences: {res['n_corr']})")
+                continue
+            T = res["T"]
+            r_c, t_c = compose(T[:3, :3], T[:3, 3], *poses[-1])
+            poses.append((r_c, t_c))
+            index.append(i)
+            print(f"  ICP: fitness {res['fitness']:.3f}, rmse {res['rmse'] * 1e3:.2f} mm, {res['iters_run']} iterations")
+            T_guess = T                      # constant-velocity prior for the next pair
+            prev = i
+        return poses, index
+
+    # ---- reconstruct ---------------------------------------------------------------------------------
+    def reconstruct(self, grid: Optional[GridSpec] = None, init_poses=None, poses=None):
+        """(points, colors, camera_poses) like D2R:479-671.
+
+        grid: fix the fusion volume (else planned from the data with Open3D's voxel origin).
+        init_poses: optional per-frame pose priors for ICP; poses: skip registration and fuse with these poses.
+        """
+        if len(self.images) < 2:
+            print("Need at least 2 images")
+            return None, None, None
+        cfg = self.config
+        print("\n" + "=" * 70)
+        print("DEPTH-ENHANCED RECONSTRUCTION PIPELINE (MI355X: ICP + voxel fusion)")
+        print("=" * 70)
+        h, w = self.depths[0].shape
+        n = len(self.depths)
+        scale = float(cfg.depth_scale)
+        print(f"Using depth scale = {scale} (depth assumed metric, as D2R:555-558)")
+        boot = FusionContext(w, h, cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.min_depth, cfg.max_depth, n_slots=n, grid=None,
+                             device=cfg.device)
+        try:
+            for i in range(n):
+                if self.depths[i].shape != (h, w):
+                    raise ValueError(f"frame {i} is {self.depths[i].shape}, expected {(h, w)}")
+                boot.upload(i, self.depths[i], self.images[i])
+            if poses is not None:
+                self.camera_poses, self.frame_index = list(poses), list(range(len(poses)))
+            else:
+                print("\n--- Step 1: Register frames (point-to-plane ICP, frame to frame) ---")
+                self.camera_poses, self.frame_index = self._register(boot, scale, init_poses)
+            if len(self.camera_poses) < 2:
+                print("Pose estimation failed")
+                return None, None, None
+            if grid is None:
+                print("\n--- Step 2: Bound the scene ---")
+                mn, mx = np.full(3, np.inf), np.full(3, -np.inf)
+                for pose, fi in zip(self.camera_poses, self.frame_index):
+                    pts, _ = boot.backproject(fi, pose=pose, scale=scale, subsample=cfg.subsample_factor)
+                    if len(pts):
+                        mn, mx = np.minimum(mn, pts.min(0)), np.maximum(mx, pts.max(0))
+                if not np.all(np.isfinite(mn)):
+                    print("Reconstruction failed")
+                    return None, None, None
+                grid, clipped = plan_grid(mn, mx, cfg.voxel_size, cfg.grid_dim, trunc_voxels=cfg.sdf_trunc_voxels)
+                if clipped:
+                    print(f"  Warning: scene extent {np.round(mx - mn, 3)} m exceeds {cfg.grid_dim} voxels of {cfg.voxel_size} m; "
+                          "points outside the grid are dropped")
+            print(f"  Grid {grid.dims} @ {grid.voxel_size * 1e3:g} mm, origin {np.round(grid.origin, 4)}")
+        except Exception:
+            boot.close()
+            raise
+        # fuse: a second context that shares nothing but the frames (re-uploaded slot by slot: HBM is plentiful, the
+        # registration context is released first)
+        boot.close()
+        print("\n--- Step 3: Fuse depth frames (TSDF + voxel centroids) ---")
+        with FusionContext(w, h, cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.min_depth, cfg.max_depth, n_slots=2, grid=grid,
+                           device=cfg.device) as ctx:
+            for k, (pose, fi) in enumerate(zip(self.camera_poses, self.frame_index)):
+                ctx.upload(k & 1, self.depths[fi], self.images[fi])
+                if grid.channels & abi.CH_TSDF:
+                    ctx.integrate(k & 1, pose, scale=scale)
+                ctx.accumulate_centroid(k & 1, pose, scale=scale, subsample=cfg.subsample_factor)
+                print(f"Camera {fi}: fused")
+            st = ctx.stats()
+            print("\n--- Step 4: Extract and clean point cloud ---")
+            xyz, rgb = ctx.extract(abi.EXTRACT_CENTROID, min_count=1, min_weight=cfg.tsdf_min_weight,
+                                   max_abs_tsdf=cfg.tsdf_max_abs)
+            n_vox = len(xyz)
+            if len(xyz) > 0:
+                keep = ctx.statistical_outlier(xyz, 20, 2.0, cell_size=2.0 * grid.voxel_size)     # D2R:413-415
+                xyz, rgb = xyz[keep], rgb[keep]
+            self.stats = dict(points_accumulated=st["centroid_points"], points_dropped=st["centroid_dropped"],
+                              voxels=n_vox, after_outlier_filter=len(xyz))
+        print(f"\nFinal reconstruction: {len(xyz)} points, {len(self.camera_poses)} cameras")
+        return xyz.astype(np.float64), rgb, self.camera_poses
+
+    def save_reconstruction(self, points, colors, output_path: str, ascii: bool = False):
+        fileio.save_reconstruction(points, colors, output_path, ascii=ascii)
