@@ -1,0 +1,146 @@
+"""CPU: host-side logic that needs no device -- file rules, PLY, resize, configuration, grid planning, frame
+sharding, pose chaining, the synthetic generator."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ref_numpy as rn
+from tl3d import fileio, synth
+from tl3d.config import CameraIntrinsics, ReconstructionConfig
+from tl3d.distributed import chain_poses, pairs_for_rank, shard_range
+from tl3d.pipeline import compose, plan_grid
+
+
+def test_config_defaults_are_the_references(golden_dir):
+    g = np.load(os.path.join(golden_dir, "misc.npz"))
+    c = ReconstructionConfig()
+    assert [c.fx, c.fy, c.cx, c.cy, c.min_depth, c.max_depth, c.voxel_size, float(c.subsample_factor)] == g["defaults/d2r"].tolist()
+    assert np.array_equal(c.K, np.array([[1719.0, 0, 540.0], [0, 1719.0, 960.0], [0, 0, 1]]))
+    k = CameraIntrinsics.from_matrix(c.K, 1080, 1920)
+    assert (k.fx, k.cy, k.width) == (1719.0, 960.0, 1080) and np.array_equal(k.to_matrix(), c.K)
+
+
+def test_find_matching_depth_priority(tmp_path):
+    names = ["img_depth.npy", "img_depth.png", "img.npy", "img.png", "depth_img.npy", "depth_img.png"]
+    for n in names:
+        (tmp_path / n).write_bytes(b"x")
+    for n in names:                                   # D2R:105-112: first existing pattern wins
+        assert fileio.DepthImageLoader.find_matching_depth("img.jpg", tmp_path).name == n
+        os.remove(tmp_path / n)
+    assert fileio.DepthImageLoader.find_matching_depth("img.jpg", tmp_path) is None
+
+
+def test_depth_loading_formats(tmp_path):
+    from PIL import Image
+    d = (np.random.default_rng(0).random((6, 9)) * 3).astype(np.float32)
+    np.save(tmp_path / "a_depth.npy", d.astype(np.float64))
+    out = fileio.DepthImageLoader.load_depth(tmp_path / "a_depth.npy")
+    assert out.dtype == np.float32 and np.array_equal(out, d.astype(np.float64).astype(np.float32))
+    mm = np.array([[0, 1, 999, 1000, 65535]], np.uint16)
+    Image.fromarray(mm).save(tmp_path / "b_depth.png")
+    out = fileio.DepthImageLoader.load_depth(tmp_path / "b_depth.png")
+    assert np.array_equal(out, mm.astype(np.float32) / 1000.0)          # millimetres -> metres (D2R:90)
+    assert np.array_equal(fileio.DepthImageLoader.load_depth(tmp_path / "b_depth.png", raw_u16=True), mm)
+    assert fileio.DepthImageLoader.load_depth(tmp_path / "c.txt") is None
+
+
+def test_load_data_pairs_sorts_and_resizes(tmp_path, capsys):
+    from PIL import Image
+    rgb, dep = tmp_path / "rgb", tmp_path / "depth"
+    rgb.mkdir(); dep.mkdir()
+    for i, name in enumerate(["b.png", "a.jpg", "c.jpeg", "skip.txt"]):
+        if name.endswith("txt"):
+            (rgb / name).write_text("x")
+        else:
+            Image.fromarray(np.full((8, 10, 3), 40 * i, np.uint8)).save(rgb / name)
+    np.save(dep / "a_depth.npy", np.ones((8, 10), np.float32))
+    np.save(dep / "b.npy", np.full((4, 5), 2.0, np.float32))             # smaller: resized to the RGB size
+    images, depths, names = fileio.load_data(rgb, dep)
+    assert names == ["a.jpg", "b.png"] and depths[1].shape == (8, 10) and np.allclose(depths[1], 2.0)
+    assert images[0].shape == (8, 10, 3) and images[0].dtype == np.uint8
+    out = capsys.readouterr().out
+    assert "Found 3 RGB images" in out and "Warning: No depth found for c.jpeg" in out and "Loaded 2 image-depth pairs" in out
+
+
+def test_resize_bilinear_properties():
+    src = np.arange(12, dtype=np.float32).reshape(3, 4)
+    assert np.array_equal(fileio.resize_bilinear(src, 4, 3), src)                         # identity
+    up = fileio.resize_bilinear(src, 8, 6)
+    assert up.shape == (6, 8) and up.min() == 0 and up.max() == 11                        # border replicated, no overshoot
+    assert np.allclose(up[0, :2], [0.0, 0.25]) and np.allclose(up[:, 0][:2], [0.0, 1.0])  # half-pixel centres
+    const = fileio.resize_bilinear(np.full((5, 7), 3.5, np.float32), 13, 11)
+    assert np.allclose(const, 3.5, rtol=0, atol=5e-7)                                     # float32 weights, as cv2
+
+
+def test_ply_writers_roundtrip(tmp_path, capsys, golden_dir):
+    g = np.load(os.path.join(golden_dir, "misc.npz"))
+    pts, col = g["ply/points"], g["ply/colors"]
+    fileio.write_ply_ascii(tmp_path / "a.ply", pts, col)
+    assert (tmp_path / "a.ply").read_text() == str(g["ply/d2r_text"])                     # the reference's bytes
+    assert fileio.save_reconstruction(pts.astype(np.float64), col, tmp_path / "x" / "y" / "b.ply")
+    assert "Saved to" in capsys.readouterr().out
+    rp, rc = rn.read_ply(tmp_path / "x" / "y" / "b.ply")
+    assert np.array_equal(rp, pts.astype(np.float64)) and np.array_equal(rc, col)
+    head = (tmp_path / "x" / "y" / "b.ply").read_bytes().split(b"end_header\n")[0].decode()
+    assert "format binary_little_endian 1.0" in head and "property double x" in head and "property uchar red" in head
+    assert not fileio.save_reconstruction(np.array([]), np.array([]), tmp_path / "never.ply")
+    assert "No points to save" in capsys.readouterr().out and not (tmp_path / "never.ply").exists()
+
+
+def test_plan_grid_uses_open3d_origin_and_caps():
+    spec, clipped = plan_grid([-0.5, -0.2, 1.0], [0.5, 0.3, 1.4], 0.005, 512)
+    assert not clipped and np.allclose(spec.origin, [-0.5025, -0.2025, 0.9975])
+    assert all(d % 8 == 0 for d in spec.dims) and spec.dims[0] >= 201 and spec.dims[0] < 216
+    spec, clipped = plan_grid([-5, -0.2, 1.0], [5, 0.3, 1.4], 0.005, 512)
+    assert clipped and spec.dims[0] == 512 and abs(spec.origin[0] + 1.28) < 1e-9
+
+
+def test_sharding_covers_every_frame_once():
+    for n in (1, 2, 7, 50, 512):
+        for world in (1, 2, 3, 4, 8):
+            ranges = [shard_range(n, world, r) for r in range(world)]
+            assert ranges[0][0] == 0 and ranges[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+            assert max(h - l for l, h in ranges) - min(h - l for l, h in ranges) <= 1
+            pairs = sum((pairs_for_rank(n, world, r) for r in range(world)), [])
+            assert pairs == [(i - 1, i) for i in range(1, n)]            # the boundary pair belongs to the later rank
+
+
+def test_pose_chain_is_the_references_composition():
+    rng = np.random.default_rng(3)
+    rel = []
+    for _ in range(5):
+        q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        q *= np.sign(np.linalg.det(q))
+        T = np.eye(4); T[:3, :3] = q; T[:3, 3] = rng.normal(size=3)
+        rel.append(T)
+    poses = chain_poses(rel)
+    r, t = np.eye(3), np.zeros((3, 1))
+    for T, (rc, tc) in zip(rel, poses[1:]):
+        r, t = T[:3, :3] @ r, T[:3, :3] @ t + T[:3, 3:4]              # D2R:619-620 written out
+        assert np.allclose(rc, r) and np.allclose(tc, t)
+    r1, t1 = compose(rel[0][:3, :3], rel[0][:3, 3], np.eye(3), np.zeros(3))
+    assert np.allclose(r1, poses[1][0]) and np.allclose(t1, poses[1][1])
+    ro, to = rn.compose_pose(rel[0][:3, :3], rel[0][:3, 3], np.eye(3), np.zeros(3))
+    assert np.allclose(ro, poses[1][0]) and np.allclose(to, poses[1][1])
+
+
+def test_synth_geometry_and_relative_pose():
+    scene = synth.plane_sphere_scene()
+    cam = dict(width=64, height=48, fx=60.0, fy=60.0, cx=31.5, cy=23.5)
+    poses = synth.dolly_poses(2, (0.0, 0.0, 0.0), (0.05, 0.0, 0.0))
+    d, c = synth.render(scene, poses[0], **cam)
+    assert d.dtype == np.float32 and c.dtype == np.uint8 and c.shape == (48, 64, 3)
+    # centre pixel hits the sphere front: centre (0.05, 0, 1.3), r 0.25
+    assert abs(d[24, 32] - (1.3 - np.sqrt(0.25 ** 2 - 0.05 ** 2))) < 5e-3
+    # back-projected points lie on the analytic surfaces
+    pts, _ = rn.backproject(d, c, cam["fx"], cam["fy"], cam["cx"], cam["cy"], pose=poses[0])
+    (nrm, dpl), = scene.planes
+    (cs, rs), = scene.spheres
+    err = np.minimum(np.abs(pts @ np.asarray(nrm) - dpl), np.abs(np.linalg.norm(pts - np.asarray(cs), axis=1) - rs))
+    assert err.max() < 1e-5
+    r_rel, t_rel = synth.relative_pose(poses[0], poses[1])
+    assert np.allclose(r_rel, np.eye(3)) and np.allclose(t_rel.ravel(), [-0.05, 0, 0])
+    R, t = synth.look_at((0.3, -0.2, -1.0), (0.0, 0.0, 0.0))
+    assert np.allclose(R @ R.T, np.eye(3)) and abs(np.linalg.det(R) - 1) < 1e-12 and np.allclose(R @ np.array([0.3, -0.2, -1.0]) + t.ravel(), 0)
