@@ -171,3 +171,55 @@ def test_tsdf_culling_is_conservative_for_arbitrary_views():
         g = ctx.download_grid(tl3d.CH_TSDF)
     assert orc.tsdf[:, 1].sum() > 100000
     assert np.array_equal(g, orc.tsdf)
+
+
+def test_grid_tensor_is_a_zero_copy_view():
+    """torch.distributed all-reduces the library's grid memory in place (bench.py, tl3d.distributed)."""
+    import torch
+    poses, frames = small_scene_frames(n=1)
+    ctx, orc = make_pair(dims=(64, 64, 64), voxel=0.04)
+    with ctx:
+        ctx.upload(0, *frames[0])
+        ctx.integrate(0, poses[0])
+        ctx.accumulate_centroid(0, poses[0])
+        ctx.sync()
+        t = ctx.grid_tensor(tl3d.CH_TSDF)
+        c = ctx.grid_tensor(tl3d.CH_CENTROID)
+        assert t.dtype == torch.int32 and t.numel() == 2 * 64 ** 3 and c.dtype == torch.int64 and c.numel() == 4 * 64 ** 3
+        g = ctx.download_grid(tl3d.CH_TSDF)
+        assert np.array_equal(t.cpu().numpy().reshape(-1, 2), g)
+        t.mul_(2)                                   # what a 2-rank all-reduce of identical grids would leave
+        c.mul_(2)
+        torch.cuda.synchronize()
+        assert np.array_equal(ctx.download_grid(tl3d.CH_TSDF), 2 * g)
+        xyz, _ = ctx.extract(tl3d.EXTRACT_CENTROID)
+    orc.centroid_accumulate(frames[0][0], frames[0][1], poses[0][0], poses[0][1])
+    oxyz, _ = orc.extract(0)
+    assert np.array_equal(xyz, oxyz)                # doubled sums and doubled counts: same centroids
+
+
+def test_tsdf_lane_mappings_agree_for_rolled_and_top_down_cameras():
+    """The MIXED path picks its lane->voxel mapping from the pose (which grid axis is vertical in the image):
+    exercise all three choices -- upright, rolled 90 degrees (x vertical), looking straight down (z vertical)."""
+    from tl3d import synth
+    cam = dict(width=200, height=152, fx=150.0, fy=160.0, cx=101.3, cy=70.7)
+    ctx, orc = make_pair(cam=cam, dims=(64, 56, 64), voxel=0.04, centre=(0.0, -0.1, 0.0), n_slots=1)
+    scene = synth.object_scene(with_room=True)
+    rz = np.array([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])
+    poses = []
+    for eye in ((0.9, 0.0, -0.4), (-0.3, -0.2, 0.95)):
+        r, t = synth.look_at(eye, (0.0, 0.0, 0.0))
+        poses += [(r, t), (rz @ r, rz @ t), (rz @ rz @ r, rz @ rz @ t)]           # upright, rolled 90, rolled 180
+    poses.append(synth.look_at((0.05, -1.0, 0.02), (0.0, 0.3, 0.0), up=(0.0, 0.0, 1.0)))   # top-down
+    kinds = set()
+    with ctx:
+        for pose in poses:
+            a = np.abs(pose[0][1])
+            kinds.add(int(np.argmax(a)))
+            depth, _ = synth.render(scene, pose, want_color=False, **cam)
+            ctx.upload(0, depth, None)
+            ctx.integrate(0, pose)
+            orc.tsdf_integrate(depth, pose[0], pose[1])
+        g = ctx.download_grid(tl3d.CH_TSDF)
+    assert kinds == {0, 1, 2}, kinds
+    assert orc.tsdf[:, 1].sum() > 100000 and np.array_equal(g, orc.tsdf)

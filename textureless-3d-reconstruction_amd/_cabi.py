@@ -63,6 +63,29 @@ class Stats(C.Structure):
 _lib = None
 
 
+def _preload_shared_hip_runtime():
+    """Keep ONE HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so / libhsa-runtime64.so
+    (same SONAME as /opt/rocm's).  If libtl3d.so pulled in /opt/rocm's copy first, a later `import torch` would load a
+    second runtime into the process, and the second one intermittently finds no GPU.  Loading torch's copy first (when
+    torch is installed) makes both libtl3d.so and torch resolve to the same runtime whatever the import order."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return None
+    libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return None
+    return libdir
+
+
 def load():
     """Load libtl3d.so; raises if it has not been built (python __graft_entry__.py / csrc/build.sh)."""
     global _lib
@@ -71,6 +94,7 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build it with `bash {os.path.join(_HERE, 'csrc', 'build.sh')}` "
                           "(there is no CPU fallback for the HIP path)")
+    _preload_shared_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     lib.tl3d_last_error.restype = C.c_char_p
     vp, i32, i64, dbl, u32 = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_uint32

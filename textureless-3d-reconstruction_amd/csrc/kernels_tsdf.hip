@@ -246,7 +246,13 @@ __device__ __forceinline__ bool tsdf_finish(const Grid &g, const TsdfConst &c, b
 }
 
 // DBG: timing experiments only (TL3D_DEBUG_ONLY=1 -> MIXED bricks only, 2 -> FREE bricks only); results incomplete.
-template <bool COUNT, int DBG>
+// MAP: lane -> voxel mapping of the MIXED path.  A gather costs the texture path roughly one step per distinct image
+// row it touches, so the 8 voxels a lane owns run along the grid axis that is most vertical in the image (chosen
+// per launch from R) and the 64 lanes of one gather instruction share (almost) one image row band:
+//   MAP 1: lanes = (x, y), lane loop over z   records k*64 + lane          (512 B contiguous per instruction)
+//   MAP 2: lanes = (x, z), lane loop over y   records z*64 + k*8 + x       (8 segments of 64 B)
+//   MAP 0: lanes = (x pair, y, z pair), 16-B pairs -- the generic layout, used when x is the vertical axis
+template <bool COUNT, int DBG, int MAP>
 __global__ __launch_bounds__(256) void tsdf_integrate_kernel(Cam cam, Grid g, PoseF pose, TsdfConst c,
                                                              const float *__restrict__ depth,
                                                              const unsigned *__restrict__ list,
@@ -255,7 +261,7 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(Cam cam, Grid g, Po
     const int lane = threadIdx.x & 63;
     const int wid = threadIdx.x >> 6;
     unsigned nmixed = list_counts[0], nfree = list_counts[1];
-    if (DBG == 1) nfree = 0;
+    if (DBG == 1 || DBG == 3 || DBG == 4) nfree = 0;
     const unsigned nlist = nmixed + nfree;
     const unsigned nbricks = (unsigned)(g.nbx * g.nby * g.nbz);
     unsigned nread = 0, nwritten = 0;
@@ -280,46 +286,86 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(Cam cam, Grid g, Po
         const int bx = brick % g.nbx;
         const int by = (brick / g.nbx) % g.nby;
         const int bz = brick / (g.nbx * g.nby);
-        // phase 1: project the lane's 8 voxels, issue the 8 depth gathers back to back
-        float zc[8], dv[8];
-        bool ok[8];
+        if constexpr (MAP == 0) {
+            // phase 1: project the lane's 8 voxels, issue the 8 depth gathers back to back
+            float zc[8], dv[8];
+            bool ok[8];
+    #pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int pr = it * 64 + lane;
+                const int i = bx * 8 + ((pr & 3) << 1);
+                const int j = by * 8 + ((pr >> 2) & 7);
+                const int k = bz * 8 + (pr >> 5);
+                const float py = fmaf((float)j + 0.5f, g.vs, g.oy);
+                const float pz = fmaf((float)k + 0.5f, g.vs, g.oz);
+                const float ax = fmaf(pose.r[1], py, fmaf(pose.r[2], pz, pose.t[0]));
+                const float ay = fmaf(pose.r[4], py, fmaf(pose.r[5], pz, pose.t[1]));
+                const float az = fmaf(pose.r[7], py, fmaf(pose.r[8], pz, pose.t[2]));
+    #pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const float px = fmaf((float)(i + hh) + 0.5f, g.vs, g.ox);
+                    const float xc = fmaf(pose.r[0], px, ax), yc = fmaf(pose.r[3], px, ay);
+                    zc[2 * it + hh] = fmaf(pose.r[6], px, az);
+                    int pix;
+                    ok[2 * it + hh] = tsdf_project(cam, c, xc, yc, zc[2 * it + hh], pix);
+                    dv[2 * it + hh] = depth[pix];
+                }
+            }
+            // phase 2: decide; phase 3: load the 16-B pairs that change; phase 4: add and store them
+            int q[8];
+    #pragma unroll
+            for (int e8 = 0; e8 < 8; ++e8) ok[e8] = tsdf_finish(g, c, ok[e8], dv[e8], zc[e8], q[e8]);
+            int4 rec[4];
+    #pragma unroll
+            for (int it = 0; it < 4; ++it)
+                if (ok[2 * it] | ok[2 * it + 1]) rec[it] = recs[it * 64 + lane];
+    #pragma unroll
+            for (int it = 0; it < 4; ++it)
+                if (ok[2 * it] | ok[2 * it + 1]) {
+                    if (ok[2 * it]) { rec[it].x += q[2 * it]; rec[it].y += 1; }
+                    if (ok[2 * it + 1]) { rec[it].z += q[2 * it + 1]; rec[it].w += 1; }
+                    recs[it * 64 + lane] = rec[it];
+                    if (COUNT) { nread += 2; nwritten += 2; }
+                }
+    
+        } else {
+            // lane-owned column of 8 voxels along the image-vertical grid axis; records are touched 8 B at a time
+            const int la = lane & 7, lb = lane >> 3;
+            const int i = bx * 8 + la;                                     // x is a lane axis in both maps
+            const float px = fmaf((float)i + 0.5f, g.vs, g.ox);
+            float zc[8], dv[8];
+            bool ok[8];
+            int2 *__restrict__ recs2 = reinterpret_cast<int2 *>(recs);
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int pr = it * 64 + lane;
-            const int i = bx * 8 + ((pr & 3) << 1);
-            const int j = by * 8 + ((pr >> 2) & 7);
-            const int k = bz * 8 + (pr >> 5);
-            const float py = fmaf((float)j + 0.5f, g.vs, g.oy);
-            const float pz = fmaf((float)k + 0.5f, g.vs, g.oz);
-            const float ax = fmaf(pose.r[1], py, fmaf(pose.r[2], pz, pose.t[0]));
-            const float ay = fmaf(pose.r[4], py, fmaf(pose.r[5], pz, pose.t[1]));
-            const float az = fmaf(pose.r[7], py, fmaf(pose.r[8], pz, pose.t[2]));
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const float px = fmaf((float)(i + hh) + 0.5f, g.vs, g.ox);
-                const float xc = fmaf(pose.r[0], px, ax), yc = fmaf(pose.r[3], px, ay);
-                zc[2 * it + hh] = fmaf(pose.r[6], px, az);
+            for (int k = 0; k < 8; ++k) {
+                const int j = by * 8 + (MAP == 1 ? lb : k);
+                const int kk = bz * 8 + (MAP == 1 ? k : lb);
+                const float py = fmaf((float)j + 0.5f, g.vs, g.oy);
+                const float pz = fmaf((float)kk + 0.5f, g.vs, g.oz);
+                const float xc = fmaf(pose.r[0], px, fmaf(pose.r[1], py, fmaf(pose.r[2], pz, pose.t[0])));
+                const float yc = fmaf(pose.r[3], px, fmaf(pose.r[4], py, fmaf(pose.r[5], pz, pose.t[1])));
+                zc[k] = fmaf(pose.r[6], px, fmaf(pose.r[7], py, fmaf(pose.r[8], pz, pose.t[2])));
                 int pix;
-                ok[2 * it + hh] = tsdf_project(cam, c, xc, yc, zc[2 * it + hh], pix);
-                dv[2 * it + hh] = depth[pix];
+                ok[k] = tsdf_project(cam, c, xc, yc, zc[k], pix);
+                dv[k] = (DBG == 3) ? 1.0f + 1e-6f * (float)(pix & 1023) : depth[pix];
             }
+            int q[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) ok[k] = tsdf_finish(g, c, ok[k], dv[k], zc[k], q[k]);
+            int2 rec[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (ok[k]) rec[k] = (DBG == 4) ? make_int2(q[k], k) : recs2[MAP == 1 ? (k * 64 + lane) : (lb * 64 + k * 8 + la)];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (ok[k]) {
+                    rec[k].x += q[k];
+                    rec[k].y += 1;
+                    if (DBG == 4) { if (rec[k].x == 0x7fffffff) recs2[0] = rec[k]; }      // keep the values alive, never store
+                    else recs2[MAP == 1 ? (k * 64 + lane) : (lb * 64 + k * 8 + la)] = rec[k];
+                    if (COUNT) { nread += 1; nwritten += 1; }
+                }
         }
-        // phase 2: decide; phase 3: load the 16-B pairs that change; phase 4: add and store them
-        int q[8];
-#pragma unroll
-        for (int e8 = 0; e8 < 8; ++e8) ok[e8] = tsdf_finish(g, c, ok[e8], dv[e8], zc[e8], q[e8]);
-        int4 rec[4];
-#pragma unroll
-        for (int it = 0; it < 4; ++it)
-            if (ok[2 * it] | ok[2 * it + 1]) rec[it] = recs[it * 64 + lane];
-#pragma unroll
-        for (int it = 0; it < 4; ++it)
-            if (ok[2 * it] | ok[2 * it + 1]) {
-                if (ok[2 * it]) { rec[it].x += q[2 * it]; rec[it].y += 1; }
-                if (ok[2 * it + 1]) { rec[it].z += q[2 * it + 1]; rec[it].w += 1; }
-                recs[it * 64 + lane] = rec[it];
-                if (COUNT) { nread += 2; nwritten += 2; }
-            }
     }
     if (COUNT) {
 #pragma unroll
@@ -419,14 +465,28 @@ int launch_tsdf_update(hipStream_t s, const Cam &cam, const Grid &g, const PoseF
     int nblk = (nbricks + 3) / 4;
     if (nblk > max_blk) nblk = max_blk;
     static const int dbg = getenv("TL3D_DEBUG_ONLY") ? atoi(getenv("TL3D_DEBUG_ONLY")) : 0;
-    if (count)
-        hipLaunchKernelGGL((tsdf_integrate_kernel<true, 0>), dim3(nblk), dim3(256), 0, s, cam, g, p, c, depth, t.list, t.list_counts, grid, counters);
-    else if (dbg == 1)
-        hipLaunchKernelGGL((tsdf_integrate_kernel<false, 1>), dim3(nblk), dim3(256), 0, s, cam, g, p, c, depth, t.list, t.list_counts, grid, counters);
-    else if (dbg == 2)
-        hipLaunchKernelGGL((tsdf_integrate_kernel<false, 2>), dim3(nblk), dim3(256), 0, s, cam, g, p, c, depth, t.list, t.list_counts, grid, counters);
-    else
-        hipLaunchKernelGGL((tsdf_integrate_kernel<false, 0>), dim3(nblk), dim3(256), 0, s, cam, g, p, c, depth, t.list, t.list_counts, grid, counters);
+    static const int force_map = getenv("TL3D_TSDF_MAP") ? atoi(getenv("TL3D_TSDF_MAP")) : -1;
+    // the grid axis most vertical in the image (largest |R[1][a]|): y -> MAP 2, z -> MAP 1, x -> generic MAP 0
+    const float ax = fabsf(p.r[3]), ay = fabsf(p.r[4]), az = fabsf(p.r[5]);
+    int map = (ay >= ax && ay >= az) ? 2 : (az >= ax ? 1 : 0);
+    if (force_map >= 0 && force_map <= 2) map = force_map;
+#define TL3D_LAUNCH_UPD(C_, D_, M_)                                                                                              \
+    hipLaunchKernelGGL((tsdf_integrate_kernel<C_, D_, M_>), dim3(nblk), dim3(256), 0, s, cam, g, p, c, depth, t.list, t.list_counts, \
+                       grid, counters)
+#define TL3D_LAUNCH_MAP(C_, D_)                        \
+    do {                                               \
+        if (map == 2) TL3D_LAUNCH_UPD(C_, D_, 2);      \
+        else if (map == 1) TL3D_LAUNCH_UPD(C_, D_, 1); \
+        else TL3D_LAUNCH_UPD(C_, D_, 0);               \
+    } while (0)
+    if (count) TL3D_LAUNCH_MAP(true, 0);
+    else if (dbg == 1) TL3D_LAUNCH_MAP(false, 1);
+    else if (dbg == 2) TL3D_LAUNCH_MAP(false, 2);
+    else if (dbg == 3) TL3D_LAUNCH_MAP(false, 3);
+    else if (dbg == 4) TL3D_LAUNCH_MAP(false, 4);
+    else TL3D_LAUNCH_MAP(false, 0);
+#undef TL3D_LAUNCH_MAP
+#undef TL3D_LAUNCH_UPD
     TL3D_HIP(hipGetLastError());
     return TL3D_OK;
 }

@@ -1,0 +1,71 @@
+"""Summarise rocprofv3 csv output (kernel stats + PMC per tl3d kernel); emit pmc_traffic.json for bench.py."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+out = sys.argv[1]
+
+
+def rows(pattern):
+    for f in glob.glob(os.path.join(out, pattern), recursive=True):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                yield r
+
+
+print("== kernel stats (tl3d kernels + top 3 others), rocprofv3 --kernel-trace --stats ==")
+n = 0
+stats_rows = []
+for r in rows("trace/**/*kernel_stats.csv"):
+    keep = "tl3d" in r.get("Name", "") or n < 3
+    if keep:
+        stats_rows.append(r)
+        print(f"{r.get('Name','')[:72]:72s} calls={r.get('Calls'):>6s} avg_ns={float(r.get('AverageNs',0)):11.1f} "
+              f"min={r.get('MinNs')} max={r.get('MaxNs')} pct={r.get('Percentage')}")
+    n += 1
+for f in glob.glob(os.path.join(out, "bench_trace.log")):
+    for line in open(f):
+        if line.startswith("{"):
+            print("== bench line of the traced run ==")
+            print(line.strip())
+
+agg = defaultdict(lambda: defaultdict(float))
+cnt = defaultdict(lambda: defaultdict(int))
+for r in rows("pmc_*/**/*counter_collection.csv"):
+    k = r.get("Kernel_Name", "")
+    if "tl3d" not in k:
+        continue
+    k = k.split("(")[0].replace("void ", "")
+    c = r.get("Counter_Name")
+    agg[k][c] += float(r.get("Counter_Value", 0))
+    cnt[k][c] += 1
+print("== PMC, mean per dispatch (separate --pmc passes) ==")
+for k in sorted(agg):
+    print(k)
+    for c in sorted(agg[k]):
+        print(f"    {c:36s} {agg[k][c] / max(1, cnt[k][c]):18.1f}  (n={cnt[k][c]})")
+
+key = [k for k in agg if "tsdf_integrate_kernel<false, 0>" in k]
+if key and "FETCH_SIZE" in agg[key[0]] and "WRITE_SIZE" in agg[key[0]]:
+    k = key[0]
+    fetch_kb = agg[k]["FETCH_SIZE"] / cnt[k]["FETCH_SIZE"]
+    write_kb = agg[k]["WRITE_SIZE"] / cnt[k]["WRITE_SIZE"]
+    traffic = (2.0 * fetch_kb + write_kb) * 1024.0
+    alg = None
+    for f in glob.glob(os.path.join(out, "bench_pmc1.log")):
+        for line in open(f):
+            if line.startswith("{"):
+                alg = json.loads(line)["roofline"]["bytes_per_launch"]
+    j = {"grid": 512, "width": 1080, "height": 1920, "kernel": "tsdf_integrate_kernel",
+         "fetch_size_kb": round(fetch_kb, 1), "write_size_kb": round(write_kb, 1),
+         "hbm_bytes_per_launch": int(traffic), "algorithmic_bytes_per_launch": alg,
+         "note": "traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE on gfx950 reports half the bytes of 16-B-per-lane "
+                 "streaming reads (MI355X_MICROARCH.md, HBM); the factor is exact for the FREE-brick stream and an upper "
+                 "bound for the predicated MIXED-brick loads and the 4-B depth gathers"}
+    with open(os.path.join(out, "pmc_traffic.json"), "w") as f:
+        json.dump(j, f, indent=1)
+    print("== traffic ==")
+    print(json.dumps(j))
