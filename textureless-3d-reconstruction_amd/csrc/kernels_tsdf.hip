@@ -5,7 +5,7 @@
 //
 // Launches per frame, all on the ctx stream:
 //   1. depth_tiles_kernel     32x32-pixel tiles -> (min, max, all-valid) of the valid scaled depth   4 B/pixel read
-//   2. tile_pyramid_kernel    1 block: 2x2 reductions of the tiles up to a single tile
+//   2. tile_pyramid_kernel    1 workgroup of 4 waves: 2x2 reductions of the tiles up to a single tile
 //   3. brick_cull_kernel      one lane per 8^3 brick (one wave per 4x4x4-brick cell) classifies it from <= 16
 //                             pyramid lookups:
 //        SKIP   outside the view, no valid depth under it, or more than trunc behind every surface it can see
@@ -45,50 +45,63 @@ struct Pyramid {
 // tile = (dmin, dmax, allvalid ? 1 : 0, unused)
 
 // ---- 1. depth tiles --------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void depth_tiles_kernel(Cam cam, TsdfConst c, const float *__restrict__ depth, int ntx,
+__global__ __launch_bounds__(256) void depth_tiles_kernel(Cam cam, TsdfConst c, const float *__restrict__ depth, int ntx, int nty,
                                                           float4 *__restrict__ tiles, unsigned *__restrict__ list_counts) {
     __shared__ float smin[4], smax[4];
     __shared__ int sbad[4];
-    const int tx = blockIdx.x, ty = blockIdx.y;
-    if (tx == 0 && ty == 0 && threadIdx.x < 2) list_counts[threadIdx.x] = 0u;   // reset the brick-list cursors
-    const int lx = threadIdx.x & 31, ly0 = threadIdx.x >> 5;        // 32 x 8 threads, 4 rows each
-    float mn = INFINITY, mx = -INFINITY;
-    int bad = 0;
-    const int u = tx * TILE + lx;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int v = ty * TILE + ly0 + r * 8;
-        if (u < cam.W && v < cam.H) {
-            const float d = depth[(size_t)v * cam.W + u] * c.sc;
-            if (d > c.mind && d < c.maxd) {
-                mn = fminf(mn, d);
-                mx = fmaxf(mx, d);
+    if (blockIdx.x == 0 && threadIdx.x < 2) list_counts[threadIdx.x] = 0u;      // reset the brick-list cursors
+    // one 32x32-pixel tile per workgroup iteration: 8 lanes x 16 B cover a tile row, 32 rows -> 256 threads
+    const int q4 = threadIdx.x & 7, row = threadIdx.x >> 3;
+    const bool vec = (cam.W & 3) == 0;                              // rows are 16-B aligned
+    for (int tile = blockIdx.x; tile < ntx * nty; tile += gridDim.x) {
+        const int tx = tile % ntx, ty = tile / ntx;
+        float mn = INFINITY, mx = -INFINITY;
+        int bad = 0;
+        const int u0 = tx * TILE + q4 * 4, v = ty * TILE + row;
+        if (v < cam.H && u0 < cam.W) {
+            float dd[4];
+            int nv = min(4, cam.W - u0);
+            if (vec) {
+                const float4 t4 = *reinterpret_cast<const float4 *>(depth + (size_t)v * cam.W + u0);
+                dd[0] = t4.x; dd[1] = t4.y; dd[2] = t4.z; dd[3] = t4.w;
             } else {
-                bad = 1;
+                for (int k = 0; k < 4; ++k) dd[k] = (k < nv) ? depth[(size_t)v * cam.W + u0 + k] : 0.0f;
             }
-        }
-    }
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-        mn = fminf(mn, __shfl_down(mn, d));
-        mx = fmaxf(mx, __shfl_down(mx, d));
-        bad |= __shfl_down(bad, d);
+            for (int k = 0; k < 4; ++k)
+                if (k < nv) {
+                    const float d = dd[k] * c.sc;
+                    if (d > c.mind && d < c.maxd) {
+                        mn = fminf(mn, d);
+                        mx = fmaxf(mx, d);
+                    } else {
+                        bad = 1;
+                    }
+                }
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            mn = fminf(mn, __shfl_down(mn, d));
+            mx = fmaxf(mx, __shfl_down(mx, d));
+            bad |= __shfl_down(bad, d);
+        }
+        if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = mn; smax[threadIdx.x >> 6] = mx; sbad[threadIdx.x >> 6] = bad; }
+        __syncthreads();
+        if (threadIdx.x == 0)
+            tiles[tile] = make_float4(fminf(fminf(smin[0], smin[1]), fminf(smin[2], smin[3])),
+                                      fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3])),
+                                      (sbad[0] | sbad[1] | sbad[2] | sbad[3]) ? 0.0f : 1.0f, 0.0f);
+        __syncthreads();
     }
-    if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = mn; smax[threadIdx.x >> 6] = mx; sbad[threadIdx.x >> 6] = bad; }
-    __syncthreads();
-    if (threadIdx.x == 0)
-        tiles[ty * ntx + tx] = make_float4(fminf(fminf(smin[0], smin[1]), fminf(smin[2], smin[3])),
-                                           fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3])),
-                                           (sbad[0] | sbad[1] | sbad[2] | sbad[3]) ? 0.0f : 1.0f, 0.0f);
 }
 
 // ---- 2. pyramid ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void tile_pyramid_kernel(Pyramid py, float4 *__restrict__ tiles) {
+__global__ __launch_bounds__(256) void tile_pyramid_kernel(Pyramid py, float4 *__restrict__ tiles) {
     for (int L = 1; L < py.nlev; ++L) {
         const int n = py.ntx[L] * py.nty[L];
         const float4 *__restrict__ src = tiles + py.off[L - 1];
         float4 *__restrict__ dst = tiles + py.off[L];
-        for (int i = threadIdx.x; i < n; i += 1024) {
+        for (int i = threadIdx.x; i < n; i += 256) {
             const int x = i % py.ntx[L], y = i / py.ntx[L];
             float4 r = make_float4(INFINITY, -INFINITY, 1.0f, 0.0f);
 #pragma unroll
@@ -440,11 +453,12 @@ int launch_tsdf_prepare(hipStream_t s, const Cam &cam, const Grid &g, const Pose
                         float scale, float mind, float maxd, void *scratch) {
     const TsdfConst c = make_const(cam, scale, mind, maxd);
     const TsdfScratch t = carve(cam, scratch);
-    hipLaunchKernelGGL(depth_tiles_kernel, dim3(t.py.ntx[0], t.py.nty[0]), dim3(256), 0, s, cam, c, depth, t.py.ntx[0], t.tiles,
-                       t.list_counts);
+    const int ntiles = t.py.ntx[0] * t.py.nty[0];
+    hipLaunchKernelGGL(depth_tiles_kernel, dim3(ntiles < 1024 ? ntiles : 1024), dim3(256), 0, s, cam, c, depth, t.py.ntx[0], t.py.nty[0],
+                       t.tiles, t.list_counts);
     TL3D_HIP(hipGetLastError());
     if (t.py.nlev > 1) {
-        hipLaunchKernelGGL(tile_pyramid_kernel, dim3(1), dim3(1024), 0, s, t.py, t.tiles);
+        hipLaunchKernelGGL(tile_pyramid_kernel, dim3(1), dim3(256), 0, s, t.py, t.tiles);
         TL3D_HIP(hipGetLastError());
     }
     const int ncells = ((g.nbx + 3) / 4) * ((g.nby + 3) / 4) * ((g.nbz + 3) / 4);

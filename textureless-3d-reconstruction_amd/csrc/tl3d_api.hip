@@ -1,5 +1,6 @@
 // tl3d_api.hip -- the extern "C" surface declared in include/tl3d.h: context, frame slots, launch glue.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <math.h>
 
 #include <new>
@@ -484,13 +485,19 @@ int tl3d_integrate(tl3d_ctx *ctx, int slot, const double R[9], const double t[3]
     const float mind = (float)ctx->cfg.min_depth, maxd = (float)ctx->cfg.max_depth;
     const int b = (int)(ctx->tsdf_seq++ & 1u);
     Slot &sl = ctx->slots[slot];
-    // prep (tiles, pyramid, classification) on the side stream: needs the slot's upload and a free scratch buffer
-    if (sl.ev_upload) TL3D_HIP(hipStreamWaitEvent(ctx->prep_stream, sl.ev_upload, 0));
-    if (ctx->upd_recorded[b]) TL3D_HIP(hipStreamWaitEvent(ctx->prep_stream, ctx->ev_upd[b], 0));
-    rc = launch_tsdf_prepare(ctx->prep_stream, ctx->cam, ctx->grid, p, fr, sl.depth, (float)scale, mind, maxd, ctx->tsdf_scratch[b]);
-    if (rc) return rc;
-    TL3D_HIP(hipEventRecord(ctx->ev_prep[b], ctx->prep_stream));
-    TL3D_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_prep[b], 0));
+    static const bool single = getenv("TL3D_SINGLE_STREAM") && atoi(getenv("TL3D_SINGLE_STREAM")) != 0;
+    if (single) {
+        rc = launch_tsdf_prepare(ctx->stream, ctx->cam, ctx->grid, p, fr, sl.depth, (float)scale, mind, maxd, ctx->tsdf_scratch[b]);
+        if (rc) return rc;
+    } else {
+        // prep (tiles, classification) on the side stream: needs the slot's upload and a free scratch buffer
+        if (sl.ev_upload) TL3D_HIP(hipStreamWaitEvent(ctx->prep_stream, sl.ev_upload, 0));
+        if (ctx->upd_recorded[b]) TL3D_HIP(hipStreamWaitEvent(ctx->prep_stream, ctx->ev_upd[b], 0));
+        rc = launch_tsdf_prepare(ctx->prep_stream, ctx->cam, ctx->grid, p, fr, sl.depth, (float)scale, mind, maxd, ctx->tsdf_scratch[b]);
+        if (rc) return rc;
+        TL3D_HIP(hipEventRecord(ctx->ev_prep[b], ctx->prep_stream));
+        TL3D_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_prep[b], 0));
+    }
     const int kt = ktimer_begin(ctx);                 // event pair around the dominant kernel only
     rc = launch_tsdf_update(ctx->stream, ctx->cam, ctx->grid, p, sl.depth, (float)scale, mind, maxd, ctx->tsdf,
                             ctx->tsdf_scratch[b], ctx->d_counters, ctx->count_records);
