@@ -454,9 +454,11 @@ static int solve6(const double a21[21], const double b[6], double damping, doubl
         for (int j = 0; j < 6; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
     }
     for (int sweep = 0; sweep < 12; ++sweep) {
+        double offmax = 0.0;                      /* largest pivot met in this sweep: stop once it is negligible */
         for (int p = 0; p < 5; ++p)
             for (int q = p + 1; q < 6; ++q) {
                 const double apq = A[p][q];
+                if (fabs(apq) > offmax) offmax = fabs(apq);
                 if (fabs(apq) < 1e-300) continue;
                 const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
                 const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
@@ -477,6 +479,7 @@ static int solve6(const double a21[21], const double b[6], double damping, doubl
                     V[k][q] = sn * vkp + c * vkq;
                 }
             }
+        if (!(offmax > 1e-15 * tr)) break;
     }
     double lmax = 0.0;
     for (int i = 0; i < 6; ++i) if (A[i][i] > lmax) lmax = A[i][i];

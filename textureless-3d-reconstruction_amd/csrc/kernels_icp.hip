@@ -127,59 +127,94 @@ __global__ __launch_bounds__(256) void icp_reduce_kernel(Cam cam, const float *_
     }
 }
 
-// Same algorithm as oracle/tl3d_oracle.c: solve6 (cyclic Jacobi, 12 sweeps, relative eigenvalue cutoff).
-__device__ int solve6(const double *a21, const double *b, double damping, double eig_rel, double x[6]) {
-    double A[6][6], V[6][6];
-    int m = 0;
+// Same algorithm and the same arithmetic order as oracle/tl3d_oracle.c: solve6 (cyclic Jacobi, 12 sweeps, relative
+// eigenvalue cutoff), spread over the lanes of one wave: lane k (< 6) keeps row k of A and row k of V in registers; a
+// rotation (p,q) reads its three pivots with wave shuffles, every lane rotates its own columns p,q, then lanes p and q
+// swap rows through shuffles.  All 64 lanes execute every shuffle (EXEC full); lanes >= 6 carry zeros.
+// Returns 0 on success; x[k] is valid on every lane (k < 6).
+__device__ __forceinline__ int solve6_wave(const double *__restrict__ a21, const double *__restrict__ b, double damping,
+                                           double eig_rel, double x[6]) {
+    const int lane = threadIdx.x & 63;
+    double a[6], v[6];
     double tr = 0.0;
-    for (int i = 0; i < 6; ++i)
-        for (int j = i; j < 6; ++j) { A[i][j] = a21[m]; A[j][i] = a21[m]; ++m; }
-    for (int i = 0; i < 6; ++i) tr += A[i][i];
-    if (!(tr > 0.0)) return 1;
-    const double lam = damping * (tr / 6.0);
-    for (int i = 0; i < 6; ++i) {
-        A[i][i] += lam;
-        for (int j = 0; j < 6; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
-    }
-    for (int sweep = 0; sweep < 12; ++sweep) {
-        for (int p = 0; p < 5; ++p)
-            for (int q = p + 1; q < 6; ++q) {
-                const double apq = A[p][q];
-                if (fabs(apq) < 1e-300) continue;
-                const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
-                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
-                for (int k = 0; k < 6; ++k) {
-                    const double akp = A[k][p], akq = A[k][q];
-                    A[k][p] = c * akp - sn * akq;
-                    A[k][q] = sn * akp + c * akq;
-                }
-                for (int k = 0; k < 6; ++k) {
-                    const double apk = A[p][k], aqk = A[q][k];
-                    A[p][k] = c * apk - sn * aqk;
-                    A[q][k] = sn * apk + c * aqk;
-                }
-                for (int k = 0; k < 6; ++k) {
-                    const double vkp = V[k][p], vkq = V[k][q];
-                    V[k][p] = c * vkp - sn * vkq;
-                    V[k][q] = sn * vkp + c * vkq;
-                }
+    {
+        int m = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = i; j < 6; ++j) {
+                const double e = a21[m++];
+                if (lane == i) a[j] = e;
+                if (lane == j) a[i] = e;
             }
     }
-    double lmax = 0.0;
-    for (int i = 0; i < 6; ++i) if (A[i][i] > lmax) lmax = A[i][i];
-    if (!(lmax > 0.0)) return 1;
-    for (int i = 0; i < 6; ++i) x[i] = 0.0;
-    int used = 0;
+    tr = ((((a21[0] + a21[6]) + a21[11]) + a21[15]) + a21[18]) + a21[20];      // A00+A11+...+A55 in index order
+    if (!(tr > 0.0)) return 1;
+    const double lam = damping * (tr / 6.0);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        if (lane >= 6) a[j] = 0.0;
+        if (lane == j) a[j] += lam;
+        v[j] = (lane == j) ? 1.0 : 0.0;
+    }
+    for (int sweep = 0; sweep < 12; ++sweep) {
+        double offmax = 0.0;
+#pragma unroll
+        for (int p = 0; p < 5; ++p)
+#pragma unroll
+            for (int q = p + 1; q < 6; ++q) {
+                const double apq = __shfl(a[q], p), app = __shfl(a[p], p), aqq = __shfl(a[q], q);
+                if (fabs(apq) > offmax) offmax = fabs(apq);
+                if (fabs(apq) < 1e-300) continue;                       // wave-uniform
+                const double theta = (aqq - app) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+                {   // columns p,q of every row
+                    const double akp = a[p], akq = a[q];
+                    a[p] = c * akp - sn * akq;
+                    a[q] = sn * akp + c * akq;
+                }
+                double rp[6], rq[6];                                    // rows p and q after the column step
+#pragma unroll
+                for (int k = 0; k < 6; ++k) { rp[k] = __shfl(a[k], p); rq[k] = __shfl(a[k], q); }
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    const double np_ = c * rp[k] - sn * rq[k], nq_ = sn * rp[k] + c * rq[k];
+                    if (lane == p) a[k] = np_;
+                    if (lane == q) a[k] = nq_;
+                }
+                {
+                    const double vkp = v[p], vkq = v[q];
+                    v[p] = c * vkp - sn * vkq;
+                    v[q] = sn * vkp + c * vkq;
+                }
+            }
+        if (!(offmax > 1e-15 * tr)) break;                          // wave-uniform; same rule as the oracle
+    }
+    double lam_e[6], lmax = 0.0;
+#pragma unroll
     for (int e = 0; e < 6; ++e) {
-        const double l = A[e][e];
-        if (!(l > eig_rel * lmax) || !(l > 0.0)) continue;
+        lam_e[e] = __shfl(a[e], e);
+        if (lam_e[e] > lmax) lmax = lam_e[e];
+    }
+    if (!(lmax > 0.0)) return 1;
+    double xk = 0.0;
+    int used = 0;
+    const double bk = (lane < 6) ? b[lane] : 0.0;
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+        const double l = lam_e[e];
+        if (!(l > eig_rel * lmax) || !(l > 0.0)) continue;            // wave-uniform
+        // proj = sum_k V[k][e] * b[k], k = 0..5 in order (as the oracle)
         double proj = 0.0;
-        for (int k = 0; k < 6; ++k) proj += V[k][e] * b[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) proj += __shfl(v[e] * bk, k);
         const double coef = -proj / l;
-        for (int k = 0; k < 6; ++k) x[k] += coef * V[k][e];
+        xk += coef * v[e];
         ++used;
     }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) x[k] = __shfl(xk, k);
     return used == 0;
 }
 
@@ -210,21 +245,40 @@ __device__ void se3_apply(const double x[6], double *T) {
     for (int i = 0; i < 16; ++i) T[i] = Tn[i];
 }
 
-__global__ __launch_bounds__(64) void icp_solve_kernel(const double *__restrict__ slab, int nblocks, IcpState *state,
-                                                       double damping, double eps, double eig_rel, int final_pass) {
+__global__ __launch_bounds__(256) void icp_solve_kernel(const double *__restrict__ slab, int nblocks, IcpState *state,
+                                                        double damping, double eps, double eig_rel, int final_pass) {
     if (!final_pass && state->done) return;
+    __shared__ double part[8][ICP_SLAB];
     __shared__ double sums[ICP_SLAB];
     const int t = threadIdx.x;
-    if (t < ICP_SLAB) {
+    {   // slab reduction: 8 groups x 32 components, loads batched 8 deep, combined in a fixed order (deterministic)
+        const int comp = t & 31, grp = t >> 5;
         double s = 0.0;
-        for (int b = 0; b < nblocks; ++b) s += slab[(size_t)b * ICP_SLAB + t];
+        int b = grp;
+        for (; b + 56 < nblocks; b += 64) {
+            double v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = slab[(size_t)(b + 8 * k) * ICP_SLAB + comp];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += v[k];
+        }
+        for (; b < nblocks; b += 8) s += slab[(size_t)b * ICP_SLAB + comp];
+        part[grp][comp] = s;
+    }
+    __syncthreads();
+    if (t < ICP_SLAB) {
+        double s = part[0][t];
+#pragma unroll
+        for (int g = 1; g < 8; ++g) s += part[g][t];
         sums[t] = s;
         state->sums[t] = s;
     }
     __syncthreads();
-    if (t != 0 || final_pass) return;
+    if (final_pass || t >= 64) return;                     // wave 0 solves
     double x[6];
-    if (sums[28] < 6.0 || solve6(sums, sums + 21, damping, eig_rel, x)) {
+    const int fail = (sums[28] < 6.0) ? 1 : solve6_wave(sums, sums + 21, damping, eig_rel, x);
+    if (t != 0) return;
+    if (fail) {
         state->done = 1;
         state->status = 2;
         return;
@@ -254,7 +308,7 @@ int launch_icp_iteration(hipStream_t s, const Cam &cam, const float *depth_src, 
     hipLaunchKernelGGL(icp_reduce_kernel, dim3(nblocks), dim3(256), 0, s, cam, depth_src, scale, mind, maxd, nmap_tgt, stride,
                        Ws, Hs, max_dist * max_dist, state, final_pass, slab);
     TL3D_HIP(hipGetLastError());
-    hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(64), 0, s, slab, nblocks, state, damping, eps, eig_rel, final_pass);
+    hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(256), 0, s, slab, nblocks, state, damping, eps, eig_rel, final_pass);
     TL3D_HIP(hipGetLastError());
     return TL3D_OK;
 }

@@ -64,7 +64,7 @@ struct Slot {
     bool has_normals = false;
 };
 
-constexpr int ICP_MAX_BLOCKS = 1024;
+constexpr int ICP_MAX_BLOCKS = 256;     // one reduce workgroup per CU; the solve sums the slab serially
 constexpr int ICP_SLAB = 32;     // doubles per block partial
 
 }  // namespace tl3d
