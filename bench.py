@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--centroid", action="store_true", help="also accumulate the voxel-centroid channel each frame")
     ap.add_argument("--icp", action="store_true", help="also run frame-to-frame ICP each frame (poses still analytic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="init torch.distributed (RCCL) even with one rank: exercises the merge path")
     ap.add_argument("--cpu-frames", type=int, default=4, help="distinct frames the CPU baseline cycles over")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-clock budget of the CPU baseline sample")
     return ap.parse_args()
@@ -58,8 +59,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
+        if "MASTER_ADDR" not in os.environ:                      # single-process rehearsal of the merge path
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29533"), RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=dev)
 
     H, W = args.height, args.width

@@ -1,0 +1,46 @@
+"""GPU: bench.py's output contract on a reduced workload (the driver parses this line), and a one-rank rehearsal of the
+RCCL merge path (all-reduce on the library's own grid memory)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--grid", "128", "--voxel", "0.02", "--width", "270", "--height", "480", "--steps", "2", "--warmup", "1",
+         "--frames-per-step", "4", "--resident-frames", "4", "--cpu-seconds", "0.5", "--cpu-frames", "2"]
+
+
+def _run(extra, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL + extra, capture_output=True, text=True,
+                         cwd=ROOT, env=e, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_json_contract():
+    d = _run([])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and d["unit"] == "frames/s"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["achieved"] > 0
+    assert r["bytes_per_launch"] == 8 * r["records_per_launch"] + 4 * 270 * 480
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert d["value"] > 0 and abs(d["ms_per_step"] - 1e3 * 4 / d["value"]) / d["ms_per_step"] < 0.05
+
+
+def test_single_rank_rccl_merge_rehearsal():
+    d = _run(["--force-dist", "--no-cpu-baseline", "--centroid"], env={"MASTER_PORT": "29541"})
+    assert d["value"] > 0 and d["config"]["centroid_channel"] is True
