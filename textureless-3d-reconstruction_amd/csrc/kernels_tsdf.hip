@@ -275,15 +275,22 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(Cam cam, Grid g, Po
     const int wid = threadIdx.x >> 6;
     unsigned nmixed = list_counts[0], nfree = list_counts[1];
     if (DBG == 1 || DBG == 3 || DBG == 4) nfree = 0;
+    if (DBG == 2) nmixed = 0;        // (list offsets below stay valid: FREE entries are addressed from the back)
     const unsigned nlist = nmixed + nfree;
     const unsigned nbricks = (unsigned)(g.nbx * g.nby * g.nbz);
     unsigned nread = 0, nwritten = 0;
     for (unsigned li0 = blockIdx.x * 4; li0 < nlist; li0 += gridDim.x * 4) {
         const unsigned li = li0 + wid;
         if (li >= nlist) break;
-        if (DBG == 2 && li < nmixed) continue;
-        // MIXED entries sit at the front of the list, FREE entries at the back (filled downwards)
-        const unsigned e = __builtin_amdgcn_readfirstlane(list[li < nmixed ? li : nbricks - 1u - (li - nmixed)]);
+        // MIXED entries sit at the front of the list, FREE entries at the back (filled downwards).  They are consumed
+        // interleaved (even slots MIXED, odd slots FREE while both last): MIXED bricks are bound by the texture-address
+        // path, FREE bricks by HBM, so mixing them on every CU overlaps the two instead of running them back to back.
+        const unsigned npair = 2u * min(nmixed, nfree);
+        unsigned src;
+        if (li < npair) src = (li & 1u) ? nbricks - 1u - (li >> 1) : (li >> 1);
+        else if (nmixed > nfree) src = li - nfree;                                   // remaining MIXED entries
+        else src = nbricks - 1u - (li - nmixed);                                     // remaining FREE entries
+        const unsigned e = __builtin_amdgcn_readfirstlane(list[src]);
         const int brick = (int)(e & ~FREE_FLAG);
         int4 *__restrict__ recs = reinterpret_cast<int4 *>(grid + ((size_t)brick << 9));
         if (e & FREE_FLAG) {
