@@ -223,3 +223,23 @@ def test_tsdf_lane_mappings_agree_for_rolled_and_top_down_cameras():
         g = ctx.download_grid(tl3d.CH_TSDF)
     assert kinds == {0, 1, 2}, kinds
     assert orc.tsdf[:, 1].sum() > 100000 and np.array_equal(g, orc.tsdf)
+
+
+def test_icp_lanes_match_blocking_calls():
+    """Asynchronous ICP lanes (independent pairs in flight on separate streams) give the blocking call's result."""
+    poses, frames = small_scene_frames(n=6, deg=1.5)
+    ctx, orc = make_pair(channels=0, dims=(8, 8, 8), n_slots=6)
+    with ctx:
+        for i, f in enumerate(frames):
+            ctx.upload(i, *f)
+            ctx.build_normals(i)
+        ref = [ctx.icp(i, i + 1, iters=8, stride=2, max_dist=0.1) for i in range(5)]
+        for i in range(5):
+            ctx.icp_enqueue(i, i, i + 1, iters=8, stride=2, max_dist=0.1)
+        with pytest.raises(tl3d.Tl3dError):
+            ctx.icp_enqueue(0, 0, 1)                 # lane 0 still holds an uncollected run
+        got = [ctx.icp_collect(i) for i in range(5)]
+        with pytest.raises(tl3d.Tl3dError):
+            ctx.icp_collect(0)                       # nothing left to collect
+    for a, b in zip(ref, got):
+        assert np.array_equal(a["T"], b["T"]) and a["n_corr"] == b["n_corr"] and a["iters_run"] == b["iters_run"]

@@ -16,13 +16,14 @@ CH_TSDF, CH_CENTROID = 1, 2
 DEPTH_F32_M, DEPTH_U16_MM = 0, 1
 F_SCALE_F64, F_NO_POSE = 1, 2
 EXTRACT_CENTROID, EXTRACT_TSDF = 0, 1
+ICP_LANES = 8
 
 # every symbol include/tl3d.h declares (checked by tests/test_cabi_symbols.py against the header text)
 SYMBOLS = [
     "tl3d_last_error", "tl3d_version", "tl3d_device_count", "tl3d_create", "tl3d_destroy", "tl3d_sync",
     "tl3d_upload_frame", "tl3d_download_depth", "tl3d_backproject", "tl3d_accumulate_centroid",
     "tl3d_accumulate_points", "tl3d_points_bounds", "tl3d_integrate", "tl3d_build_normals",
-    "tl3d_download_normals", "tl3d_icp_p2plane", "tl3d_grid_reset", "tl3d_grid_device_ptr",
+    "tl3d_download_normals", "tl3d_icp_p2plane", "tl3d_icp_enqueue", "tl3d_icp_collect", "tl3d_grid_reset", "tl3d_grid_device_ptr",
     "tl3d_grid_download", "tl3d_grid_upload", "tl3d_grid_add", "tl3d_extract", "tl3d_statistical_outlier",
     "tl3d_set_profile", "tl3d_get_stats", "tl3d_reset_stats", "tl3d_event_record", "tl3d_event_elapsed_ms",
 ]
@@ -94,6 +95,10 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build it with `bash {os.path.join(_HERE, 'csrc', 'build.sh')}` "
                           "(there is no CPU fallback for the HIP path)")
+    # ICP lanes, the TSDF prep stream and the main stream want to run side by side; ROCm multiplexes streams onto
+    # GPU_MAX_HW_QUEUES hardware queues (default 4).  Only a default: an explicit setting wins, and it has no effect if
+    # the HIP runtime was already initialised by the host application.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     _preload_shared_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     lib.tl3d_last_error.restype = C.c_char_p
@@ -114,6 +119,8 @@ def load():
         "tl3d_build_normals": [vp, i32, dbl, dbl],
         "tl3d_download_normals": [vp, i32, vp],
         "tl3d_icp_p2plane": [vp, i32, dbl, i32, vp, C.POINTER(IcpParams), C.POINTER(IcpResult)],
+        "tl3d_icp_enqueue": [vp, i32, i32, dbl, i32, vp, C.POINTER(IcpParams)],
+        "tl3d_icp_collect": [vp, i32, C.POINTER(IcpResult)],
         "tl3d_grid_reset": [vp],
         "tl3d_grid_device_ptr": [vp, u32, C.POINTER(vp), C.POINTER(C.c_size_t)],
         "tl3d_grid_download": [vp, u32, vp, C.c_size_t],

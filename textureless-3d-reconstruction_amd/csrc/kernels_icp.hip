@@ -7,7 +7,7 @@
 // per lane, reduces them with 64-lane wave shuffles, then across the 4 waves through LDS, and writes one
 // 32-double partial per workgroup; icp_solve_kernel sums the partials in block order (deterministic), solves
 // the damped system by a 6x6 Jacobi eigen-decomposition (unobservable directions dropped) and updates T in device memory.  No host round trip inside the loop: the host
-// enqueues 2 x iters kernels and reads the state once.  Bytes per iteration and sampled pixel: 4 (source
+// replays one captured hipGraph per run (2 x (iters+1) kernels + the state copies) and reads the state once.  Bytes per iteration and sampled pixel: 4 (source
 // depth) + 16 (target normal+depth gather) = 20 B.
 #include "tl3d_internal.h"
 
@@ -58,11 +58,14 @@ __global__ __launch_bounds__(256) void normals_kernel(Cam cam, const float *__re
     nmap[(size_t)v * cam.W + u] = o;
 }
 
-__global__ __launch_bounds__(256) void icp_reduce_kernel(Cam cam, const float *__restrict__ depth_s, float sc, float mind,
-                                                         float maxd, const float4 *__restrict__ nmap_t, int stride, int Ws,
-                                                         int Hs, float md2, const IcpState *__restrict__ state,
-                                                         int final_pass, double *__restrict__ slab) {
+__global__ __launch_bounds__(256) void icp_reduce_kernel(Cam cam, const IcpRun *__restrict__ run,
+                                                         const IcpState *__restrict__ state, int final_pass,
+                                                         double *__restrict__ slab) {
     if (!final_pass && state->done) return;
+    const float *__restrict__ depth_s = run->depth_src;
+    const float4 *__restrict__ nmap_t = run->nmap_tgt;
+    const float sc = run->scale, mind = run->mind, maxd = run->maxd, md2 = run->md2;
+    const int stride = run->stride, Ws = run->Ws, Hs = run->Hs;
     __shared__ double sm[4][ICP_SLAB];
     float r[9], t[3];
     r[0] = (float)state->T[0]; r[1] = (float)state->T[1]; r[2] = (float)state->T[2];  t[0] = (float)state->T[3];
@@ -246,8 +249,9 @@ __device__ void se3_apply(const double x[6], double *T) {
 }
 
 __global__ __launch_bounds__(256) void icp_solve_kernel(const double *__restrict__ slab, int nblocks, IcpState *state,
-                                                        double damping, double eps, double eig_rel, int final_pass) {
+                                                        const IcpRun *__restrict__ run, int final_pass) {
     if (!final_pass && state->done) return;
+    const double damping = run->damping, eps = run->eps, eig_rel = run->eig_rel;
     __shared__ double part[8][ICP_SLAB];
     __shared__ double sums[ICP_SLAB];
     const int t = threadIdx.x;
@@ -301,14 +305,10 @@ int launch_normals(hipStream_t s, const Cam &cam, const float *depth, float scal
     return TL3D_OK;
 }
 
-int launch_icp_iteration(hipStream_t s, const Cam &cam, const float *depth_src, float scale, float mind, float maxd,
-                         const float4 *nmap_tgt, int stride, float max_dist, double damping, double eps, double eig_rel, int final_pass,
-                         double *slab, IcpState *state, int nblocks) {
-    const int Ws = (cam.W + stride - 1) / stride, Hs = (cam.H + stride - 1) / stride;
-    hipLaunchKernelGGL(icp_reduce_kernel, dim3(nblocks), dim3(256), 0, s, cam, depth_src, scale, mind, maxd, nmap_tgt, stride,
-                       Ws, Hs, max_dist * max_dist, state, final_pass, slab);
+int launch_icp_iteration(hipStream_t s, const Cam &cam, const IcpRun *run, int final_pass, double *slab, IcpState *state, int nblocks) {
+    hipLaunchKernelGGL(icp_reduce_kernel, dim3(nblocks), dim3(256), 0, s, cam, run, state, final_pass, slab);
     TL3D_HIP(hipGetLastError());
-    hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(256), 0, s, slab, nblocks, state, damping, eps, eig_rel, final_pass);
+    hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(256), 0, s, slab, nblocks, state, run, final_pass);
     TL3D_HIP(hipGetLastError());
     return TL3D_OK;
 }

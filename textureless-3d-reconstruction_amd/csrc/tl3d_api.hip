@@ -195,8 +195,6 @@ int tl3d_create(const tl3d_config *cfg, int device, tl3d_ctx **out) {
     }
     if (hipMalloc(&ctx->d_counters, 16 * sizeof(unsigned long long)) != hipSuccess) return fail(set_err(TL3D_E_NOMEM, "alloc failed"));
     if (hipMemsetAsync(ctx->d_counters, 0, 16 * sizeof(unsigned long long), ctx->stream) != hipSuccess) return fail(set_err(TL3D_E_HIP, "memset failed"));
-    if (hipMalloc(&ctx->icp_slab, (size_t)ICP_MAX_BLOCKS * ICP_SLAB * sizeof(double)) != hipSuccess) return fail(set_err(TL3D_E_NOMEM, "alloc failed"));
-    if (hipMalloc(&ctx->icp_state, sizeof(IcpState)) != hipSuccess) return fail(set_err(TL3D_E_NOMEM, "alloc failed"));
     if (hipMalloc(&ctx->bounds_slab, 1024 * 6 * sizeof(float)) != hipSuccess) return fail(set_err(TL3D_E_NOMEM, "alloc failed"));
     for (int i = 0; i < 2; ++i)
         if (hipEventCreate(&ctx->ev[i]) != hipSuccess) return fail(set_err(TL3D_E_HIP, "event create failed"));
@@ -216,6 +214,7 @@ int tl3d_destroy(tl3d_ctx *ctx) {
             if (ctx->slots[i].bgr) (void)hipFree(ctx->slots[i].bgr);
             if (ctx->slots[i].nmap) (void)hipFree(ctx->slots[i].nmap);
             if (ctx->slots[i].ev_upload) (void)hipEventDestroy(ctx->slots[i].ev_upload);
+            if (ctx->slots[i].ev_normals) (void)hipEventDestroy(ctx->slots[i].ev_normals);
         }
         delete[] ctx->slots;
     }
@@ -232,8 +231,17 @@ int tl3d_destroy(tl3d_ctx *ctx) {
     if (ctx->block_counts) (void)hipFree(ctx->block_counts);
     if (ctx->block_offsets) (void)hipFree(ctx->block_offsets);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
-    if (ctx->icp_slab) (void)hipFree(ctx->icp_slab);
-    if (ctx->icp_state) (void)hipFree(ctx->icp_state);
+    for (int l = 0; l < TL3D_ICP_LANES; ++l) {
+        tl3d_ctx::IcpLane &ln = ctx->icp_lanes[l];
+        if (ln.stream) (void)hipStreamSynchronize(ln.stream);
+        if (ln.slab) (void)hipFree(ln.slab);
+        if (ln.state) (void)hipFree(ln.state);
+        if (ln.graph) (void)hipGraphExecDestroy(ln.graph);
+        if (ln.host) (void)hipHostFree(ln.host);
+        if (ln.run) (void)hipFree(ln.run);
+        if (ln.run_host) (void)hipHostFree(ln.run_host);
+        if (ln.stream) (void)hipStreamDestroy(ln.stream);
+    }
     if (ctx->bounds_slab) (void)hipFree(ctx->bounds_slab);
     for (int i = 0; i < 2; ++i)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
@@ -253,6 +261,8 @@ int tl3d_sync(tl3d_ctx *ctx) {
     REQUIRE(ctx != nullptr, TL3D_E_INVALID, "null ctx");
     TL3D_HIP(hipSetDevice(ctx->device));
     if (ctx->prep_stream) TL3D_HIP(hipStreamSynchronize(ctx->prep_stream));
+    for (int l = 0; l < TL3D_ICP_LANES; ++l)
+        if (ctx->icp_lanes[l].stream) TL3D_HIP(hipStreamSynchronize(ctx->icp_lanes[l].stream));
     TL3D_HIP(hipStreamSynchronize(ctx->stream));
     return TL3D_OK;
 }
@@ -521,6 +531,8 @@ int tl3d_build_normals(tl3d_ctx *ctx, int slot, double scale, double depth_jump)
                         (float)depth_jump, s.nmap);
     if (rc) return rc;
     s.has_normals = true;
+    if (!s.ev_normals) TL3D_HIP(hipEventCreateWithFlags(&s.ev_normals, hipEventDisableTiming));
+    TL3D_HIP(hipEventRecord(s.ev_normals, ctx->stream));      // ICP lanes wait on this, not on the whole main stream
     return TL3D_OK;
 }
 
@@ -535,41 +547,100 @@ int tl3d_download_normals(tl3d_ctx *ctx, int slot, float *out) {
     return TL3D_OK;
 }
 
-int tl3d_icp_p2plane(tl3d_ctx *ctx, int slot_src, double scale_src, int slot_tgt, const double T_init[16],
-                     const tl3d_icp_params *prm, tl3d_icp_result *out) {
+static int icp_lane_init(tl3d_ctx *ctx, int lane) {
+    tl3d_ctx::IcpLane &ln = ctx->icp_lanes[lane];
+    if (ln.stream) return TL3D_OK;
+    TL3D_HIP(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+    if (hipMalloc(&ln.slab, (size_t)ICP_MAX_BLOCKS * ICP_SLAB * sizeof(double)) != hipSuccess) return set_err(TL3D_E_NOMEM, "alloc failed");
+    if (hipMalloc(&ln.state, sizeof(IcpState)) != hipSuccess) return set_err(TL3D_E_NOMEM, "alloc failed");
+    if (hipHostMalloc(&ln.host, sizeof(IcpState), hipHostMallocDefault) != hipSuccess) return set_err(TL3D_E_NOMEM, "pinned alloc failed");
+    if (hipMalloc(&ln.run, sizeof(IcpRun)) != hipSuccess) return set_err(TL3D_E_NOMEM, "alloc failed");
+    if (hipHostMalloc(&ln.run_host, sizeof(IcpRun), hipHostMallocDefault) != hipSuccess) return set_err(TL3D_E_NOMEM, "pinned alloc failed");
+    ln.graph = nullptr;
+    ln.graph_iters = -1;
+    ln.busy = false;
+    return TL3D_OK;
+}
+
+int tl3d_icp_enqueue(tl3d_ctx *ctx, int lane, int slot_src, double scale_src, int slot_tgt, const double T_init[16],
+                     const tl3d_icp_params *prm) {
     int rc = check_slot(ctx, slot_src, true);
     if (rc) return rc;
     rc = check_slot(ctx, slot_tgt, true);
     if (rc) return rc;
-    REQUIRE(prm && out, TL3D_E_INVALID, "null argument");
+    REQUIRE(lane >= 0 && lane < TL3D_ICP_LANES, TL3D_E_INVALID, "lane %d out of range [0,%d)", lane, TL3D_ICP_LANES);
+    REQUIRE(prm != nullptr, TL3D_E_INVALID, "null argument");
     REQUIRE(prm->iters >= 0 && prm->iters <= 1000, TL3D_E_INVALID, "iters out of range");
     REQUIRE(prm->stride >= 1, TL3D_E_INVALID, "stride must be >= 1");
     REQUIRE(prm->max_dist > 0, TL3D_E_INVALID, "max_dist must be positive");
     REQUIRE(ctx->slots[slot_tgt].has_normals, TL3D_E_STATE, "target slot %d has no normal map (call tl3d_build_normals)", slot_tgt);
     TL3D_HIP(hipSetDevice(ctx->device));
-    IcpState h;
-    memset(&h, 0, sizeof(h));
+    rc = icp_lane_init(ctx, lane);
+    if (rc) return rc;
+    tl3d_ctx::IcpLane &ln = ctx->icp_lanes[lane];
+    REQUIRE(!ln.busy, TL3D_E_STATE, "ICP lane %d still holds an uncollected run", lane);
+    // order this run after the frames it reads became valid on the main stream
+    Slot &ss = ctx->slots[slot_src], &st = ctx->slots[slot_tgt];
+    if (ss.ev_upload) TL3D_HIP(hipStreamWaitEvent(ln.stream, ss.ev_upload, 0));
+    if (st.ev_upload) TL3D_HIP(hipStreamWaitEvent(ln.stream, st.ev_upload, 0));
+    if (st.ev_normals) TL3D_HIP(hipStreamWaitEvent(ln.stream, st.ev_normals, 0));
+    IcpState *h = ln.host;
+    memset(h, 0, sizeof(*h));
     if (T_init) {
-        memcpy(h.T, T_init, sizeof(h.T));
+        memcpy(h->T, T_init, sizeof(h->T));
     } else {
-        h.T[0] = h.T[5] = h.T[10] = h.T[15] = 1.0;
+        h->T[0] = h->T[5] = h->T[10] = h->T[15] = 1.0;
     }
-    TL3D_HIP(hipMemcpyAsync(ctx->icp_state, &h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
-    TL3D_HIP(hipStreamSynchronize(ctx->stream));      // h is a stack object
-    const int Ws = (ctx->cam.W + prm->stride - 1) / prm->stride, Hs = (ctx->cam.H + prm->stride - 1) / prm->stride;
-    long long nb = ((long long)Ws * Hs + 255) / 256;
-    if (nb > ICP_MAX_BLOCKS) nb = ICP_MAX_BLOCKS;
-    if (nb < 1) nb = 1;
-    const float mind = (float)ctx->cfg.min_depth, maxd = (float)ctx->cfg.max_depth;
-    for (int it = 0; it <= prm->iters; ++it) {
-        const int final_pass = (it == prm->iters);
-        rc = launch_icp_iteration(ctx->stream, ctx->cam, ctx->slots[slot_src].depth, (float)scale_src, mind, maxd,
-                                  ctx->slots[slot_tgt].nmap, prm->stride, (float)prm->max_dist, prm->damping, prm->eps, prm->eig_rel,
-                                  final_pass, ctx->icp_slab, ctx->icp_state, (int)nb);
-        if (rc) return rc;
+    IcpRun *r = ln.run_host;
+    r->depth_src = ss.depth;
+    r->nmap_tgt = st.nmap;
+    r->scale = (float)scale_src;
+    r->md2 = (float)prm->max_dist * (float)prm->max_dist;
+    r->mind = (float)ctx->cfg.min_depth;
+    r->maxd = (float)ctx->cfg.max_depth;
+    r->stride = prm->stride;
+    r->Ws = (ctx->cam.W + prm->stride - 1) / prm->stride;
+    r->Hs = (ctx->cam.H + prm->stride - 1) / prm->stride;
+    r->pad = 0;
+    r->damping = prm->damping;
+    r->eps = prm->eps;
+    r->eig_rel = prm->eig_rel;
+    // The chain's launch arguments never change (everything per-run sits behind ln.run / ln.state / pinned buffers), so
+    // it is captured once per iteration count and replayed: one host call per registration instead of ~25.
+    if (!ln.graph || ln.graph_iters != prm->iters) {
+        if (ln.graph) { (void)hipGraphExecDestroy(ln.graph); ln.graph = nullptr; }
+        hipGraph_t g = nullptr;
+        TL3D_HIP(hipStreamBeginCapture(ln.stream, hipStreamCaptureModeThreadLocal));
+        hipError_t ce = hipMemcpyAsync(ln.run, ln.run_host, sizeof(IcpRun), hipMemcpyHostToDevice, ln.stream);
+        if (ce == hipSuccess) ce = hipMemcpyAsync(ln.state, ln.host, sizeof(IcpState), hipMemcpyHostToDevice, ln.stream);
+        int lrc = TL3D_OK;
+        for (int it = 0; ce == hipSuccess && lrc == TL3D_OK && it <= prm->iters; ++it)
+            lrc = launch_icp_iteration(ln.stream, ctx->cam, ln.run, it == prm->iters, ln.slab, ln.state, ICP_MAX_BLOCKS);
+        if (ce == hipSuccess && lrc == TL3D_OK) ce = hipMemcpyAsync(ln.host, ln.state, sizeof(IcpState), hipMemcpyDeviceToHost, ln.stream);
+        hipError_t ee = hipStreamEndCapture(ln.stream, &g);
+        if (ce != hipSuccess || ee != hipSuccess || lrc != TL3D_OK || !g) {
+            if (g) (void)hipGraphDestroy(g);
+            return set_err(TL3D_E_HIP, "ICP graph capture failed: %s", hipGetErrorString(ce != hipSuccess ? ce : ee));
+        }
+        hipError_t ie = hipGraphInstantiate(&ln.graph, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (ie != hipSuccess) { ln.graph = nullptr; return set_err(TL3D_E_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ie)); }
+        ln.graph_iters = prm->iters;
     }
-    TL3D_HIP(hipMemcpyAsync(&h, ctx->icp_state, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
-    TL3D_HIP(hipStreamSynchronize(ctx->stream));
+    TL3D_HIP(hipGraphLaunch(ln.graph, ln.stream));
+    ln.busy = true;
+    return TL3D_OK;
+}
+
+int tl3d_icp_collect(tl3d_ctx *ctx, int lane, tl3d_icp_result *out) {
+    REQUIRE(ctx && out, TL3D_E_INVALID, "null argument");
+    REQUIRE(lane >= 0 && lane < TL3D_ICP_LANES, TL3D_E_INVALID, "lane %d out of range [0,%d)", lane, TL3D_ICP_LANES);
+    tl3d_ctx::IcpLane &ln = ctx->icp_lanes[lane];
+    REQUIRE(ln.stream && ln.busy, TL3D_E_STATE, "ICP lane %d holds no run", lane);
+    TL3D_HIP(hipSetDevice(ctx->device));
+    TL3D_HIP(hipStreamSynchronize(ln.stream));
+    ln.busy = false;
+    const IcpState &h = *ln.host;
     memcpy(out->T, h.T, sizeof(out->T));
     out->n_corr = (int64_t)h.sums[28];
     out->n_src = (int64_t)h.sums[29];
@@ -578,6 +649,14 @@ int tl3d_icp_p2plane(tl3d_ctx *ctx, int slot_src, double scale_src, int slot_tgt
     out->iters_run = h.iters_run;
     out->status = h.status;
     return TL3D_OK;
+}
+
+int tl3d_icp_p2plane(tl3d_ctx *ctx, int slot_src, double scale_src, int slot_tgt, const double T_init[16],
+                     const tl3d_icp_params *prm, tl3d_icp_result *out) {
+    REQUIRE(out != nullptr, TL3D_E_INVALID, "null argument");
+    int rc = tl3d_icp_enqueue(ctx, 0, slot_src, scale_src, slot_tgt, T_init, prm);
+    if (rc) return rc;
+    return tl3d_icp_collect(ctx, 0, out);
 }
 
 // ------------------------------------------------------------------------------------------- grids

@@ -54,11 +54,20 @@ struct IcpState {                // lives in device memory for the whole ICP run
     int pad;
 };
 
+struct IcpRun {                  // per-run arguments of the ICP kernels, read from device memory so that a lane's
+    const float *depth_src;      // kernel chain has constant launch arguments and can be replayed as a hipGraph
+    const float4 *nmap_tgt;
+    float scale, md2, mind, maxd;
+    int stride, Ws, Hs, pad;
+    double damping, eps, eig_rel;
+};
+
 struct Slot {
     float *depth = nullptr;      // [H][W] f32
     uint8_t *bgr = nullptr;      // [H][W][3]
     float4 *nmap = nullptr;      // [H][W] (nx,ny,nz,d), lazily allocated
     hipEvent_t ev_upload = nullptr;   // recorded on the main stream after the slot's last upload
+    hipEvent_t ev_normals = nullptr;  // recorded on the main stream after the slot's normal map was built
     bool has_color = false;
     bool loaded = false;
     bool has_normals = false;
@@ -95,8 +104,18 @@ struct tl3d_ctx {
     unsigned long long *block_offsets;
     size_t scratch_blocks;
     unsigned long long *d_counters;   // device counters [16]
-    double *icp_slab;            // [ICP_MAX_BLOCKS][ICP_SLAB]
-    tl3d::IcpState *icp_state;
+    struct IcpLane {             // one in-flight ICP run: own stream, device state, partial-sum slab, pinned read-back
+        hipStream_t stream;
+        double *slab;            // [ICP_MAX_BLOCKS][ICP_SLAB]
+        tl3d::IcpState *state;
+        tl3d::IcpState *host;    // pinned: initial state in, final state out
+        tl3d::IcpRun *run;       // device descriptor of the current run
+        tl3d::IcpRun *run_host;  // pinned
+        hipGraphExec_t graph;    // captured chain: descriptor + state upload, (iters+1) x (reduce, solve), state download
+        int graph_iters;
+        bool busy;
+    };
+    IcpLane icp_lanes[TL3D_ICP_LANES];
     float *bounds_slab;
     // stats / profiling
     tl3d_stats stats;
@@ -149,9 +168,7 @@ int launch_tsdf_update(hipStream_t s, const Cam &cam, const Grid &g, const PoseF
                        float maxd, int2 *grid, void *scratch, unsigned long long *counters, bool count);
 // normals + icp
 int launch_normals(hipStream_t s, const Cam &cam, const float *depth, float scale, float mind, float maxd, float jump, float4 *nmap);
-int launch_icp_iteration(hipStream_t s, const Cam &cam, const float *depth_src, float scale, float mind, float maxd,
-                         const float4 *nmap_tgt, int stride, float max_dist, double damping, double eps, double eig_rel, int final_pass,
-                         double *slab, IcpState *state, int nblocks);
+int launch_icp_iteration(hipStream_t s, const Cam &cam, const IcpRun *run, int final_pass, double *slab, IcpState *state, int nblocks);
 // extraction
 int launch_extract_count(hipStream_t s, const Grid &g, int mode, int min_count, int min_weight, double max_abs,
                          const int2 *tsdf, const unsigned long long *cen, unsigned *block_counts, int nblocks);

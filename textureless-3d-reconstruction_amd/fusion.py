@@ -184,6 +184,20 @@ class FusionContext:
         return dict(T=np.array(res.T).reshape(4, 4), fitness=res.fitness, rmse=res.rmse, n_corr=res.n_corr,
                     n_src=res.n_src, iters_run=res.iters_run, status=res.status)
 
+    def icp_enqueue(self, lane: int, slot_src: int, slot_tgt: int, T_init=None, iters=10, stride=4, max_dist=0.05,
+                    damping=1e-6, eps=1e-9, scale_src=1.0, eig_rel=1e-4):
+        """Asynchronous form: up to abi.ICP_LANES independent registrations in flight (one per lane)."""
+        T0 = np.ascontiguousarray(np.eye(4) if T_init is None else np.asarray(T_init, np.float64).reshape(4, 4))
+        prm = abi.IcpParams(int(iters), int(stride), float(max_dist), float(damping), float(eps), float(eig_rel))
+        abi.check(self._lib.tl3d_icp_enqueue(self._h, int(lane), int(slot_src), float(scale_src), int(slot_tgt), abi.ptr(T0),
+                                             C.byref(prm)))
+
+    def icp_collect(self, lane: int):
+        res = abi.IcpResult()
+        abi.check(self._lib.tl3d_icp_collect(self._h, int(lane), C.byref(res)))
+        return dict(T=np.array(res.T).reshape(4, 4), fitness=res.fitness, rmse=res.rmse, n_corr=res.n_corr,
+                    n_src=res.n_src, iters_run=res.iters_run, status=res.status)
+
     # ---- grids -----------------------------------------------------------------------------
     def reset(self):
         abi.check(self._lib.tl3d_grid_reset(self._h))

@@ -72,36 +72,57 @@ class DepthToReconstructionPipeline:
 
     # ---- poses: ICP replaces detect_and_match / compute_pose ---------------------------------------
     def _register(self, ctx: FusionContext, scale: float, init_poses=None):
+        """Frame-to-frame registration.  Consecutive pairs are independent, so they are enqueued on the library's ICP
+        lanes in batches (each run is a latency-bound chain of small kernels; several chains fill the GPU) and collected
+        in order.  A failed pair drops its frame (reference rule, D2R:598-615): the following pair is then re-registered
+        against the last kept frame."""
         cfg = self.config
         n = len(self.depths)
+        lanes = abi.ICP_LANES
+        kw = dict(iters=cfg.icp_iters, stride=cfg.icp_stride, max_dist=cfg.icp_max_dist, damping=cfg.icp_damping,
+                  scale_src=scale, eig_rel=cfg.icp_eig_rel)
         poses = [(np.eye(3), np.zeros((3, 1)))]
         index = [0]
         prev = 0
-        ctx.build_normals(0, scale=scale)
-        T_guess = np.eye(4)
-        for i in range(1, n):
-            print(f"\nProcessing image {i}...")
+        for i in range(n):
             ctx.build_normals(i, scale=scale)
-            if init_poses is not None:
-                r0, t0 = init_poses[prev]
-                r1, t1 = init_poses[i]
-                rr = np.asarray(r1) @ np.asarray(r0).T
-                T_guess = np.eye(4)
-                T_guess[:3, :3], T_guess[:3, 3] = rr, (np.asarray(t1).reshape(3) - rr @ np.asarray(t0).reshape(3))
-            res = ctx.icp(prev, i, T_init=T_guess, iters=cfg.icp_iters, stride=cfg.icp_stride, max_dist=cfg.icp_max_dist,
-                          damping=cfg.icp_damping, scale_src=scale, eig_rel=cfg.icp_eig_rel)
-            self.icp_log.append(dict(frame=i, against=prev, **{k: res[k] for k in ("fitness", "rmse", "n_corr", "iters_run", "status")}))
-            if res["status"] == 2 or res["n_corr"] < 8:
-                # mirrors the reference's skip rule (<8 matches / pose None, D2R:598-615): pose list not extended
-                print(f"  Skipping - registration failed (correspondences: {res['n_corr']})")
-                continue
-            T = res["T"]
-            r_c, t_c = compose(T[:3, :3], T[:3, 3], *poses[-1])
-            poses.append((r_c, t_c))
-            index.append(i)
-            print(f"  ICP: fitness {res['fitness']:.3f}, rmse {res['rmse'] * 1e3:.2f} mm, {res['iters_run']} iterations")
-            T_guess = T                      # constant-velocity prior for the next pair
-            prev = i
+        T_guess = np.eye(4)
+
+        def prior(a, b_):
+            if init_poses is None:
+                return T_guess
+            r0, t0 = init_poses[a]
+            r1, t1 = init_poses[b_]
+            rr = np.asarray(r1) @ np.asarray(r0).T
+            T = np.eye(4)
+            T[:3, :3], T[:3, 3] = rr, (np.asarray(t1).reshape(3) - rr @ np.asarray(t0).reshape(3))
+            return T
+
+        i = 1
+        while i < n:
+            batch = list(range(i, min(n, i + lanes)))
+            for lane, cur in enumerate(batch):
+                src = prev if cur == batch[0] else cur - 1
+                ctx.icp_enqueue(lane, src, cur, T_init=prior(src, cur), **kw)
+            results = [ctx.icp_collect(lane) for lane in range(len(batch))]
+            for lane, cur in enumerate(batch):
+                print(f"\nProcessing image {cur}...")
+                res = results[lane]
+                src = prev if cur == batch[0] else cur - 1
+                if src != prev:                       # the frame this run started from was dropped: redo against `prev`
+                    res = ctx.icp(prev, cur, T_init=prior(prev, cur), **kw)
+                self.icp_log.append(dict(frame=cur, against=prev, **{k: res[k] for k in ("fitness", "rmse", "n_corr", "iters_run", "status")}))
+                if res["status"] == 2 or res["n_corr"] < 8:
+                    print(f"  Skipping - registration failed (correspondences: {res['n_corr']})")
+                    continue
+                T = res["T"]
+                r_c, t_c = compose(T[:3, :3], T[:3, 3], *poses[-1])
+                poses.append((r_c, t_c))
+                index.append(cur)
+                print(f"  ICP: fitness {res['fitness']:.3f}, rmse {res['rmse'] * 1e3:.2f} mm, {res['iters_run']} iterations")
+                T_guess = T                  # constant-velocity prior for the next batch
+                prev = cur
+            i = batch[-1] + 1
         return poses, index
 
     # ---- reconstruct ---------------------------------------------------------------------------------
