@@ -47,6 +47,17 @@ def plan_grid(bounds_min, bounds_max, voxel_size, grid_dim, channels=abi.CH_TSDF
     return GridSpec(tuple(int(d) for d in dims), tuple(float(o) for o in origin), v, trunc_voxels * v, channels), clipped
 
 
+def align_grid_to_open3d(grid: GridSpec, min_bound) -> GridSpec:
+    """Shift a grid by less than one voxel so its lattice coincides with Open3D's (voxel origin = min_bound - voxel/2,
+    depth_to_reconstruction.py:410).  With the lattices in phase the fused centroids are the reference's centroids up
+    to the accumulator quantum; out of phase, two 5 mm samplings of one surface sit 1-2 mm apart."""
+    v = float(grid.voxel_size)
+    o3d = np.asarray(min_bound, np.float64) - 0.5 * v
+    org = np.asarray(grid.origin, np.float64)
+    shift = np.mod(o3d - org, v)                       # in [0, v)
+    return GridSpec(grid.dims, tuple(float(x) for x in org + shift - v), grid.voxel_size, grid.sdf_trunc, grid.channels)
+
+
 class DepthToReconstructionPipeline:
     def __init__(self, config: ReconstructionConfig = None):
         self.config = config or ReconstructionConfig()
