@@ -102,10 +102,13 @@ __global__ __launch_bounds__(256) void centroid_frame_kernel(Cam cam, Grid g, Bp
             k = centroid_key(g, pt, r8, g8, b8);
         }
     }
-    const unsigned long long mv = __ballot(valid), mk = __ballot(k.rec != ~0ull);
-    if ((threadIdx.x & 63) == 0 && mv) {
-        atomicAdd(counters + 0, (unsigned long long)__popcll(mk));
-        atomicAdd(counters + 1, (unsigned long long)(__popcll(mv) - __popcll(mk)));
+    // statistics: one pair of adds per workgroup into one of 256 counter lines (a single hot word would serialise the
+    // whole launch: same-address atomics retire at ~90 per microsecond)
+    const int nvalid = __syncthreads_count(valid), nkept = __syncthreads_count(k.rec != ~0ull);
+    if (threadIdx.x == 0 && nvalid) {
+        unsigned long long *line = counters + (size_t)(blockIdx.x & 255) * 8;
+        atomicAdd(line + 0, (unsigned long long)nkept);
+        atomicAdd(line + 1, (unsigned long long)(nvalid - nkept));
     }
     centroid_commit_runs(k, grid);
 }
@@ -123,10 +126,13 @@ __global__ __launch_bounds__(256) void centroid_points_kernel(Grid g, const floa
         const float pt[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
         k = centroid_key(g, pt, rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]);
     }
-    const unsigned long long mv = __ballot(valid), mk = __ballot(k.rec != ~0ull);
-    if ((threadIdx.x & 63) == 0 && mv) {
-        atomicAdd(counters + 0, (unsigned long long)__popcll(mk));
-        atomicAdd(counters + 1, (unsigned long long)(__popcll(mv) - __popcll(mk)));
+    // statistics: one pair of adds per workgroup into one of 256 counter lines (a single hot word would serialise the
+    // whole launch: same-address atomics retire at ~90 per microsecond)
+    const int nvalid = __syncthreads_count(valid), nkept = __syncthreads_count(k.rec != ~0ull);
+    if (threadIdx.x == 0 && nvalid) {
+        unsigned long long *line = counters + (size_t)(blockIdx.x & 255) * 8;
+        atomicAdd(line + 0, (unsigned long long)nkept);
+        atomicAdd(line + 1, (unsigned long long)(nvalid - nkept));
     }
     centroid_commit_runs(k, grid);
 }

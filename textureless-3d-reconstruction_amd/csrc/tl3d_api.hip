@@ -195,6 +195,8 @@ int tl3d_create(const tl3d_config *cfg, int device, tl3d_ctx **out) {
     }
     if (hipMalloc(&ctx->d_counters, 16 * sizeof(unsigned long long)) != hipSuccess) return fail(set_err(TL3D_E_NOMEM, "alloc failed"));
     if (hipMemsetAsync(ctx->d_counters, 0, 16 * sizeof(unsigned long long), ctx->stream) != hipSuccess) return fail(set_err(TL3D_E_HIP, "memset failed"));
+    if (hipMalloc(&ctx->d_cen_counters, 256 * 8 * sizeof(unsigned long long)) != hipSuccess) return fail(set_err(TL3D_E_NOMEM, "alloc failed"));
+    if (hipMemsetAsync(ctx->d_cen_counters, 0, 256 * 8 * sizeof(unsigned long long), ctx->stream) != hipSuccess) return fail(set_err(TL3D_E_HIP, "memset failed"));
     if (hipMalloc(&ctx->bounds_slab, 1024 * 6 * sizeof(float)) != hipSuccess) return fail(set_err(TL3D_E_NOMEM, "alloc failed"));
     for (int i = 0; i < 2; ++i)
         if (hipEventCreate(&ctx->ev[i]) != hipSuccess) return fail(set_err(TL3D_E_HIP, "event create failed"));
@@ -231,6 +233,7 @@ int tl3d_destroy(tl3d_ctx *ctx) {
     if (ctx->block_counts) (void)hipFree(ctx->block_counts);
     if (ctx->block_offsets) (void)hipFree(ctx->block_offsets);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+    if (ctx->d_cen_counters) (void)hipFree(ctx->d_cen_counters);
     for (int l = 0; l < TL3D_ICP_LANES; ++l) {
         tl3d_ctx::IcpLane &ln = ctx->icp_lanes[l];
         if (ln.stream) (void)hipStreamSynchronize(ln.stream);
@@ -386,7 +389,7 @@ int tl3d_accumulate_centroid(tl3d_ctx *ctx, int slot, const double R[9], const d
     TL3D_HIP(hipSetDevice(ctx->device));
     const Slot &s = ctx->slots[slot];
     const PoseD p = make_pose_d(R, t, (flags & TL3D_F_NO_POSE) != 0);
-    rc = launch_centroid_frame(ctx->stream, ctx->cam, ctx->grid, a, p, s.depth, s.has_color ? s.bgr : nullptr, ctx->centroid, ctx->d_counters);
+    rc = launch_centroid_frame(ctx->stream, ctx->cam, ctx->grid, a, p, s.depth, s.has_color ? s.bgr : nullptr, ctx->centroid, ctx->d_cen_counters);
     if (rc) return rc;
     ctx->stats.centroid_launches++;
     return TL3D_OK;
@@ -412,7 +415,7 @@ int tl3d_accumulate_points(tl3d_ctx *ctx, const float *xyz, const uint8_t *rgb, 
         dxyz = tx;
         drgb = tc;
     }
-    int rc = launch_centroid_points(ctx->stream, ctx->grid, dxyz, drgb, n, ctx->centroid, ctx->d_counters);
+    int rc = launch_centroid_points(ctx->stream, ctx->grid, dxyz, drgb, n, ctx->centroid, ctx->d_cen_counters);
     if (!direct) {
         hipError_t e = hipStreamSynchronize(ctx->stream);
         (void)hipFree(tx);
@@ -831,8 +834,12 @@ int tl3d_get_stats(tl3d_ctx *ctx, tl3d_stats *out) {
     REQUIRE(ctx && out, TL3D_E_INVALID, "null argument");
     TL3D_HIP(hipSetDevice(ctx->device));
     unsigned long long h[16];
+    std::vector<unsigned long long> hc(256 * 8);
     TL3D_HIP(hipMemcpyAsync(h, ctx->d_counters, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    TL3D_HIP(hipMemcpyAsync(hc.data(), ctx->d_cen_counters, hc.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     TL3D_HIP(hipStreamSynchronize(ctx->stream));
+    h[0] = h[1] = 0;
+    for (int i = 0; i < 256; ++i) { h[0] += hc[(size_t)i * 8]; h[1] += hc[(size_t)i * 8 + 1]; }
     for (int i = 0; i < ctx->ktimers_used; ++i) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, ctx->ktimers[i].a, ctx->ktimers[i].b) == hipSuccess) {
@@ -856,6 +863,7 @@ int tl3d_reset_stats(tl3d_ctx *ctx) {
     TL3D_HIP(hipSetDevice(ctx->device));
     TL3D_HIP(hipStreamSynchronize(ctx->stream));
     TL3D_HIP(hipMemsetAsync(ctx->d_counters, 0, 16 * sizeof(unsigned long long), ctx->stream));
+    TL3D_HIP(hipMemsetAsync(ctx->d_cen_counters, 0, 256 * 8 * sizeof(unsigned long long), ctx->stream));
     memset(&ctx->stats, 0, sizeof(ctx->stats));
     ctx->ktimers_used = 0;
     return TL3D_OK;

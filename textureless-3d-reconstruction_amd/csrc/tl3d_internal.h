@@ -104,6 +104,7 @@ struct tl3d_ctx {
     unsigned long long *block_offsets;
     size_t scratch_blocks;
     unsigned long long *d_counters;   // device counters [16]
+    unsigned long long *d_cen_counters;   // centroid statistics, sharded: [256 lines][8] (points kept, points dropped)
     struct IcpLane {             // one in-flight ICP run: own stream, device state, partial-sum slab, pinned read-back
         hipStream_t stream;
         double *slab;            // [ICP_MAX_BLOCKS][ICP_SLAB]
