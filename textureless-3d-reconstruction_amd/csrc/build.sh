@@ -13,11 +13,14 @@ mkdir -p "${HERE}/build"
 for f in tl3d_api kernels_backproject kernels_centroid kernels_tsdf kernels_icp kernels_extract kernels_sor; do
   src="${HERE}/${f}.hip"; obj="${HERE}/build/${f}.o"
   if [[ ! -f "$obj" || "$src" -nt "$obj" || "${HERE}/tl3d_internal.h" -nt "$obj" || "${HERE}/bp_device.h" -nt "$obj" || "${HERE}/../../include/tl3d.h" -nt "$obj" ]]; then
+    rm -f "$obj"                                   # a failed compile must not leave a stale object to link
     "$HIPCC" "${FLAGS[@]}" ${TL3D_EXTRA_FLAGS:-} -c "$src" -o "$obj" &
     PIDS+=($!)
   fi
   OBJS+=("$obj")
 done
-for p in "${PIDS[@]:-}"; do [[ -z "$p" ]] || wait "$p"; done
+FAIL=0
+for p in "${PIDS[@]:-}"; do [[ -z "$p" ]] || wait "$p" || FAIL=1; done
+if [[ "$FAIL" != 0 ]]; then echo "build FAILED" >&2; exit 1; fi
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT" "${OBJS[@]}"
 echo "built $OUT"
