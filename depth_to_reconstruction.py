@@ -36,6 +36,8 @@ def main(argv=None):
     parser.add_argument("--tsdf-min-weight", type=int, default=0, help="> 0: keep only voxels the TSDF saw this often")
     parser.add_argument("--ascii", action="store_true", help="write the reference's ASCII fallback PLY instead of binary")
     parser.add_argument("--device", type=int, default=0)
+    parser.add_argument("--stream", action="store_true",
+                        help="decode on worker threads into pinned buffers with asynchronous uploads; host RAM never holds the sequence")
     args = parser.parse_args(argv)
 
     from tl3d.config import ReconstructionConfig
@@ -46,7 +48,7 @@ def main(argv=None):
                                   sdf_trunc_voxels=args.sdf_trunc, icp_iters=args.icp_iters, icp_stride=args.icp_stride,
                                   icp_max_dist=args.icp_max_dist, tsdf_min_weight=args.tsdf_min_weight, device=args.device)
     pipeline = DepthToReconstructionPipeline(config)
-    num_loaded = pipeline.load_data(args.rgb_folder, args.depth_folder)
+    num_loaded = (pipeline.load_data_streaming if args.stream else pipeline.load_data)(args.rgb_folder, args.depth_folder)
     if num_loaded < 2:
         print("Failed to load sufficient data")
         return 0

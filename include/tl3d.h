@@ -128,6 +128,13 @@ int tl3d_sync(tl3d_ctx *ctx);
  * lists self.images/self.depths (D2R:434-437).  bgr may be NULL (colour (0,0,0)). */
 int tl3d_upload_frame(tl3d_ctx *ctx, int slot, const void *depth_hd, int depth_kind, const uint8_t *bgr_hd);
 int tl3d_download_depth(tl3d_ctx *ctx, int slot, float *depth_out_hd);
+/* f2: decode/upload pipeline (replaces holding every decoded frame in host RAM, D2R:434-437, 469-470).
+ * Pinned staging buffers + an upload that returns at once: the host buffers must stay untouched until
+ * tl3d_slot_wait(slot) returns.  Kernels that read the slot are ordered after the copy on the device. */
+int tl3d_pinned_alloc(size_t bytes, void **out);
+int tl3d_pinned_free(void *p);
+int tl3d_upload_frame_async(tl3d_ctx *ctx, int slot, const void *depth_hd, int depth_kind, const uint8_t *bgr_hd);
+int tl3d_slot_wait(tl3d_ctx *ctx, int slot);
 
 /* a3+a4/a5: DenseReconstructor.depth_to_pointcloud (depth_to_reconstruction.py:328-384) and
  * DensePointCloudGenerator.depth_to_pointcloud (depth_enhanced_reconstruction.py:554-613).
@@ -164,6 +171,9 @@ int tl3d_icp_enqueue(tl3d_ctx *ctx, int lane, int slot_src, double scale_src, in
 int tl3d_icp_collect(tl3d_ctx *ctx, int lane, tl3d_icp_result *out);
 
 /* grids */
+/* Give a context created with channels = 0 its grid later (geometry fields of cfg: channels, nx, ny, nz, origin,
+ * voxel_size, sdf_trunc, ext_*): frames stay resident while poses and scene bounds are still being computed. */
+int tl3d_attach_grid(tl3d_ctx *ctx, const tl3d_config *cfg);
 int tl3d_grid_reset(tl3d_ctx *ctx);
 int tl3d_grid_device_ptr(tl3d_ctx *ctx, uint32_t channel, void **ptr, size_t *bytes);
 int tl3d_grid_download(tl3d_ctx *ctx, uint32_t channel, void *out_hd, size_t bytes);

@@ -114,3 +114,56 @@ def test_cli_depth_enhanced_driver(tmp_path):
     empty = tmp_path / "empty"
     empty.mkdir()
     assert cli.main(["--input", str(empty), "--output", str(out_dir)]) == 1      # DER:1452-1454
+
+
+def test_streaming_upload_path_equals_in_memory_path(tmp_path):
+    """Row f2: threaded decode -> pinned staging -> asynchronous upload gives the same reconstruction as loading
+    everything into host lists first (the reference's way, D2R:439-477)."""
+    from PIL import Image
+    scene, poses, rel, frames = _sequence(n=7)
+    rgb_dir, depth_dir = tmp_path / "rgb", tmp_path / "depth"
+    rgb_dir.mkdir(); depth_dir.mkdir()
+    for i, (d, c) in enumerate(frames):
+        Image.fromarray(c[..., ::-1]).save(rgb_dir / f"f_{i:03d}.png")
+        if i % 2:
+            np.save(depth_dir / f"f_{i:03d}_depth.npy", d)                       # float32 metres
+        else:
+            Image.fromarray(np.clip(d * 1000.0, 0, 65535).astype(np.uint16)).save(depth_dir / f"f_{i:03d}_depth.png")   # u16 mm
+    cfg = ReconstructionConfig(**CAM, grid_dim=1024)
+    a = DepthToReconstructionPipeline(cfg)
+    assert a.load_data(str(rgb_dir), str(depth_dir)) == 7
+    pa, ca, _ = a.reconstruct(poses=rel)
+    b = DepthToReconstructionPipeline(cfg)
+    assert b.load_data_streaming(str(rgb_dir), str(depth_dir)) == 7
+    pb, cb, _ = b.reconstruct(poses=rel)
+    assert np.array_equal(pa, pb) and np.array_equal(ca, cb)                      # u16 /1000 on device == on host
+
+
+def test_prefetcher_ring_reuse_and_attach_grid():
+    from tl3d.fileio import FramePrefetcher
+    import tempfile, os
+    rng = np.random.default_rng(0)
+    with tempfile.TemporaryDirectory() as td:
+        files = []
+        for i in range(9):
+            d = (1.0 + rng.random((48, 64))).astype(np.float32)
+            np.save(os.path.join(td, f"{i}_depth.npy"), d)
+            files.append(os.path.join(td, f"{i}_depth.npy"))
+        from pathlib import Path
+        with tl3d.FusionContext(64, 48, 50.0, 50.0, 32.0, 24.0, n_slots=3) as ctx:          # fewer slots than frames
+            pre = FramePrefetcher(ctx, [None] * 9, [Path(f) for f in files], n_staging=2, workers=3)
+            seen = []
+            for i, slot in pre:
+                assert slot == i % 3
+                ctx.slot_wait(slot)
+                assert np.array_equal(ctx.download_depth(slot), np.load(files[i]))
+                seen.append(i)
+            pre.close()
+            assert seen == list(range(9))
+            with pytest.raises(tl3d.Tl3dError):
+                ctx.integrate(0, (np.eye(3), np.zeros(3)))                                   # no grid yet
+            ctx.attach_grid(tl3d.GridSpec.cube(64, 0.05, centre=(0, 0, 1.5)))
+            ctx.integrate(0, (np.eye(3), np.zeros(3)))
+            assert ctx.download_grid(tl3d.CH_TSDF)[:, 1].sum() > 0
+            with pytest.raises(tl3d.Tl3dError):
+                ctx.attach_grid(tl3d.GridSpec.cube(64, 0.05))                                # already has one

@@ -21,7 +21,8 @@ ICP_LANES = 8
 # every symbol include/tl3d.h declares (checked by tests/test_cabi_symbols.py against the header text)
 SYMBOLS = [
     "tl3d_last_error", "tl3d_version", "tl3d_device_count", "tl3d_create", "tl3d_destroy", "tl3d_sync",
-    "tl3d_upload_frame", "tl3d_download_depth", "tl3d_backproject", "tl3d_accumulate_centroid",
+    "tl3d_upload_frame", "tl3d_download_depth", "tl3d_pinned_alloc", "tl3d_pinned_free", "tl3d_upload_frame_async",
+    "tl3d_slot_wait", "tl3d_attach_grid", "tl3d_backproject", "tl3d_accumulate_centroid",
     "tl3d_accumulate_points", "tl3d_points_bounds", "tl3d_integrate", "tl3d_build_normals",
     "tl3d_download_normals", "tl3d_icp_p2plane", "tl3d_icp_enqueue", "tl3d_icp_collect", "tl3d_grid_reset", "tl3d_grid_device_ptr",
     "tl3d_grid_download", "tl3d_grid_upload", "tl3d_grid_add", "tl3d_extract", "tl3d_statistical_outlier",
@@ -111,6 +112,11 @@ def load():
         "tl3d_sync": [vp],
         "tl3d_upload_frame": [vp, i32, vp, i32, vp],
         "tl3d_download_depth": [vp, i32, vp],
+        "tl3d_pinned_alloc": [C.c_size_t, C.POINTER(vp)],
+        "tl3d_pinned_free": [vp],
+        "tl3d_upload_frame_async": [vp, i32, vp, i32, vp],
+        "tl3d_slot_wait": [vp, i32],
+        "tl3d_attach_grid": [vp, C.POINTER(Config)],
         "tl3d_backproject": [vp, i32, vp, vp, dbl, u32, i32, dbl, dbl, vp, vp, i64, C.POINTER(i64)],
         "tl3d_accumulate_centroid": [vp, i32, vp, vp, dbl, u32, i32, dbl, dbl],
         "tl3d_accumulate_points": [vp, vp, vp, i64],

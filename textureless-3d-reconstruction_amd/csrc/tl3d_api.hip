@@ -91,6 +91,66 @@ static int check_slot(tl3d_ctx *ctx, int slot, bool need_loaded) {
     return TL3D_OK;
 }
 
+static int upload_impl(tl3d_ctx *ctx, int slot, const void *depth_hd, int depth_kind, const uint8_t *bgr_hd, bool wait);
+
+static int validate_grid(const tl3d_config *cfg) {
+    REQUIRE((cfg->channels & ~(TL3D_CH_TSDF | TL3D_CH_CENTROID)) == 0 && cfg->channels != 0, TL3D_E_INVALID, "bad channel bits 0x%x", cfg->channels);
+    REQUIRE(cfg->nx > 0 && cfg->ny > 0 && cfg->nz > 0 && cfg->nx % TL3D_BRICK == 0 && cfg->ny % TL3D_BRICK == 0 &&
+                cfg->nz % TL3D_BRICK == 0,
+            TL3D_E_INVALID, "grid dims %dx%dx%d must be positive multiples of %d", cfg->nx, cfg->ny, cfg->nz, TL3D_BRICK);
+    REQUIRE((double)cfg->nx * cfg->ny * cfg->nz <= 4294967296.0, TL3D_E_INVALID, "grid larger than 2^32 voxels");
+    REQUIRE(cfg->voxel_size > 0, TL3D_E_INVALID, "voxel_size must be positive");
+    if (cfg->channels & TL3D_CH_TSDF) REQUIRE(cfg->sdf_trunc > 0, TL3D_E_INVALID, "sdf_trunc must be positive");
+    return TL3D_OK;
+}
+
+// allocates (or borrows) the grid channels of cfg and the TSDF side stream / scratch; ctx->stream must exist
+static int alloc_grid(tl3d_ctx *ctx, const tl3d_config *cfg) {
+    Grid &g = ctx->grid;
+    g.nx = cfg->nx; g.ny = cfg->ny; g.nz = cfg->nz;
+    g.nbx = cfg->nx / 8; g.nby = cfg->ny / 8; g.nbz = cfg->nz / 8;
+    g.oxd = cfg->origin[0]; g.oyd = cfg->origin[1]; g.ozd = cfg->origin[2]; g.vsd = cfg->voxel_size;
+    g.ox = (float)g.oxd; g.oy = (float)g.oyd; g.oz = (float)g.ozd; g.vs = (float)g.vsd;
+    g.trunc = (float)cfg->sdf_trunc;
+    g.inv_trunc = (cfg->channels & TL3D_CH_TSDF) ? 1.0f / g.trunc : 0.0f;
+    ctx->nvox = (size_t)g.nx * g.ny * g.nz;
+    if (cfg->channels & TL3D_CH_TSDF) {
+        if (cfg->ext_tsdf) {
+            ctx->tsdf = (int2 *)cfg->ext_tsdf;
+        } else {
+            if (hipMalloc(&ctx->tsdf, ctx->nvox * sizeof(int2)) != hipSuccess) return set_err(TL3D_E_NOMEM, "TSDF grid alloc (%zu B) failed", ctx->nvox * 8);
+            ctx->own_tsdf = true;
+            if (hipMemsetAsync(ctx->tsdf, 0, ctx->nvox * sizeof(int2), ctx->stream) != hipSuccess) return set_err(TL3D_E_HIP, "memset failed");
+        }
+        {   // the prep kernels are short and latency-bound: give them dispatch priority over the streaming update
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            if (hipStreamCreateWithPriority(&ctx->prep_stream, hipStreamNonBlocking, hi) != hipSuccess) return set_err(TL3D_E_HIP, "stream create failed");
+        }
+        for (int b = 0; b < 2; ++b) {
+            if (hipMalloc(&ctx->tsdf_scratch[b], tsdf_scratch_bytes(ctx->cam, g)) != hipSuccess) return set_err(TL3D_E_NOMEM, "TSDF scratch alloc failed");
+            if (hipEventCreateWithFlags(&ctx->ev_prep[b], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&ctx->ev_upd[b], hipEventDisableTiming) != hipSuccess)
+                return set_err(TL3D_E_HIP, "event create failed");
+        }
+    }
+    if (cfg->channels & TL3D_CH_CENTROID) {
+        if (cfg->ext_centroid) {
+            ctx->centroid = (unsigned long long *)cfg->ext_centroid;
+        } else {
+            if (hipMalloc(&ctx->centroid, ctx->nvox * 32) != hipSuccess) return set_err(TL3D_E_NOMEM, "centroid grid alloc (%zu B) failed", ctx->nvox * 32);
+            ctx->own_centroid = true;
+            if (hipMemsetAsync(ctx->centroid, 0, ctx->nvox * 32, ctx->stream) != hipSuccess) return set_err(TL3D_E_HIP, "memset failed");
+        }
+    }
+    ctx->cfg.channels = cfg->channels;
+    ctx->cfg.nx = cfg->nx; ctx->cfg.ny = cfg->ny; ctx->cfg.nz = cfg->nz;
+    for (int i = 0; i < 3; ++i) ctx->cfg.origin[i] = cfg->origin[i];
+    ctx->cfg.voxel_size = cfg->voxel_size;
+    ctx->cfg.sdf_trunc = cfg->sdf_trunc;
+    return TL3D_OK;
+}
+
 extern "C" {
 
 const char *tl3d_last_error(void) { return g_err; }
@@ -115,13 +175,8 @@ int tl3d_create(const tl3d_config *cfg, int device, tl3d_ctx **out) {
     REQUIRE(cfg->fx > 0 && cfg->fy > 0, TL3D_E_INVALID, "focal lengths must be positive");
     REQUIRE(cfg->n_slots >= 1 && cfg->n_slots <= (1 << 20), TL3D_E_INVALID, "n_slots %d out of range", cfg->n_slots);
     if (cfg->channels) {
-        REQUIRE((cfg->channels & ~(TL3D_CH_TSDF | TL3D_CH_CENTROID)) == 0, TL3D_E_INVALID, "unknown channel bits 0x%x", cfg->channels);
-        REQUIRE(cfg->nx > 0 && cfg->ny > 0 && cfg->nz > 0 && cfg->nx % TL3D_BRICK == 0 && cfg->ny % TL3D_BRICK == 0 &&
-                    cfg->nz % TL3D_BRICK == 0,
-                TL3D_E_INVALID, "grid dims %dx%dx%d must be positive multiples of %d", cfg->nx, cfg->ny, cfg->nz, TL3D_BRICK);
-        REQUIRE((double)cfg->nx * cfg->ny * cfg->nz <= 4294967296.0, TL3D_E_INVALID, "grid larger than 2^32 voxels");
-        REQUIRE(cfg->voxel_size > 0, TL3D_E_INVALID, "voxel_size must be positive");
-        if (cfg->channels & TL3D_CH_TSDF) REQUIRE(cfg->sdf_trunc > 0, TL3D_E_INVALID, "sdf_trunc must be positive");
+        const int vrc = validate_grid(cfg);
+        if (vrc) return vrc;
     }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
@@ -156,42 +211,8 @@ int tl3d_create(const tl3d_config *cfg, int device, tl3d_ctx **out) {
         ctx->own_stream = true;
     }
     if (cfg->channels) {
-        g.nx = cfg->nx; g.ny = cfg->ny; g.nz = cfg->nz;
-        g.nbx = cfg->nx / 8; g.nby = cfg->ny / 8; g.nbz = cfg->nz / 8;
-        g.oxd = cfg->origin[0]; g.oyd = cfg->origin[1]; g.ozd = cfg->origin[2]; g.vsd = cfg->voxel_size;
-        g.ox = (float)g.oxd; g.oy = (float)g.oyd; g.oz = (float)g.ozd; g.vs = (float)g.vsd;
-        g.trunc = (float)cfg->sdf_trunc;
-        g.inv_trunc = (cfg->channels & TL3D_CH_TSDF) ? 1.0f / g.trunc : 0.0f;
-        ctx->nvox = (size_t)g.nx * g.ny * g.nz;
-        if (cfg->channels & TL3D_CH_TSDF) {
-            if (cfg->ext_tsdf) {
-                ctx->tsdf = (int2 *)cfg->ext_tsdf;
-            } else {
-                if (hipMalloc(&ctx->tsdf, ctx->nvox * sizeof(int2)) != hipSuccess) return fail(set_err(TL3D_E_NOMEM, "TSDF grid alloc (%zu B) failed", ctx->nvox * 8));
-                ctx->own_tsdf = true;
-                if (hipMemsetAsync(ctx->tsdf, 0, ctx->nvox * sizeof(int2), ctx->stream) != hipSuccess) return fail(set_err(TL3D_E_HIP, "memset failed"));
-            }
-            {   // the prep kernels are short and latency-bound: give them dispatch priority over the streaming update
-                int lo = 0, hi = 0;
-                (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-                if (hipStreamCreateWithPriority(&ctx->prep_stream, hipStreamNonBlocking, hi) != hipSuccess) return fail(set_err(TL3D_E_HIP, "stream create failed"));
-            }
-            for (int b = 0; b < 2; ++b) {
-                if (hipMalloc(&ctx->tsdf_scratch[b], tsdf_scratch_bytes(ctx->cam, g)) != hipSuccess) return fail(set_err(TL3D_E_NOMEM, "TSDF scratch alloc failed"));
-                if (hipEventCreateWithFlags(&ctx->ev_prep[b], hipEventDisableTiming) != hipSuccess ||
-                    hipEventCreateWithFlags(&ctx->ev_upd[b], hipEventDisableTiming) != hipSuccess)
-                    return fail(set_err(TL3D_E_HIP, "event create failed"));
-            }
-        }
-        if (cfg->channels & TL3D_CH_CENTROID) {
-            if (cfg->ext_centroid) {
-                ctx->centroid = (unsigned long long *)cfg->ext_centroid;
-            } else {
-                if (hipMalloc(&ctx->centroid, ctx->nvox * 32) != hipSuccess) return fail(set_err(TL3D_E_NOMEM, "centroid grid alloc (%zu B) failed", ctx->nvox * 32));
-                ctx->own_centroid = true;
-                if (hipMemsetAsync(ctx->centroid, 0, ctx->nvox * 32, ctx->stream) != hipSuccess) return fail(set_err(TL3D_E_HIP, "memset failed"));
-            }
-        }
+        const int grc = alloc_grid(ctx, cfg);
+        if (grc) return fail(grc);
     }
     if (hipMalloc(&ctx->d_counters, 16 * sizeof(unsigned long long)) != hipSuccess) return fail(set_err(TL3D_E_NOMEM, "alloc failed"));
     if (hipMemsetAsync(ctx->d_counters, 0, 16 * sizeof(unsigned long long), ctx->stream) != hipSuccess) return fail(set_err(TL3D_E_HIP, "memset failed"));
@@ -272,6 +293,12 @@ int tl3d_sync(tl3d_ctx *ctx) {
 
 // ------------------------------------------------------------------------------------------- frames
 int tl3d_upload_frame(tl3d_ctx *ctx, int slot, const void *depth_hd, int depth_kind, const uint8_t *bgr_hd) {
+    return upload_impl(ctx, slot, depth_hd, depth_kind, bgr_hd, true);
+}
+
+}  // extern "C"
+
+static int upload_impl(tl3d_ctx *ctx, int slot, const void *depth_hd, int depth_kind, const uint8_t *bgr_hd, bool wait) {
     int rc = check_slot(ctx, slot, false);
     if (rc) return rc;
     REQUIRE(depth_hd != nullptr, TL3D_E_INVALID, "null depth");
@@ -300,7 +327,47 @@ int tl3d_upload_frame(tl3d_ctx *ctx, int slot, const void *depth_hd, int depth_k
     if (!s.ev_upload) TL3D_HIP(hipEventCreateWithFlags(&s.ev_upload, hipEventDisableTiming));
     TL3D_HIP(hipEventRecord(s.ev_upload, ctx->stream));       // the prep stream waits on this, not on the whole main stream
     // pageable host sources are consumed before hipMemcpyAsync returns only for small copies; make the hand-over explicit
-    if (!is_device_ptr(depth_hd) || (bgr_hd && !is_device_ptr(bgr_hd))) TL3D_HIP(hipStreamSynchronize(ctx->stream));
+    if (wait && (!is_device_ptr(depth_hd) || (bgr_hd && !is_device_ptr(bgr_hd)))) TL3D_HIP(hipStreamSynchronize(ctx->stream));
+    return TL3D_OK;
+}
+
+extern "C" {
+
+int tl3d_attach_grid(tl3d_ctx *ctx, const tl3d_config *cfg) {
+    REQUIRE(ctx && cfg, TL3D_E_INVALID, "null argument");
+    REQUIRE(ctx->tsdf == nullptr && ctx->centroid == nullptr, TL3D_E_STATE, "context already has a grid");
+    int rc = validate_grid(cfg);
+    if (rc) return rc;
+    TL3D_HIP(hipSetDevice(ctx->device));
+    rc = alloc_grid(ctx, cfg);
+    if (rc) return rc;
+    TL3D_HIP(hipStreamSynchronize(ctx->stream));
+    return TL3D_OK;
+}
+
+int tl3d_pinned_alloc(size_t bytes, void **out) {
+    REQUIRE(out != nullptr && bytes > 0, TL3D_E_INVALID, "bad argument");
+    if (hipHostMalloc(out, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return set_err(TL3D_E_NOMEM, "pinned allocation of %zu B failed", bytes);
+    }
+    return TL3D_OK;
+}
+
+int tl3d_pinned_free(void *p) {
+    if (p && hipHostFree(p) != hipSuccess) return set_err(TL3D_E_HIP, "hipHostFree failed");
+    return TL3D_OK;
+}
+
+int tl3d_upload_frame_async(tl3d_ctx *ctx, int slot, const void *depth_hd, int depth_kind, const uint8_t *bgr_hd) {
+    return upload_impl(ctx, slot, depth_hd, depth_kind, bgr_hd, false);
+}
+
+int tl3d_slot_wait(tl3d_ctx *ctx, int slot) {
+    int rc = check_slot(ctx, slot, true);
+    if (rc) return rc;
+    TL3D_HIP(hipSetDevice(ctx->device));
+    if (ctx->slots[slot].ev_upload) TL3D_HIP(hipEventSynchronize(ctx->slots[slot].ev_upload));
     return TL3D_OK;
 }
 

@@ -132,6 +132,81 @@ def load_data(rgb_folder, depth_folder, verbose: bool = True):
     return images, depths, names
 
 
+class FramePrefetcher:
+    """Row f2: decode files on worker threads into pinned staging buffers and hand them to the device with asynchronous
+    uploads, so decode, PCIe copy and GPU work overlap and host RAM holds `n_staging` frames instead of all of them
+    (the reference keeps every decoded frame in two Python lists, D2R:434-437).
+
+    for index, slot in FramePrefetcher(ctx, rgb_files, depth_files): ...   # frame `index` is (being) uploaded to `slot`
+    Slots are assigned round-robin over ctx.n_slots; with n_slots >= number of frames every frame stays resident.
+    """
+
+    def __init__(self, ctx, rgb_files, depth_files, n_staging: int = 4, workers: int = 4, raw_u16: bool = True):
+        from concurrent.futures import ThreadPoolExecutor
+        from .fusion import PinnedArray
+        assert len(rgb_files) == len(depth_files)
+        self.ctx, self.rgb_files, self.depth_files = ctx, list(rgb_files), list(depth_files)
+        self.raw_u16 = raw_u16
+        h, w = ctx.height, ctx.width
+        self.n_staging = max(2, int(n_staging))
+        self._f32 = [PinnedArray((h, w), np.float32) for _ in range(self.n_staging)]
+        self._u16 = [PinnedArray((h, w), np.uint16) for _ in range(self.n_staging)]
+        self._bgr = [PinnedArray((h, w, 3), np.uint8) for _ in range(self.n_staging)]
+        self._pool = ThreadPoolExecutor(max_workers=max(1, int(workers)))
+        self.decode_s = 0.0
+
+    def _decode(self, i, b):
+        import time
+        t0 = time.perf_counter()
+        img = None if self.rgb_files[i] is None else read_image_bgr(self.rgb_files[i])
+        d = DepthImageLoader.load_depth(self.depth_files[i], raw_u16=self.raw_u16)
+        if d is None:
+            raise IOError(f"cannot read depth {self.depth_files[i]}")
+        h, w = self.ctx.height, self.ctx.width
+        if d.shape != (h, w):
+            d = resize_bilinear(d.astype(np.float32) / (1000.0 if d.dtype == np.uint16 else 1.0), w, h)
+        dst = self._u16[b].array if d.dtype == np.uint16 else self._f32[b].array
+        np.copyto(dst, d)
+        if img is not None:
+            if img.shape[:2] != (h, w):
+                raise ValueError(f"image {self.rgb_files[i]} is {img.shape[:2]}, expected {(h, w)}")
+            np.copyto(self._bgr[b].array, img)
+        self.decode_s += time.perf_counter() - t0
+        return dst, (self._bgr[b].array if img is not None else None)
+
+    def __iter__(self):
+        """Invariant: the frames that own a staging buffer (being decoded, or decoded and possibly still being copied)
+        form a contiguous index range of length <= n_staging, so `index % n_staging` never collides."""
+        from collections import deque
+        n, S = len(self.depth_files), self.n_staging
+        pending = {}                                  # frame index -> decode future
+        in_flight = deque()                           # frame indices whose upload was enqueued but not yet waited for
+        nxt = 0
+        for i in range(n):
+            while True:
+                while nxt < n and len(pending) + len(in_flight) < S:
+                    pending[nxt] = self._pool.submit(self._decode, nxt, nxt % S)
+                    nxt += 1
+                if i in pending:
+                    break
+                self.ctx.slot_wait(in_flight.popleft() % self.ctx.n_slots)      # ring full of uploads: retire the oldest
+            depth, bgr = pending.pop(i).result()
+            slot = i % self.ctx.n_slots
+            self.ctx.upload_async(slot, depth, bgr)
+            in_flight.append(i)
+            while len(in_flight) > max(1, S - 2):      # keep most of the ring for decoders
+                self.ctx.slot_wait(in_flight.popleft() % self.ctx.n_slots)
+            yield i, slot
+        while in_flight:
+            self.ctx.slot_wait(in_flight.popleft() % self.ctx.n_slots)
+
+    def close(self):
+        self._pool.shutdown(wait=True)
+        for group in (self._f32, self._u16, self._bgr):
+            for p in group:
+                p.free()
+
+
 def save_depth_like_processor(depth_m: np.ndarray, out_dir, frame_id: str):
     """Write `<id>_depth.npy` and `<id>_depth.png` = (depth*1000).astype(uint16), the pair depth_processor.py:905-921
     produces (used by the synthetic-dataset writer and the plumbing test)."""

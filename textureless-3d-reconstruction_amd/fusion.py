@@ -34,6 +34,31 @@ class GridSpec:
                         4.0 * voxel_size if sdf_trunc is None else sdf_trunc, channels)
 
 
+class PinnedArray:
+    """numpy view of page-locked host memory from tl3d_pinned_alloc (async H2D copies need it to overlap)."""
+
+    def __init__(self, shape, dtype):
+        self.lib = abi.load()
+        self.nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        abi.check(self.lib.tl3d_pinned_alloc(self.nbytes, C.byref(p)))
+        self._p = p
+        buf = (C.c_char * self.nbytes).from_address(p.value)
+        self.array = np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    def free(self):
+        if self._p is not None:
+            self.array = None
+            self.lib.tl3d_pinned_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class FusionContext:
     def __init__(self, width: int, height: int, fx: float, fy: float, cx: float, cy: float,
                  min_depth: float = 0.1, max_depth: float = 50.0, n_slots: int = 2,
@@ -109,6 +134,30 @@ class FusionContext:
                 bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
             assert tuple(bgr.shape) == (self.height, self.width, 3), f"colour {tuple(bgr.shape)}"
         abi.check(self._lib.tl3d_upload_frame(self._h, int(slot), abi.ptr(depth), kind, abi.ptr(bgr)))
+
+    def upload_async(self, slot: int, depth, bgr=None):
+        """Enqueue the copies and return; `depth` / `bgr` (ideally pinned, see pinned_array) must stay untouched until
+        slot_wait(slot).  Device work that reads the slot is ordered after the copy automatically."""
+        kind = abi.DEPTH_U16_MM if depth.dtype == np.uint16 else abi.DEPTH_F32_M
+        assert depth.flags["C_CONTIGUOUS"] and depth.shape == (self.height, self.width)
+        assert bgr is None or (bgr.flags["C_CONTIGUOUS"] and bgr.shape == (self.height, self.width, 3) and bgr.dtype == np.uint8)
+        abi.check(self._lib.tl3d_upload_frame_async(self._h, int(slot), abi.ptr(depth), kind, abi.ptr(bgr)))
+
+    def slot_wait(self, slot: int):
+        abi.check(self._lib.tl3d_slot_wait(self._h, int(slot)))
+
+    def attach_grid(self, grid: "GridSpec", ext_tsdf=None, ext_centroid=None):
+        """Give a grid-less context its fusion grid (frames stay resident across registration and fusion)."""
+        cfg = abi.Config()
+        cfg.abi_version = abi.ABI_VERSION
+        cfg.channels = int(grid.channels)
+        cfg.nx, cfg.ny, cfg.nz = (int(d) for d in grid.dims)
+        cfg.origin = (C.c_double * 3)(*[float(o) for o in grid.origin])
+        cfg.voxel_size, cfg.sdf_trunc = float(grid.voxel_size), float(grid.sdf_trunc)
+        cfg.ext_tsdf, cfg.ext_centroid = abi.ptr(ext_tsdf), abi.ptr(ext_centroid)
+        abi.check(self._lib.tl3d_attach_grid(self._h, C.byref(cfg)))
+        self._keep = (ext_tsdf, ext_centroid)
+        self.grid = grid
 
     def download_depth(self, slot: int) -> np.ndarray:
         out = np.empty((self.height, self.width), np.float32)

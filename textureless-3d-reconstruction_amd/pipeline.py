@@ -73,7 +73,32 @@ class DepthToReconstructionPipeline:
     # ---- a2 --------------------------------------------------------------------------------------
     def load_data(self, rgb_folder: str, depth_folder: str) -> int:
         self.images, self.depths, self.image_names = fileio.load_data(rgb_folder, depth_folder)
+        self._files = None
         return len(self.images)
+
+    def load_data_streaming(self, rgb_folder: str, depth_folder: str) -> int:
+        """Same pairing rules and messages as load_data(), but only the file names are kept: reconstruct() then decodes
+        on worker threads into pinned buffers and uploads asynchronously (fileio.FramePrefetcher), so host RAM never
+        holds the whole sequence (the reference keeps every frame in two lists, D2R:434-437)."""
+        from pathlib import Path
+        rgb_path, depth_path = Path(rgb_folder), Path(depth_folder)
+        files = sorted(f for f in rgb_path.iterdir() if f.suffix.lower() in fileio.IMAGE_SUFFIXES)
+        print(f"Found {len(files)} RGB images")
+        pairs = []
+        for f in files:
+            d = fileio.DepthImageLoader.find_matching_depth(f.name, depth_path)
+            if d is None:
+                print(f"  Warning: No depth found for {f.name}")
+                continue
+            pairs.append((f, d))
+        print(f"Loaded {len(pairs)} image-depth pairs")
+        self._files = pairs
+        self.image_names = [f.name for f, _ in pairs]
+        if pairs:
+            first = fileio.read_image_bgr(pairs[0][0])
+            self._frame_shape = first.shape[:2]
+        self.images, self.depths = [None] * len(pairs), [None] * len(pairs)
+        return len(pairs)
 
     def set_frames(self, images, depths, names=None):
         """Same state load_data() leaves, from arrays already in memory."""
@@ -150,22 +175,33 @@ class DepthToReconstructionPipeline:
         print("\n" + "=" * 70)
         print("DEPTH-ENHANCED RECONSTRUCTION PIPELINE (MI355X: ICP + voxel fusion)")
         print("=" * 70)
-        h, w = self.depths[0].shape
+        streaming = getattr(self, "_files", None) is not None
+        h, w = self._frame_shape if streaming else self.depths[0].shape
         n = len(self.depths)
         scale = float(cfg.depth_scale)
         print(f"Using depth scale = {scale} (depth assumed metric, as D2R:555-558)")
-        boot = FusionContext(w, h, cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.min_depth, cfg.max_depth, n_slots=n, grid=None,
-                             device=cfg.device)
+        # one context: every frame is uploaded once and stays resident in HBM through registration, bounding and fusion
+        # (288 GB holds ~19 000 frames of 1080x1920 depth+colour); the grid is attached once the scene bounds are known
+        ctx = FusionContext(w, h, cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.min_depth, cfg.max_depth, n_slots=n, grid=None,
+                            device=cfg.device)
         try:
-            for i in range(n):
-                if self.depths[i].shape != (h, w):
-                    raise ValueError(f"frame {i} is {self.depths[i].shape}, expected {(h, w)}")
-                boot.upload(i, self.depths[i], self.images[i])
+            if streaming:
+                pre = fileio.FramePrefetcher(ctx, [f for f, _ in self._files], [d for _, d in self._files])
+                try:
+                    for _i, _slot in pre:
+                        pass
+                finally:
+                    pre.close()
+            else:
+                for i in range(n):
+                    if self.depths[i].shape != (h, w):
+                        raise ValueError(f"frame {i} is {self.depths[i].shape}, expected {(h, w)}")
+                    ctx.upload(i, self.depths[i], self.images[i])
             if poses is not None:
                 self.camera_poses, self.frame_index = list(poses), list(range(len(poses)))
             else:
                 print("\n--- Step 1: Register frames (point-to-plane ICP, frame to frame) ---")
-                self.camera_poses, self.frame_index = self._register(boot, scale, init_poses)
+                self.camera_poses, self.frame_index = self._register(ctx, scale, init_poses)
             if len(self.camera_poses) < 2:
                 print("Pose estimation failed")
                 return None, None, None
@@ -173,7 +209,7 @@ class DepthToReconstructionPipeline:
                 print("\n--- Step 2: Bound the scene ---")
                 mn, mx = np.full(3, np.inf), np.full(3, -np.inf)
                 for pose, fi in zip(self.camera_poses, self.frame_index):
-                    pts, _ = boot.backproject(fi, pose=pose, scale=scale, subsample=cfg.subsample_factor)
+                    pts, _ = ctx.backproject(fi, pose=pose, scale=scale, subsample=cfg.subsample_factor)
                     if len(pts):
                         mn, mx = np.minimum(mn, pts.min(0)), np.maximum(mx, pts.max(0))
                 if not np.all(np.isfinite(mn)):
@@ -184,20 +220,12 @@ class DepthToReconstructionPipeline:
                     print(f"  Warning: scene extent {np.round(mx - mn, 3)} m exceeds {cfg.grid_dim} voxels of {cfg.voxel_size} m; "
                           "points outside the grid are dropped")
             print(f"  Grid {grid.dims} @ {grid.voxel_size * 1e3:g} mm, origin {np.round(grid.origin, 4)}")
-        except Exception:
-            boot.close()
-            raise
-        # fuse: a second context that shares nothing but the frames (re-uploaded slot by slot: HBM is plentiful, the
-        # registration context is released first)
-        boot.close()
-        print("\n--- Step 3: Fuse depth frames (TSDF + voxel centroids) ---")
-        with FusionContext(w, h, cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.min_depth, cfg.max_depth, n_slots=2, grid=grid,
-                           device=cfg.device) as ctx:
-            for k, (pose, fi) in enumerate(zip(self.camera_poses, self.frame_index)):
-                ctx.upload(k & 1, self.depths[fi], self.images[fi])
+            ctx.attach_grid(grid)
+            print("\n--- Step 3: Fuse depth frames (TSDF + voxel centroids) ---")
+            for pose, fi in zip(self.camera_poses, self.frame_index):
                 if grid.channels & abi.CH_TSDF:
-                    ctx.integrate(k & 1, pose, scale=scale)
-                ctx.accumulate_centroid(k & 1, pose, scale=scale, subsample=cfg.subsample_factor)
+                    ctx.integrate(fi, pose, scale=scale)
+                ctx.accumulate_centroid(fi, pose, scale=scale, subsample=cfg.subsample_factor)
                 print(f"Camera {fi}: fused")
             st = ctx.stats()
             print("\n--- Step 4: Extract and clean point cloud ---")
@@ -209,6 +237,8 @@ class DepthToReconstructionPipeline:
                 xyz, rgb = xyz[keep], rgb[keep]
             self.stats = dict(points_accumulated=st["centroid_points"], points_dropped=st["centroid_dropped"],
                               voxels=n_vox, after_outlier_filter=len(xyz))
+        finally:
+            ctx.close()
         print(f"\nFinal reconstruction: {len(xyz)} points, {len(self.camera_poses)} cameras")
         return xyz.astype(np.float64), rgb, self.camera_poses
 
