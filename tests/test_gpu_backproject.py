@@ -88,3 +88,34 @@ def test_empty_and_capacity():
             ctx.backproject(1)                          # bad slot
         with pytest.raises(tl3d.Tl3dError):
             ctx.integrate(0, (np.eye(3), np.zeros(3)))  # no grid channel
+
+
+def test_randomised_shapes_strides_and_limits_match_pinned_oracle():
+    """Ragged sizes (1xN, Nx1, odd, prime), every stride 1..5, D2R/DER limits, pose / no pose, f32 / fp64 scale: the HIP
+    path against oracle/ref_numpy.py, which is itself bit-checked against the reference's own outputs."""
+    rng = np.random.default_rng(2024)
+    shapes = [(1, 1), (1, 37), (41, 1), (2, 3), (17, 19), (61, 83), (97, 64), (128, 257)]
+    for case in range(40):
+        h, w = shapes[case % len(shapes)]
+        depth = (0.05 + 3.0 * rng.random((h, w))).astype(np.float32)
+        bad = rng.random((h, w))
+        depth[bad < 0.05] = 0.0
+        depth[(bad > 0.05) & (bad < 0.08)] = np.nan
+        depth[(bad > 0.08) & (bad < 0.10)] = np.inf
+        depth[(bad > 0.10) & (bad < 0.12)] = 120.0
+        color = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        K = dict(fx=float(rng.uniform(20, 900)), fy=float(rng.uniform(20, 900)), cx=float(rng.uniform(0, w)), cy=float(rng.uniform(0, h)))
+        sub = int(rng.integers(1, 6))
+        lim = (0.1, 50.0) if case % 2 else (0.1, 100.0)
+        pose = None if case % 5 == 0 else gi.pose(100 + case)
+        scale = [1.0, 0.37, np.float64(1.7), np.float64(1.0)][case % 4]
+        with tl3d.FusionContext(w, h, K["fx"], K["fy"], K["cx"], K["cy"], lim[0], lim[1], n_slots=1) as ctx:
+            ctx.upload(0, depth, color)
+            p, c = ctx.backproject(0, pose=pose, scale=float(scale), subsample=sub, scale_f64=isinstance(scale, np.float64))
+            p, c = p.copy(), c.copy()
+        rp, rc = rn.backproject(depth, color, K["fx"], K["fy"], K["cx"], K["cy"], pose=pose, scale=scale, subsample=sub,
+                                min_depth=lim[0], max_depth=lim[1])
+        assert len(p) == len(rp), (case, h, w, sub)
+        assert np.array_equal(c, rc)
+        if len(p):
+            assert ulp_diff(p, rp).max() <= 1, (case, ulp_diff(p, rp).max())

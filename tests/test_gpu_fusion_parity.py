@@ -243,3 +243,20 @@ def test_icp_lanes_match_blocking_calls():
             ctx.icp_collect(0)                       # nothing left to collect
     for a, b in zip(ref, got):
         assert np.array_equal(a["T"], b["T"]) and a["n_corr"] == b["n_corr"] and a["iters_run"] == b["iters_run"]
+
+
+def test_fusion_is_deterministic_and_order_free():
+    """Integer accumulators: the same frames give the same grids bit for bit on every run and in any order
+    (a float-atomics design would not), which is also what makes the multi-GPU merge exact."""
+    poses, frames = small_scene_frames(n=5, deg=7.0)
+    grids = []
+    for order in ([0, 1, 2, 3, 4], [0, 1, 2, 3, 4], [4, 2, 0, 3, 1]):
+        ctx, _ = make_pair(dims=(96, 96, 96), voxel=0.025, centre=(0.0, -0.2, 0.0), n_slots=5)
+        with ctx:
+            for i in order:
+                ctx.upload(i, *frames[i])
+                ctx.integrate(i, poses[i])
+                ctx.accumulate_centroid(i, poses[i], subsample=1 + (i & 1))
+            grids.append((ctx.download_grid(tl3d.CH_TSDF), ctx.download_grid(tl3d.CH_CENTROID)))
+    for t, c in grids[1:]:
+        assert np.array_equal(t, grids[0][0]) and np.array_equal(c, grids[0][1])
