@@ -33,6 +33,8 @@ def main(argv=None):
     parser.add_argument("--icp-stride", type=int, default=2)
     parser.add_argument("--icp-max-dist", type=float, default=0.05)
     parser.add_argument("--depth-scale", type=float, default=1.0, help="metric scale of the depth files")
+    parser.add_argument("--anchors", type=str, default=None,
+                        help=".npz of sparse metric anchors (p3_<i>: [n,3], p2_<i>: [n,2] per frame i) for relative depth")
     parser.add_argument("--tsdf-min-weight", type=int, default=0, help="> 0: keep only voxels the TSDF saw this often")
     parser.add_argument("--ascii", action="store_true", help="write the reference's ASCII fallback PLY instead of binary")
     parser.add_argument("--device", type=int, default=0)
@@ -52,7 +54,12 @@ def main(argv=None):
     if num_loaded < 2:
         print("Failed to load sufficient data")
         return 0
-    points, colors, poses = pipeline.reconstruct()
+    anchors = None
+    if args.anchors:
+        import numpy as np
+        z = np.load(args.anchors)
+        anchors = {int(k[3:]): (z[k], z["p2_" + k[3:]]) for k in z.files if k.startswith("p3_")}
+    points, colors, poses = pipeline.reconstruct(anchors=anchors)
     if points is not None and len(points) > 0:
         pipeline.save_reconstruction(points, colors, args.output, ascii=args.ascii)
         if not args.no_vis:

@@ -167,3 +167,27 @@ def test_prefetcher_ring_reuse_and_attach_grid():
             assert ctx.download_grid(tl3d.CH_TSDF)[:, 1].sum() > 0
             with pytest.raises(tl3d.Tl3dError):
                 ctx.attach_grid(tl3d.GridSpec.cube(64, 0.05))                                # already has one
+
+
+def test_relative_depth_with_sparse_anchors_recovers_the_metric_reconstruction():
+    """Row f3: depth maps in relative units plus a few metric anchors per view -> the reference's median-ratio / EMA scale
+    (D2R:297-326, 552-554, 650) feeds normals, ICP and fusion, and the result matches the metric-depth run."""
+    scene, poses, rel, frames = _sequence(n=6, kind="object")
+    cfg = ReconstructionConfig(**CAM, voxel_size=0.005, subsample_factor=2, grid_dim=1024, icp_iters=20, icp_stride=2)
+    true_scale = 1.6
+    rng = np.random.default_rng(5)
+    anchors, rel_depths = {}, []
+    for i, (d, c) in enumerate(frames):
+        rel_depths.append((d / np.float32(true_scale)).astype(np.float32))
+        px = rng.uniform([2, 2], [W - 3, H - 3], (60, 2))
+        z = np.array([d[int(p[1]), int(p[0])] for p in px], np.float64)
+        ok = z > 0
+        anchors[i] = (np.stack([0 * z, 0 * z, z], 1)[ok], px[ok])
+    pipe = DepthToReconstructionPipeline(cfg)
+    pipe.set_frames([c for d, c in frames], rel_depths)
+    pts, col, est = pipe.reconstruct(anchors=anchors)
+    assert np.allclose(pipe.scales, true_scale, rtol=1e-5)
+    for (r, t), (rg, tg) in zip(est, rel):
+        assert np.linalg.norm(r - rg) + np.linalg.norm(t - tg) < 3e-3
+    ref_p, _ = _reference_cpu_path(frames, rel, cfg)
+    assert rn.chamfer_mean(pts, ref_p) < 1e-3

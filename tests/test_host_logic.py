@@ -144,3 +144,28 @@ def test_synth_geometry_and_relative_pose():
     assert np.allclose(r_rel, np.eye(3)) and np.allclose(t_rel.ravel(), [-0.05, 0, 0])
     R, t = synth.look_at((0.3, -0.2, -1.0), (0.0, 0.0, 0.0))
     assert np.allclose(R @ R.T, np.eye(3)) and abs(np.linalg.det(R) - 1) < 1e-12 and np.allclose(R @ np.array([0.3, -0.2, -1.0]) + t.ravel(), 0)
+
+
+def test_scale_tracker_is_the_references_running_average(capsys):
+    """Row f3: first two views averaged (D2R:552-554), then 0.7/0.3 EMA (D2R:650); views without anchors keep the value."""
+    from tl3d.pipeline import ScaleTracker, per_frame_scales
+    tr = ScaleTracker()
+    assert tr.first_pair(2.0, 3.0) == 2.5
+    assert abs(tr.update(1.5) - (0.7 * 2.5 + 0.3 * 1.5)) < 1e-15
+    assert tr.update(None) == tr.history[-2]
+    # anchors -> estimate_scale (median ratio, D2R:297-326) per frame
+    rng = np.random.default_rng(1)
+    depths = [(1.0 + rng.random((30, 40))).astype(np.float32) for _ in range(4)]
+    true = [2.0, 2.2, 1.8, None]
+    anchors = {}
+    for i, s in enumerate(true):
+        if s is None:
+            continue
+        px = rng.uniform([0, 0], [39.9, 29.9], (25, 2))
+        z = np.array([depths[i][int(p[1]), int(p[0])] for p in px]) * s
+        anchors[i] = (np.stack([0 * z, 0 * z, z], 1), px)
+    got = per_frame_scales(depths, anchors)
+    capsys.readouterr()
+    assert abs(got[0] - 2.1) < 1e-6 and abs(got[1] - 2.1) < 1e-6            # (2.0 + 2.2) / 2
+    assert abs(got[2] - (0.7 * 2.1 + 0.3 * 1.8)) < 1e-6 and got[3] == got[2]
+    assert per_frame_scales(depths, None, default=1.25) == [1.25] * 4

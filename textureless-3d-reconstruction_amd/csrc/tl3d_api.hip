@@ -125,9 +125,19 @@ static int alloc_grid(tl3d_ctx *ctx, const tl3d_config *cfg) {
         {   // the prep kernels are short and latency-bound: give them dispatch priority over the streaming update
             int lo = 0, hi = 0;
             (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-            if (hipStreamCreateWithPriority(&ctx->prep_stream, hipStreamNonBlocking, hi) != hipSuccess) return set_err(TL3D_E_HIP, "stream create failed");
+            const char *ns = getenv("TL3D_PREP_STREAMS");
+            ctx->n_prep_streams = ns ? atoi(ns) : 2;
+            if (ctx->n_prep_streams < 1) ctx->n_prep_streams = 1;
+            if (ctx->n_prep_streams > 2) ctx->n_prep_streams = 2;
+            for (int q = 0; q < ctx->n_prep_streams; ++q)
+                if (!ctx->prep_stream[q] && hipStreamCreateWithPriority(&ctx->prep_stream[q], hipStreamNonBlocking, hi) != hipSuccess)
+                    return set_err(TL3D_E_HIP, "stream create failed");
         }
-        for (int b = 0; b < 2; ++b) {
+        const char *nb = getenv("TL3D_TSDF_NBUF");
+        ctx->tsdf_nbuf = nb ? atoi(nb) : 3;
+        if (ctx->tsdf_nbuf < 1) ctx->tsdf_nbuf = 1;
+        if (ctx->tsdf_nbuf > TL3D_TSDF_NBUF) ctx->tsdf_nbuf = TL3D_TSDF_NBUF;
+        for (int b = 0; b < ctx->tsdf_nbuf; ++b) {
             if (hipMalloc(&ctx->tsdf_scratch[b], tsdf_scratch_bytes(ctx->cam, g)) != hipSuccess) return set_err(TL3D_E_NOMEM, "TSDF scratch alloc failed");
             if (hipEventCreateWithFlags(&ctx->ev_prep[b], hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&ctx->ev_upd[b], hipEventDisableTiming) != hipSuccess)
@@ -244,13 +254,15 @@ int tl3d_destroy(tl3d_ctx *ctx) {
     if (ctx->own_tsdf && ctx->tsdf) (void)hipFree(ctx->tsdf);
     if (ctx->own_centroid && ctx->centroid) (void)hipFree(ctx->centroid);
     if (ctx->stage_u16) (void)hipFree(ctx->stage_u16);
-    if (ctx->prep_stream) (void)hipStreamSynchronize(ctx->prep_stream);
-    for (int b = 0; b < 2; ++b) {
+    for (int q = 0; q < 2; ++q)
+        if (ctx->prep_stream[q]) (void)hipStreamSynchronize(ctx->prep_stream[q]);
+    for (int b = 0; b < TL3D_TSDF_NBUF; ++b) {
         if (ctx->tsdf_scratch[b]) (void)hipFree(ctx->tsdf_scratch[b]);
         if (ctx->ev_prep[b]) (void)hipEventDestroy(ctx->ev_prep[b]);
         if (ctx->ev_upd[b]) (void)hipEventDestroy(ctx->ev_upd[b]);
     }
-    if (ctx->prep_stream) (void)hipStreamDestroy(ctx->prep_stream);
+    for (int q = 0; q < 2; ++q)
+        if (ctx->prep_stream[q]) (void)hipStreamDestroy(ctx->prep_stream[q]);
     if (ctx->block_counts) (void)hipFree(ctx->block_counts);
     if (ctx->block_offsets) (void)hipFree(ctx->block_offsets);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
@@ -284,7 +296,8 @@ int tl3d_destroy(tl3d_ctx *ctx) {
 int tl3d_sync(tl3d_ctx *ctx) {
     REQUIRE(ctx != nullptr, TL3D_E_INVALID, "null ctx");
     TL3D_HIP(hipSetDevice(ctx->device));
-    if (ctx->prep_stream) TL3D_HIP(hipStreamSynchronize(ctx->prep_stream));
+    for (int q = 0; q < 2; ++q)
+        if (ctx->prep_stream[q]) TL3D_HIP(hipStreamSynchronize(ctx->prep_stream[q]));
     for (int l = 0; l < TL3D_ICP_LANES; ++l)
         if (ctx->icp_lanes[l].stream) TL3D_HIP(hipStreamSynchronize(ctx->icp_lanes[l].stream));
     TL3D_HIP(hipStreamSynchronize(ctx->stream));
@@ -563,7 +576,9 @@ int tl3d_integrate(tl3d_ctx *ctx, int slot, const double R[9], const double t[3]
     const PoseF p = make_pose_f(R, t);
     const Frustum fr = make_frustum(ctx->cam);
     const float mind = (float)ctx->cfg.min_depth, maxd = (float)ctx->cfg.max_depth;
-    const int b = (int)(ctx->tsdf_seq++ & 1u);
+    const unsigned seq = ctx->tsdf_seq++;
+    const int b = (int)(seq % (unsigned)ctx->tsdf_nbuf);
+    hipStream_t ps = ctx->prep_stream[seq % (unsigned)ctx->n_prep_streams];
     Slot &sl = ctx->slots[slot];
     static const bool single = getenv("TL3D_SINGLE_STREAM") && atoi(getenv("TL3D_SINGLE_STREAM")) != 0;
     if (single) {
@@ -571,11 +586,11 @@ int tl3d_integrate(tl3d_ctx *ctx, int slot, const double R[9], const double t[3]
         if (rc) return rc;
     } else {
         // prep (tiles, classification) on the side stream: needs the slot's upload and a free scratch buffer
-        if (sl.ev_upload) TL3D_HIP(hipStreamWaitEvent(ctx->prep_stream, sl.ev_upload, 0));
-        if (ctx->upd_recorded[b]) TL3D_HIP(hipStreamWaitEvent(ctx->prep_stream, ctx->ev_upd[b], 0));
-        rc = launch_tsdf_prepare(ctx->prep_stream, ctx->cam, ctx->grid, p, fr, sl.depth, (float)scale, mind, maxd, ctx->tsdf_scratch[b]);
+        if (sl.ev_upload) TL3D_HIP(hipStreamWaitEvent(ps, sl.ev_upload, 0));
+        if (ctx->upd_recorded[b]) TL3D_HIP(hipStreamWaitEvent(ps, ctx->ev_upd[b], 0));
+        rc = launch_tsdf_prepare(ps, ctx->cam, ctx->grid, p, fr, sl.depth, (float)scale, mind, maxd, ctx->tsdf_scratch[b]);
         if (rc) return rc;
-        TL3D_HIP(hipEventRecord(ctx->ev_prep[b], ctx->prep_stream));
+        TL3D_HIP(hipEventRecord(ctx->ev_prep[b], ps));
         TL3D_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_prep[b], 0));
     }
     const int kt = ktimer_begin(ctx);                 // event pair around the dominant kernel only

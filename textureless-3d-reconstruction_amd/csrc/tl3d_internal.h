@@ -78,6 +78,8 @@ constexpr int ICP_SLAB = 32;     // doubles per block partial
 
 }  // namespace tl3d
 
+// prep of frame i+k may run while frame i updates: the period is max(update, (update + prep + 2 event hops) / NBUF)
+#define TL3D_TSDF_NBUF 4
 struct tl3d_ctx {
     tl3d_config cfg;
     int device;
@@ -94,11 +96,13 @@ struct tl3d_ctx {
     uint16_t *stage_u16;         // u16 depth staging
     // TSDF integration is double-buffered over two streams: the tile/pyramid/cull kernels of frame i+1 run on
     // prep_stream while the update kernel of frame i streams the grid on the main stream.
-    hipStream_t prep_stream;
-    void *tsdf_scratch[2];       // depth tiles + compact brick list, one per in-flight frame
-    hipEvent_t ev_prep[2];       // prep of the frame using scratch b is done (recorded on prep_stream)
-    hipEvent_t ev_upd[2];        // update of the frame using scratch b is done (recorded on the main stream)
-    bool upd_recorded[2];
+    hipStream_t prep_stream[2];  // consecutive frames alternate, so two prep chains are in flight
+    int n_prep_streams;
+    void *tsdf_scratch[TL3D_TSDF_NBUF];   // depth tiles + compact brick list, one per in-flight frame
+    hipEvent_t ev_prep[TL3D_TSDF_NBUF];   // prep of the frame using scratch b is done (recorded on prep_stream)
+    hipEvent_t ev_upd[TL3D_TSDF_NBUF];    // update of the frame using scratch b is done (recorded on the main stream)
+    bool upd_recorded[TL3D_TSDF_NBUF];
+    int tsdf_nbuf;                        // buffers in use (env TL3D_TSDF_NBUF, default 3)
     unsigned tsdf_seq;
     unsigned *block_counts;      // compaction counts
     unsigned long long *block_offsets;

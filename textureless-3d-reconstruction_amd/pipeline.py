@@ -47,6 +47,65 @@ def plan_grid(bounds_min, bounds_max, voxel_size, grid_dim, channels=abi.CH_TSDF
     return GridSpec(tuple(int(d) for d in dims), tuple(float(o) for o in origin), v, trunc_voxels * v, channels), clipped
 
 
+class ScaleTracker:
+    """The reference's depth-scale bookkeeping (row f3), with the anchor source left to the caller.
+
+    depth_to_reconstruction.py estimates, per view, the median of Z_anchor / depth[pixel] over sparse anchors
+    (estimate_scale, D2R:297-326), averages the first two views (D2R:552-554) and then runs
+    avg = 0.7 * avg + 0.3 * scale_i (D2R:650); views without enough anchors keep the running value (D2R:645-647).
+    In the reference the anchors are triangulated SIFT matches -- the SfM front end that ICP replaces here -- so
+    they are an input: any sparse metric source (fiducials, a laser range, an external SLAM map) can provide
+    {frame_index: (points3d [n,3], pixels [n,2])}.  Without anchors the depth is taken as metric (D2R:555-558)."""
+
+    def __init__(self, default: float = 1.0):
+        self.avg = float(default)
+        self.history = []
+
+    def first_pair(self, s0: float, s1: float) -> float:
+        self.avg = (s0 + s1) / 2
+        self.history = [self.avg, self.avg]
+        return self.avg
+
+    def update(self, scale_i=None) -> float:
+        if scale_i is not None:
+            self.avg = 0.7 * self.avg + 0.3 * scale_i
+        self.history.append(self.avg)
+        return self.avg
+
+
+def per_frame_scales(depths, anchors, default: float = 1.0, fetch=None):
+    """Scale of every frame from sparse anchors, exactly as the reference sequences it.  `fetch(i)` returns frame i's
+    depth map when `depths[i]` is not held on the host (streaming)."""
+    from .dense import estimate_scale_d2r
+    n = len(depths)
+    tr = ScaleTracker(default)
+    if not anchors:
+        return [float(default)] * n
+
+    def depth_of(i):
+        return depths[i] if depths[i] is not None else fetch(i)
+
+    def est(i):
+        if i not in anchors:
+            return None
+        p3, p2 = anchors[i]
+        if len(p3) < 3:
+            print("  Warning: Not enough valid points for scale, using previous")
+            return None
+        return estimate_scale_d2r(np.asarray(p3), np.asarray(p2), depth_of(i))
+
+    s0, s1 = est(0), est(1) if n > 1 else None
+    if s0 is not None and s1 is not None:
+        tr.first_pair(s0, s1)
+    else:
+        print("Warning: Not enough sparse points for scale estimation")
+        tr.history = [tr.avg, tr.avg]
+    print(f"Average scale: {tr.avg:.6f}")
+    for i in range(2, n):
+        tr.update(est(i))
+    return tr.history[:n]
+
+
 def align_grid_to_open3d(grid: GridSpec, min_bound) -> GridSpec:
     """Shift a grid by less than one voxel so its lattice coincides with Open3D's (voxel origin = min_bound - voxel/2,
     depth_to_reconstruction.py:410).  With the lattices in phase the fused centroids are the reference's centroids up
@@ -107,7 +166,7 @@ class DepthToReconstructionPipeline:
         return len(self.images)
 
     # ---- poses: ICP replaces detect_and_match / compute_pose ---------------------------------------
-    def _register(self, ctx: FusionContext, scale: float, init_poses=None):
+    def _register(self, ctx: FusionContext, scales, init_poses=None):
         """Frame-to-frame registration.  Consecutive pairs are independent, so they are enqueued on the library's ICP
         lanes in batches (each run is a latency-bound chain of small kernels; several chains fill the GPU) and collected
         in order.  A failed pair drops its frame (reference rule, D2R:598-615): the following pair is then re-registered
@@ -115,13 +174,15 @@ class DepthToReconstructionPipeline:
         cfg = self.config
         n = len(self.depths)
         lanes = abi.ICP_LANES
+        if not isinstance(scales, (list, tuple)):
+            scales = [float(scales)] * n
         kw = dict(iters=cfg.icp_iters, stride=cfg.icp_stride, max_dist=cfg.icp_max_dist, damping=cfg.icp_damping,
-                  scale_src=scale, eig_rel=cfg.icp_eig_rel)
+                  eig_rel=cfg.icp_eig_rel)
         poses = [(np.eye(3), np.zeros((3, 1)))]
         index = [0]
         prev = 0
         for i in range(n):
-            ctx.build_normals(i, scale=scale)
+            ctx.build_normals(i, scale=scales[i])
         T_guess = np.eye(4)
 
         def prior(a, b_):
@@ -139,14 +200,14 @@ class DepthToReconstructionPipeline:
             batch = list(range(i, min(n, i + lanes)))
             for lane, cur in enumerate(batch):
                 src = prev if cur == batch[0] else cur - 1
-                ctx.icp_enqueue(lane, src, cur, T_init=prior(src, cur), **kw)
+                ctx.icp_enqueue(lane, src, cur, T_init=prior(src, cur), scale_src=scales[src], **kw)
             results = [ctx.icp_collect(lane) for lane in range(len(batch))]
             for lane, cur in enumerate(batch):
                 print(f"\nProcessing image {cur}...")
                 res = results[lane]
                 src = prev if cur == batch[0] else cur - 1
                 if src != prev:                       # the frame this run started from was dropped: redo against `prev`
-                    res = ctx.icp(prev, cur, T_init=prior(prev, cur), **kw)
+                    res = ctx.icp(prev, cur, T_init=prior(prev, cur), scale_src=scales[prev], **kw)
                 self.icp_log.append(dict(frame=cur, against=prev, **{k: res[k] for k in ("fitness", "rmse", "n_corr", "iters_run", "status")}))
                 if res["status"] == 2 or res["n_corr"] < 8:
                     print(f"  Skipping - registration failed (correspondences: {res['n_corr']})")
@@ -162,11 +223,13 @@ class DepthToReconstructionPipeline:
         return poses, index
 
     # ---- reconstruct ---------------------------------------------------------------------------------
-    def reconstruct(self, grid: Optional[GridSpec] = None, init_poses=None, poses=None):
+    def reconstruct(self, grid: Optional[GridSpec] = None, init_poses=None, poses=None, anchors=None):
         """(points, colors, camera_poses) like D2R:479-671.
 
         grid: fix the fusion volume (else planned from the data with Open3D's voxel origin).
         init_poses: optional per-frame pose priors for ICP; poses: skip registration and fuse with these poses.
+        anchors: {frame: (points3d, pixels)} sparse metric anchors -> per-frame depth scale by the reference's rule
+        (ScaleTracker); default: config.depth_scale for every frame (metric depth).
         """
         if len(self.images) < 2:
             print("Need at least 2 images")
@@ -179,7 +242,8 @@ class DepthToReconstructionPipeline:
         h, w = self._frame_shape if streaming else self.depths[0].shape
         n = len(self.depths)
         scale = float(cfg.depth_scale)
-        print(f"Using depth scale = {scale} (depth assumed metric, as D2R:555-558)")
+        if not anchors:
+            print(f"Using depth scale = {scale} (depth assumed metric, as D2R:555-558)")
         # one context: every frame is uploaded once and stays resident in HBM through registration, bounding and fusion
         # (288 GB holds ~19 000 frames of 1080x1920 depth+colour); the grid is attached once the scene bounds are known
         ctx = FusionContext(w, h, cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.min_depth, cfg.max_depth, n_slots=n, grid=None,
@@ -197,11 +261,12 @@ class DepthToReconstructionPipeline:
                     if self.depths[i].shape != (h, w):
                         raise ValueError(f"frame {i} is {self.depths[i].shape}, expected {(h, w)}")
                     ctx.upload(i, self.depths[i], self.images[i])
+            self.scales = per_frame_scales(self.depths, anchors, default=scale, fetch=ctx.download_depth)
             if poses is not None:
                 self.camera_poses, self.frame_index = list(poses), list(range(len(poses)))
             else:
                 print("\n--- Step 1: Register frames (point-to-plane ICP, frame to frame) ---")
-                self.camera_poses, self.frame_index = self._register(ctx, scale, init_poses)
+                self.camera_poses, self.frame_index = self._register(ctx, self.scales, init_poses)
             if len(self.camera_poses) < 2:
                 print("Pose estimation failed")
                 return None, None, None
@@ -209,7 +274,7 @@ class DepthToReconstructionPipeline:
                 print("\n--- Step 2: Bound the scene ---")
                 mn, mx = np.full(3, np.inf), np.full(3, -np.inf)
                 for pose, fi in zip(self.camera_poses, self.frame_index):
-                    pts, _ = ctx.backproject(fi, pose=pose, scale=scale, subsample=cfg.subsample_factor)
+                    pts, _ = ctx.backproject(fi, pose=pose, scale=self.scales[fi], subsample=cfg.subsample_factor)
                     if len(pts):
                         mn, mx = np.minimum(mn, pts.min(0)), np.maximum(mx, pts.max(0))
                 if not np.all(np.isfinite(mn)):
@@ -224,8 +289,8 @@ class DepthToReconstructionPipeline:
             print("\n--- Step 3: Fuse depth frames (TSDF + voxel centroids) ---")
             for pose, fi in zip(self.camera_poses, self.frame_index):
                 if grid.channels & abi.CH_TSDF:
-                    ctx.integrate(fi, pose, scale=scale)
-                ctx.accumulate_centroid(fi, pose, scale=scale, subsample=cfg.subsample_factor)
+                    ctx.integrate(fi, pose, scale=self.scales[fi])
+                ctx.accumulate_centroid(fi, pose, scale=self.scales[fi], subsample=cfg.subsample_factor)
                 print(f"Camera {fi}: fused")
             st = ctx.stats()
             print("\n--- Step 4: Extract and clean point cloud ---")
