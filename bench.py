@@ -30,7 +30,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--frames-per-step", type=int, default=256)
+    ap.add_argument("--frames-per-step", type=int, default=512)
     ap.add_argument("--resident-frames", type=int, default=32, help="distinct synthetic frames kept in HBM per GPU")
     ap.add_argument("--grid", type=int, default=512)
     ap.add_argument("--voxel", type=float, default=0.005)
