@@ -260,3 +260,47 @@ def test_fusion_is_deterministic_and_order_free():
             grids.append((ctx.download_grid(tl3d.CH_TSDF), ctx.download_grid(tl3d.CH_CENTROID)))
     for t, c in grids[1:]:
         assert np.array_equal(t, grids[0][0]) and np.array_equal(c, grids[0][1])
+
+
+def test_checkpoint_resume_equals_uninterrupted_run():
+    """Grid state is plain integers: download -> new context -> upload -> keep fusing == never stopping (and == oracle)."""
+    poses, frames = small_scene_frames(n=4, deg=4.0)
+    ctx, orc = make_pair(dims=(64, 64, 64), voxel=0.04)
+    with ctx:
+        for i in range(2):
+            ctx.upload(i, *frames[i])
+            ctx.integrate(i, poses[i])
+            ctx.accumulate_centroid(i, poses[i])
+        ck_t, ck_c = ctx.download_grid(tl3d.CH_TSDF), ctx.download_grid(tl3d.CH_CENTROID)
+    ctx2, _ = make_pair(dims=(64, 64, 64), voxel=0.04)
+    with ctx2:
+        ctx2.upload_grid(tl3d.CH_TSDF, ck_t)
+        ctx2.upload_grid(tl3d.CH_CENTROID, ck_c)
+        for i in range(2, 4):
+            ctx2.upload(i, *frames[i])
+            ctx2.integrate(i, poses[i])
+            ctx2.accumulate_centroid(i, poses[i])
+        t, c = ctx2.download_grid(tl3d.CH_TSDF), ctx2.download_grid(tl3d.CH_CENTROID)
+    for (d, b), p in zip(frames, poses):
+        orc.tsdf_integrate(d, p[0], p[1])
+        orc.centroid_accumulate(d, b, p[0], p[1])
+    assert np.array_equal(t, orc.tsdf) and np.array_equal(c, orc.centroid)
+
+
+def test_point_list_accumulation_and_bounds_match_oracle():
+    """tl3d_accumulate_points / tl3d_points_bounds: the merge entry points on caller-supplied clouds (D2R:386-420)."""
+    rng = np.random.default_rng(11)
+    ctx, orc = make_pair(dims=(64, 64, 64), voxel=0.02, channels=tl3d.CH_CENTROID)
+    xyz = rng.uniform(-0.7, 0.7, (50000, 3)).astype(np.float32)        # some points fall outside the 1.28 m cube
+    xyz[:2000] = xyz[2000:4000]                                        # exact duplicates -> same voxel, same offsets
+    rgb = rng.integers(0, 256, (50000, 3), dtype=np.uint8)
+    with ctx:
+        ctx.accumulate_points(xyz, rgb)
+        ctx.accumulate_points(xyz[:0], rgb[:0])                        # empty list is a no-op
+        g = ctx.download_grid(tl3d.CH_CENTROID)
+        st = ctx.stats()
+        mn, mx = ctx.points_bounds(xyz)
+    orc.centroid_points(xyz, rgb)
+    assert np.array_equal(g, orc.centroid)
+    assert st["centroid_points"] == orc.n_acc.value and st["centroid_dropped"] == orc.n_drop.value > 0
+    assert np.array_equal(mn, xyz.min(0).astype(np.float64)) and np.array_equal(mx, xyz.max(0).astype(np.float64))
