@@ -30,12 +30,14 @@ namespace tl3d {
 
 struct TsdfConst {
     float mind, maxd, sc, wlim, hlim;
+    int xcd_group;
 };
 
 constexpr int TILE = 32;
 constexpr int TILE_SHIFT = 5;
 constexpr int MAX_LEVELS = 12;
 constexpr unsigned FREE_FLAG = 0x80000000u;
+constexpr unsigned XCD_GROUPS = 8;
 
 struct Pyramid {
     int nlev;
@@ -279,13 +281,27 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(Cam cam, Grid g, Po
     const unsigned nlist = nmixed + nfree;
     const unsigned nbricks = (unsigned)(g.nbx * g.nby * g.nbz);
     unsigned nread = 0, nwritten = 0;
-    for (unsigned li0 = blockIdx.x * 4; li0 < nlist; li0 += gridDim.x * 4) {
-        const unsigned li = li0 + wid;
-        if (li >= nlist) break;
+    // Blocks with the same blockIdx % 8 share an XCD and its L2 (a placement habit of the dispatcher: a speed choice, never
+    // a correctness one).  Each such group consumes one contiguous eighth of the list -- the classification emits bricks
+    // in grid order, so an eighth is a slab of the volume and its depth lookups stay in one region of the image.
+    const bool grouped = XCD_GROUPS > 1 && (gridDim.x % XCD_GROUPS) == 0 && c.xcd_group != 0;
+    const unsigned ngrp = grouped ? XCD_GROUPS : 1u;
+    const unsigned grp = grouped ? blockIdx.x % XCD_GROUPS : 0u, bi = grouped ? blockIdx.x / XCD_GROUPS : blockIdx.x;
+    // list positions: [0, npair) alternate MIXED / FREE, [npair, nlist) hold what is left of the larger class; every
+    // group takes its eighth of both regions, so all groups see the same MIXED : FREE ratio
+    const unsigned npair = 2u * min(nmixed, nfree);
+    const unsigned per_a = ((npair + ngrp - 1u) / ngrp + 1u) & ~1u;           // even: MIXED/FREE pairs stay together
+    const unsigned per_b = (nlist - npair + ngrp - 1u) / ngrp;
+    const unsigned a_beg = min(npair, grp * per_a), a_len = min(npair, a_beg + per_a) - a_beg;
+    const unsigned b_beg = min(nlist, npair + grp * per_b), b_len = min(nlist, b_beg + per_b) - b_beg;
+    const unsigned lstep = (gridDim.x / ngrp) * 4u;
+    for (unsigned t0 = bi * 4u; t0 < a_len + b_len; t0 += lstep) {
+        const unsigned t = t0 + wid;
+        if (t >= a_len + b_len) break;
+        const unsigned li = t < a_len ? a_beg + t : b_beg + (t - a_len);
         // MIXED entries sit at the front of the list, FREE entries at the back (filled downwards).  They are consumed
         // interleaved (even slots MIXED, odd slots FREE while both last): MIXED bricks are bound by the texture-address
         // path, FREE bricks by HBM, so mixing them on every CU overlaps the two instead of running them back to back.
-        const unsigned npair = 2u * min(nmixed, nfree);
         unsigned src;
         if (li < npair) src = (li & 1u) ? nbricks - 1u - (li >> 1) : (li >> 1);
         else if (nmixed > nfree) src = li - nfree;                                   // remaining MIXED entries
@@ -452,6 +468,8 @@ static TsdfConst make_const(const Cam &cam, float scale, float mind, float maxd)
     c.sc = scale;
     c.wlim = (float)cam.W - 0.5f;
     c.hlim = (float)cam.H - 0.5f;
+    static const int xg = getenv("TL3D_XCD_GROUP") ? atoi(getenv("TL3D_XCD_GROUP")) : 1;
+    c.xcd_group = xg;
     return c;
 }
 
