@@ -304,3 +304,26 @@ def test_point_list_accumulation_and_bounds_match_oracle():
     assert np.array_equal(g, orc.centroid)
     assert st["centroid_points"] == orc.n_acc.value and st["centroid_dropped"] == orc.n_drop.value > 0
     assert np.array_equal(mn, xyz.min(0).astype(np.float64)) and np.array_equal(mx, xyz.max(0).astype(np.float64))
+
+
+def test_deferred_update_batches_never_change_results():
+    """tl3d_integrate defers its update launches to batch boundaries; every consumer issues them first.  Odd frame counts,
+    slot re-use inside a batch (forces an early flush), interleaved centroid calls and a zero-copy torch view of the
+    grid all see exactly the oracle's grid."""
+    import torch
+    poses, frames = small_scene_frames(n=11, deg=3.0)
+    ctx, orc = make_pair(dims=(64, 64, 64), voxel=0.04, n_slots=3)
+    with ctx:
+        for i, ((d, b), p) in enumerate(zip(frames, poses)):
+            ctx.upload(i % 3, d, b)                     # slot re-used every 3 frames while updates may be pending
+            ctx.integrate(i % 3, p)
+            ctx.accumulate_centroid(i % 3, p)
+        view = ctx.grid_tensor(tl3d.CH_TSDF)            # issues the outstanding updates, then exposes the memory
+        torch.cuda.synchronize()
+        via_view = view.cpu().numpy().reshape(-1, 2)
+        t, c = ctx.download_grid(tl3d.CH_TSDF), ctx.download_grid(tl3d.CH_CENTROID)
+        assert ctx.stats()["tsdf_launches"] == 11
+    for (d, b), p in zip(frames, poses):
+        orc.tsdf_integrate(d, p[0], p[1])
+        orc.centroid_accumulate(d, b, p[0], p[1])
+    assert np.array_equal(t, orc.tsdf) and np.array_equal(c, orc.centroid) and np.array_equal(via_view, orc.tsdf)

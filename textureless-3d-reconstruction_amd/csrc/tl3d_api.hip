@@ -92,6 +92,13 @@ static int check_slot(tl3d_ctx *ctx, int slot, bool need_loaded) {
 }
 
 static int upload_impl(tl3d_ctx *ctx, int slot, const void *depth_hd, int depth_kind, const uint8_t *bgr_hd, bool wait);
+static int flush_updates(tl3d_ctx *ctx);
+// every call that reads or writes the TSDF grid, re-uses a frame slot, synchronises or time-stamps first issues the deferred updates
+#define FLUSH_UPDATES(ctx_)                      \
+    do {                                         \
+        const int rc_ = flush_updates(ctx_);     \
+        if (rc_) return rc_;                     \
+    } while (0)
 
 static int validate_grid(const tl3d_config *cfg) {
     REQUIRE((cfg->channels & ~(TL3D_CH_TSDF | TL3D_CH_CENTROID)) == 0 && cfg->channels != 0, TL3D_E_INVALID, "bad channel bits 0x%x", cfg->channels);
@@ -133,16 +140,16 @@ static int alloc_grid(tl3d_ctx *ctx, const tl3d_config *cfg) {
                 if (!ctx->prep_stream[q] && hipStreamCreateWithPriority(&ctx->prep_stream[q], hipStreamNonBlocking, hi) != hipSuccess)
                     return set_err(TL3D_E_HIP, "stream create failed");
         }
-        const char *nb = getenv("TL3D_TSDF_NBUF");
-        ctx->tsdf_nbuf = nb ? atoi(nb) : 3;
-        if (ctx->tsdf_nbuf < 1) ctx->tsdf_nbuf = 1;
-        if (ctx->tsdf_nbuf > TL3D_TSDF_NBUF) ctx->tsdf_nbuf = TL3D_TSDF_NBUF;
-        for (int b = 0; b < ctx->tsdf_nbuf; ++b) {
+        const char *nb = getenv("TL3D_TSDF_BATCH");
+        ctx->tsdf_batch = nb ? atoi(nb) : 8;
+        if (ctx->tsdf_batch < 1) ctx->tsdf_batch = 1;
+        if (ctx->tsdf_batch > TL3D_TSDF_MAXBATCH) ctx->tsdf_batch = TL3D_TSDF_MAXBATCH;
+        for (int b = 0; b < 2 * ctx->tsdf_batch; ++b) {
             if (hipMalloc(&ctx->tsdf_scratch[b], tsdf_scratch_bytes(ctx->cam, g)) != hipSuccess) return set_err(TL3D_E_NOMEM, "TSDF scratch alloc failed");
-            if (hipEventCreateWithFlags(&ctx->ev_prep[b], hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&ctx->ev_upd[b], hipEventDisableTiming) != hipSuccess)
-                return set_err(TL3D_E_HIP, "event create failed");
+            if (hipEventCreateWithFlags(&ctx->ev_prep[b], hipEventDisableTiming) != hipSuccess) return set_err(TL3D_E_HIP, "event create failed");
         }
+        for (int h = 0; h < 2; ++h)
+            if (hipEventCreateWithFlags(&ctx->ev_upd[h], hipEventDisableTiming) != hipSuccess) return set_err(TL3D_E_HIP, "event create failed");
     }
     if (cfg->channels & TL3D_CH_CENTROID) {
         if (cfg->ext_centroid) {
@@ -240,6 +247,7 @@ int tl3d_create(const tl3d_config *cfg, int device, tl3d_ctx **out) {
 int tl3d_destroy(tl3d_ctx *ctx) {
     if (!ctx) return TL3D_OK;
     (void)hipSetDevice(ctx->device);
+    (void)flush_updates(ctx);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->slots) {
         for (int i = 0; i < ctx->cfg.n_slots; ++i) {
@@ -259,7 +267,6 @@ int tl3d_destroy(tl3d_ctx *ctx) {
     for (int b = 0; b < TL3D_TSDF_NBUF; ++b) {
         if (ctx->tsdf_scratch[b]) (void)hipFree(ctx->tsdf_scratch[b]);
         if (ctx->ev_prep[b]) (void)hipEventDestroy(ctx->ev_prep[b]);
-        if (ctx->ev_upd[b]) (void)hipEventDestroy(ctx->ev_upd[b]);
     }
     for (int q = 0; q < 2; ++q)
         if (ctx->prep_stream[q]) (void)hipStreamDestroy(ctx->prep_stream[q]);
@@ -295,6 +302,7 @@ int tl3d_destroy(tl3d_ctx *ctx) {
 
 int tl3d_sync(tl3d_ctx *ctx) {
     REQUIRE(ctx != nullptr, TL3D_E_INVALID, "null ctx");
+    FLUSH_UPDATES(ctx);
     TL3D_HIP(hipSetDevice(ctx->device));
     for (int q = 0; q < 2; ++q)
         if (ctx->prep_stream[q]) TL3D_HIP(hipStreamSynchronize(ctx->prep_stream[q]));
@@ -316,6 +324,7 @@ static int upload_impl(tl3d_ctx *ctx, int slot, const void *depth_hd, int depth_
     if (rc) return rc;
     REQUIRE(depth_hd != nullptr, TL3D_E_INVALID, "null depth");
     REQUIRE(depth_kind == TL3D_DEPTH_F32_M || depth_kind == TL3D_DEPTH_U16_MM, TL3D_E_INVALID, "bad depth_kind %d", depth_kind);
+    FLUSH_UPDATES(ctx);
     TL3D_HIP(hipSetDevice(ctx->device));
     Slot &s = ctx->slots[slot];
     const size_t npx = (size_t)ctx->cam.W * ctx->cam.H;
@@ -567,6 +576,32 @@ static int ktimer_begin(tl3d_ctx *ctx) {
     return id;
 }
 
+// Launches the update kernels of the prepared frames, in call order: one wait per prep stream, the updates back to back,
+// one completion event for the half of the scratch buffers the batch used.
+static int flush_updates(tl3d_ctx *ctx) {
+    if (ctx->n_pend == 0) return TL3D_OK;
+    TL3D_HIP(hipSetDevice(ctx->device));
+    const float mind = (float)ctx->cfg.min_depth, maxd = (float)ctx->cfg.max_depth;
+    const int n = ctx->n_pend;
+    ctx->n_pend = 0;                                    // whatever happens below, the batch is consumed
+    // each prep stream is in order: waiting for the newest event of every stream covers the whole batch
+    for (int k = n - 1; k >= 0 && k >= n - ctx->n_prep_streams; --k)
+        TL3D_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_prep[ctx->pend[k].buf], 0));
+    int rc = TL3D_OK;
+    for (int k = 0; k < n && rc == TL3D_OK; ++k) {
+        const tl3d_ctx::PendingUpdate &u = ctx->pend[k];
+        const int kt = ktimer_begin(ctx);              // event pair around the dominant kernel only (profiling mode)
+        rc = launch_tsdf_update(ctx->stream, ctx->cam, ctx->grid, u.pose, ctx->slots[u.slot].depth, u.scale, mind, maxd, ctx->tsdf,
+                                ctx->tsdf_scratch[u.buf], ctx->d_counters, ctx->count_records);
+        if (kt >= 0) (void)hipEventRecord(ctx->ktimers[kt].b, ctx->stream);
+        if (rc == TL3D_OK) ctx->stats.tsdf_launches++;
+    }
+    const int half = (int)(ctx->tsdf_batch_no++ & 1u);
+    TL3D_HIP(hipEventRecord(ctx->ev_upd[half], ctx->stream));
+    ctx->upd_recorded[half] = true;
+    return rc;
+}
+
 int tl3d_integrate(tl3d_ctx *ctx, int slot, const double R[9], const double t[3], double scale) {
     int rc = check_slot(ctx, slot, true);
     if (rc) return rc;
@@ -576,31 +611,32 @@ int tl3d_integrate(tl3d_ctx *ctx, int slot, const double R[9], const double t[3]
     const PoseF p = make_pose_f(R, t);
     const Frustum fr = make_frustum(ctx->cam);
     const float mind = (float)ctx->cfg.min_depth, maxd = (float)ctx->cfg.max_depth;
-    const unsigned seq = ctx->tsdf_seq++;
-    const int b = (int)(seq % (unsigned)ctx->tsdf_nbuf);
-    hipStream_t ps = ctx->prep_stream[seq % (unsigned)ctx->n_prep_streams];
     Slot &sl = ctx->slots[slot];
     static const bool single = getenv("TL3D_SINGLE_STREAM") && atoi(getenv("TL3D_SINGLE_STREAM")) != 0;
-    if (single) {
-        rc = launch_tsdf_prepare(ctx->stream, ctx->cam, ctx->grid, p, fr, sl.depth, (float)scale, mind, maxd, ctx->tsdf_scratch[b]);
+    if (single) {                                       // everything in order on the caller's stream
+        rc = launch_tsdf_prepare(ctx->stream, ctx->cam, ctx->grid, p, fr, sl.depth, (float)scale, mind, maxd, ctx->tsdf_scratch[0]);
         if (rc) return rc;
-    } else {
-        // prep (tiles, classification) on the side stream: needs the slot's upload and a free scratch buffer
-        if (sl.ev_upload) TL3D_HIP(hipStreamWaitEvent(ps, sl.ev_upload, 0));
-        if (ctx->upd_recorded[b]) TL3D_HIP(hipStreamWaitEvent(ps, ctx->ev_upd[b], 0));
-        rc = launch_tsdf_prepare(ps, ctx->cam, ctx->grid, p, fr, sl.depth, (float)scale, mind, maxd, ctx->tsdf_scratch[b]);
+        const int kt = ktimer_begin(ctx);
+        rc = launch_tsdf_update(ctx->stream, ctx->cam, ctx->grid, p, sl.depth, (float)scale, mind, maxd, ctx->tsdf,
+                                ctx->tsdf_scratch[0], ctx->d_counters, ctx->count_records);
+        if (kt >= 0) (void)hipEventRecord(ctx->ktimers[kt].b, ctx->stream);
         if (rc) return rc;
-        TL3D_HIP(hipEventRecord(ctx->ev_prep[b], ps));
-        TL3D_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_prep[b], 0));
+        ctx->stats.tsdf_launches++;
+        return TL3D_OK;
     }
-    const int kt = ktimer_begin(ctx);                 // event pair around the dominant kernel only
-    rc = launch_tsdf_update(ctx->stream, ctx->cam, ctx->grid, p, sl.depth, (float)scale, mind, maxd, ctx->tsdf,
-                            ctx->tsdf_scratch[b], ctx->d_counters, ctx->count_records);
-    if (kt >= 0) (void)hipEventRecord(ctx->ktimers[kt].b, ctx->stream);
-    TL3D_HIP(hipEventRecord(ctx->ev_upd[b], ctx->stream));
-    ctx->upd_recorded[b] = true;
+    // prep (tiles, pyramid, classification) now, on a side stream: needs the slot's upload and a scratch buffer whose
+    // previous user (two batches ago) has been updated; the update launch itself waits for the batch to fill
+    const int half = (int)(ctx->tsdf_batch_no & 1u);
+    const int b = half * ctx->tsdf_batch + ctx->n_pend;
+    hipStream_t ps = ctx->prep_stream[ctx->tsdf_seq++ % (unsigned)ctx->n_prep_streams];
+    if (sl.ev_upload) TL3D_HIP(hipStreamWaitEvent(ps, sl.ev_upload, 0));
+    if (ctx->upd_recorded[half]) TL3D_HIP(hipStreamWaitEvent(ps, ctx->ev_upd[half], 0));
+    rc = launch_tsdf_prepare(ps, ctx->cam, ctx->grid, p, fr, sl.depth, (float)scale, mind, maxd, ctx->tsdf_scratch[b]);
     if (rc) return rc;
-    ctx->stats.tsdf_launches++;
+    TL3D_HIP(hipEventRecord(ctx->ev_prep[b], ps));
+    tl3d_ctx::PendingUpdate &u = ctx->pend[ctx->n_pend++];
+    u.slot = slot; u.buf = b; u.pose = p; u.scale = (float)scale;
+    if (ctx->n_pend >= ctx->tsdf_batch) return flush_updates(ctx);
     return TL3D_OK;
 }
 
@@ -763,6 +799,7 @@ static int grid_sel(tl3d_ctx *ctx, uint32_t channel, void **p, size_t *bytes) {
 
 int tl3d_grid_reset(tl3d_ctx *ctx) {
     REQUIRE(ctx != nullptr, TL3D_E_INVALID, "null ctx");
+    FLUSH_UPDATES(ctx);
     TL3D_HIP(hipSetDevice(ctx->device));
     if (ctx->tsdf) TL3D_HIP(hipMemsetAsync(ctx->tsdf, 0, ctx->nvox * sizeof(int2), ctx->stream));
     if (ctx->centroid) TL3D_HIP(hipMemsetAsync(ctx->centroid, 0, ctx->nvox * 32, ctx->stream));
@@ -771,6 +808,7 @@ int tl3d_grid_reset(tl3d_ctx *ctx) {
 
 int tl3d_grid_device_ptr(tl3d_ctx *ctx, uint32_t channel, void **ptr, size_t *bytes) {
     REQUIRE(ptr && bytes, TL3D_E_INVALID, "null out pointer");
+    if (ctx) FLUSH_UPDATES(ctx);
     return grid_sel(ctx, channel, ptr, bytes);
 }
 
@@ -779,6 +817,7 @@ int tl3d_grid_download(tl3d_ctx *ctx, uint32_t channel, void *out, size_t bytes)
     size_t nb;
     int rc = grid_sel(ctx, channel, &p, &nb);
     if (rc) return rc;
+    FLUSH_UPDATES(ctx);
     REQUIRE(out && bytes == nb, TL3D_E_INVALID, "buffer is %zu B, grid channel is %zu B", bytes, nb);
     TL3D_HIP(hipSetDevice(ctx->device));
     TL3D_HIP(hipMemcpyAsync(out, p, nb, hipMemcpyDefault, ctx->stream));
@@ -791,6 +830,7 @@ int tl3d_grid_upload(tl3d_ctx *ctx, uint32_t channel, const void *in, size_t byt
     size_t nb;
     int rc = grid_sel(ctx, channel, &p, &nb);
     if (rc) return rc;
+    FLUSH_UPDATES(ctx);
     REQUIRE(in && bytes == nb, TL3D_E_INVALID, "buffer is %zu B, grid channel is %zu B", bytes, nb);
     TL3D_HIP(hipSetDevice(ctx->device));
     TL3D_HIP(hipMemcpyAsync(p, in, nb, hipMemcpyDefault, ctx->stream));
@@ -803,6 +843,7 @@ int tl3d_grid_add(tl3d_ctx *ctx, uint32_t channel, const void *other, size_t byt
     size_t nb;
     int rc = grid_sel(ctx, channel, &p, &nb);
     if (rc) return rc;
+    FLUSH_UPDATES(ctx);
     REQUIRE(other && bytes == nb, TL3D_E_INVALID, "buffer is %zu B, grid channel is %zu B", bytes, nb);
     TL3D_HIP(hipSetDevice(ctx->device));
     const void *src = other;
@@ -831,6 +872,7 @@ int tl3d_extract(tl3d_ctx *ctx, int mode, int min_count, int min_weight, double 
     REQUIRE(mode == TL3D_EXTRACT_CENTROID || mode == TL3D_EXTRACT_TSDF, TL3D_E_INVALID, "bad mode %d", mode);
     if (mode == TL3D_EXTRACT_CENTROID) REQUIRE(ctx->centroid != nullptr, TL3D_E_STATE, "centroid channel not enabled");
     if (mode == TL3D_EXTRACT_TSDF) REQUIRE(ctx->tsdf != nullptr, TL3D_E_STATE, "TSDF channel not enabled");
+    FLUSH_UPDATES(ctx);
     TL3D_HIP(hipSetDevice(ctx->device));
     const int nblocks = (int)((ctx->nvox + EXTRACT_CHUNK - 1) / EXTRACT_CHUNK);
     int rc = ensure_scratch_blocks(ctx, (size_t)nblocks + 1);
@@ -907,6 +949,7 @@ int tl3d_statistical_outlier(tl3d_ctx *ctx, const float *xyz, int64_t n, int nb_
 // ------------------------------------------------------------------------------------------- measurement
 int tl3d_set_profile(tl3d_ctx *ctx, int count_records, int time_kernels) {
     REQUIRE(ctx != nullptr, TL3D_E_INVALID, "null ctx");
+    FLUSH_UPDATES(ctx);
     ctx->count_records = count_records != 0;
     ctx->time_kernels = time_kernels != 0;
     return TL3D_OK;
@@ -914,6 +957,7 @@ int tl3d_set_profile(tl3d_ctx *ctx, int count_records, int time_kernels) {
 
 int tl3d_get_stats(tl3d_ctx *ctx, tl3d_stats *out) {
     REQUIRE(ctx && out, TL3D_E_INVALID, "null argument");
+    FLUSH_UPDATES(ctx);
     TL3D_HIP(hipSetDevice(ctx->device));
     unsigned long long h[16];
     std::vector<unsigned long long> hc(256 * 8);
@@ -942,6 +986,7 @@ int tl3d_get_stats(tl3d_ctx *ctx, tl3d_stats *out) {
 
 int tl3d_reset_stats(tl3d_ctx *ctx) {
     REQUIRE(ctx != nullptr, TL3D_E_INVALID, "null ctx");
+    FLUSH_UPDATES(ctx);
     TL3D_HIP(hipSetDevice(ctx->device));
     TL3D_HIP(hipStreamSynchronize(ctx->stream));
     TL3D_HIP(hipMemsetAsync(ctx->d_counters, 0, 16 * sizeof(unsigned long long), ctx->stream));
@@ -953,6 +998,7 @@ int tl3d_reset_stats(tl3d_ctx *ctx) {
 
 int tl3d_event_record(tl3d_ctx *ctx, int which) {
     REQUIRE(ctx != nullptr && (which == 0 || which == 1), TL3D_E_INVALID, "bad argument");
+    FLUSH_UPDATES(ctx);
     TL3D_HIP(hipSetDevice(ctx->device));
     TL3D_HIP(hipEventRecord(ctx->ev[which], ctx->stream));
     return TL3D_OK;

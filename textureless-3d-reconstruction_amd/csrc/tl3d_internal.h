@@ -78,8 +78,11 @@ constexpr int ICP_SLAB = 32;     // doubles per block partial
 
 }  // namespace tl3d
 
-// prep of frame i+k may run while frame i updates: the period is max(update, (update + prep + 2 event hops) / NBUF)
-#define TL3D_TSDF_NBUF 4
+// TSDF updates are issued in batches of up to TL3D_TSDF_MAXBATCH frames: the prep chains run ahead on the side streams,
+// the main stream waits once per batch and then runs the updates back to back (a cross-stream hand-over costs ~10 us,
+// about a fifth of an update).  Two halves of scratch buffers alternate between consecutive batches.
+#define TL3D_TSDF_MAXBATCH 8
+#define TL3D_TSDF_NBUF (2 * TL3D_TSDF_MAXBATCH)
 struct tl3d_ctx {
     tl3d_config cfg;
     int device;
@@ -98,12 +101,14 @@ struct tl3d_ctx {
     // prep_stream while the update kernel of frame i streams the grid on the main stream.
     hipStream_t prep_stream[2];  // consecutive frames alternate, so two prep chains are in flight
     int n_prep_streams;
-    void *tsdf_scratch[TL3D_TSDF_NBUF];   // depth tiles + compact brick list, one per in-flight frame
-    hipEvent_t ev_prep[TL3D_TSDF_NBUF];   // prep of the frame using scratch b is done (recorded on prep_stream)
-    hipEvent_t ev_upd[TL3D_TSDF_NBUF];    // update of the frame using scratch b is done (recorded on the main stream)
-    bool upd_recorded[TL3D_TSDF_NBUF];
-    int tsdf_nbuf;                        // buffers in use (env TL3D_TSDF_NBUF, default 3)
-    unsigned tsdf_seq;
+    void *tsdf_scratch[TL3D_TSDF_NBUF];   // depth tiles + compact brick list, one per frame of the two batches in flight
+    hipEvent_t ev_prep[TL3D_TSDF_NBUF];   // prep of the frame using scratch b is done (recorded on its prep stream)
+    hipEvent_t ev_upd[2];                 // all updates of the last batch that used half h are done (main stream)
+    bool upd_recorded[2];
+    int tsdf_batch;                       // frames per batch (env TL3D_TSDF_BATCH, default 8; 1 = no deferral)
+    unsigned tsdf_seq, tsdf_batch_no;
+    struct PendingUpdate { int slot, buf; tl3d::PoseF pose; float scale; } pend[TL3D_TSDF_MAXBATCH];
+    int n_pend;                           // prepared frames whose update launch is deferred to the batch boundary
     unsigned *block_counts;      // compaction counts
     unsigned long long *block_offsets;
     size_t scratch_blocks;
