@@ -132,7 +132,7 @@ struct tl3d_ctx {
     bool count_records, time_kernels;
     hipEvent_t ev[2];
     hipEvent_t kev0, kev1;
-    struct KTimer { hipEvent_t a, b; };
+    struct KTimer { hipEvent_t a, b; int launches; };   // one event pair around `launches` back-to-back update kernels
     KTimer *ktimers;
     int n_ktimers, ktimers_used;
 };

@@ -48,7 +48,7 @@ for k in sorted(agg):
     for c in sorted(agg[k]):
         print(f"    {c:36s} {agg[k][c] / max(1, cnt[k][c]):18.1f}  (n={cnt[k][c]})")
 
-key = [k for k in agg if "tsdf_integrate_kernel<false, 0>" in k]
+key = [k for k in agg if "tsdf_integrate_kernel<false, 0" in k]      # production variant (any lane map)
 if key and "FETCH_SIZE" in agg[key[0]] and "WRITE_SIZE" in agg[key[0]]:
     k = key[0]
     fetch_kb = agg[k]["FETCH_SIZE"] / cnt[k]["FETCH_SIZE"]
