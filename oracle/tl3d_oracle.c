@@ -453,33 +453,49 @@ static int solve6(const double a21[21], const double b[6], double damping, doubl
         A[i][i] += lam;
         for (int j = 0; j < 6; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
     }
+    /* Cyclic Jacobi in round-robin order: a sweep is 5 rounds of 3 rotations on disjoint index pairs.  The three
+     * angles of a round are taken from the same matrix, then all column rotations are applied, then all row rotations
+     * (disjoint pairs commute, so this is the sequential sweep up to rounding) -- the order the device's wave executes
+     * in parallel.  A sweep starts only while an off-diagonal entry is still > 1e-15 * trace. */
+    static const int RR[5][3][2] = {{{0, 5}, {1, 4}, {2, 3}}, {{0, 4}, {3, 5}, {1, 2}}, {{0, 3}, {2, 4}, {1, 5}},
+                                    {{0, 2}, {1, 3}, {4, 5}}, {{0, 1}, {2, 5}, {3, 4}}};
     for (int sweep = 0; sweep < 12; ++sweep) {
-        double offmax = 0.0;                      /* largest pivot met in this sweep: stop once it is negligible */
-        for (int p = 0; p < 5; ++p)
-            for (int q = p + 1; q < 6; ++q) {
-                const double apq = A[p][q];
-                if (fabs(apq) > offmax) offmax = fabs(apq);
-                if (fabs(apq) < 1e-300) continue;
-                const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
+        double offmax = 0.0;
+        for (int i = 0; i < 6; ++i)
+            for (int k = 0; k < 6; ++k)
+                if (k != i && fabs(A[i][k]) > offmax) offmax = fabs(A[i][k]);
+        if (!(offmax > 1e-15 * tr)) break;
+        for (int r = 0; r < 5; ++r) {
+            double c[3], sn[3];
+            for (int u = 0; u < 3; ++u) {
+                const int pp = RR[r][u][0], q = RR[r][u][1];
+                const double apq = A[pp][q];
+                if (fabs(apq) < 1e-300) { c[u] = 1.0; sn[u] = 0.0; continue; }
+                const double theta = (A[q][q] - A[pp][pp]) / (2.0 * apq);
                 const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+                c[u] = 1.0 / sqrt(t * t + 1.0);
+                sn[u] = t * c[u];
+            }
+            for (int u = 0; u < 3; ++u) {                       /* columns */
+                const int pp = RR[r][u][0], q = RR[r][u][1];
                 for (int k = 0; k < 6; ++k) {
-                    const double akp = A[k][p], akq = A[k][q];
-                    A[k][p] = c * akp - sn * akq;
-                    A[k][q] = sn * akp + c * akq;
-                }
-                for (int k = 0; k < 6; ++k) {
-                    const double apk = A[p][k], aqk = A[q][k];
-                    A[p][k] = c * apk - sn * aqk;
-                    A[q][k] = sn * apk + c * aqk;
-                }
-                for (int k = 0; k < 6; ++k) {
-                    const double vkp = V[k][p], vkq = V[k][q];
-                    V[k][p] = c * vkp - sn * vkq;
-                    V[k][q] = sn * vkp + c * vkq;
+                    const double akp = A[k][pp], akq = A[k][q];
+                    A[k][pp] = c[u] * akp - sn[u] * akq;
+                    A[k][q] = sn[u] * akp + c[u] * akq;
+                    const double vkp = V[k][pp], vkq = V[k][q];
+                    V[k][pp] = c[u] * vkp - sn[u] * vkq;
+                    V[k][q] = sn[u] * vkp + c[u] * vkq;
                 }
             }
-        if (!(offmax > 1e-15 * tr)) break;
+            for (int u = 0; u < 3; ++u) {                       /* rows */
+                const int pp = RR[r][u][0], q = RR[r][u][1];
+                for (int k = 0; k < 6; ++k) {
+                    const double apk = A[pp][k], aqk = A[q][k];
+                    A[pp][k] = c[u] * apk - sn[u] * aqk;
+                    A[q][k] = sn[u] * apk + c[u] * aqk;
+                }
+            }
+        }
     }
     double lmax = 0.0;
     for (int i = 0; i < 6; ++i) if (A[i][i] > lmax) lmax = A[i][i];

@@ -132,8 +132,8 @@ __global__ __launch_bounds__(256) void icp_reduce_kernel(Cam cam, const IcpRun *
 
 // Same algorithm and the same arithmetic order as oracle/tl3d_oracle.c: solve6 (cyclic Jacobi, 12 sweeps, relative
 // eigenvalue cutoff), spread over the lanes of one wave: lane k (< 6) keeps row k of A and row k of V in registers; a
-// rotation (p,q) reads its three pivots with wave shuffles, every lane rotates its own columns p,q, then lanes p and q
-// swap rows through shuffles.  All 64 lanes execute every shuffle (EXEC full); lanes >= 6 carry zeros.
+// sweep's rotations run three at a time on disjoint index pairs (see the loop), partners swap rows through shuffles.
+// All 64 lanes execute every shuffle (EXEC full); lanes >= 6 carry zeros.
 // Returns 0 on success; x[k] is valid on every lane (k < 6).
 __device__ __forceinline__ int solve6_wave(const double *__restrict__ a21, const double *__restrict__ b, double damping,
                                            double eig_rel, double x[6]) {
@@ -160,39 +160,65 @@ __device__ __forceinline__ int solve6_wave(const double *__restrict__ a21, const
         if (lane == j) a[j] += lam;
         v[j] = (lane == j) ? 1.0 : 0.0;
     }
+    // Round-robin order: a sweep is 5 rounds of 3 rotations on disjoint pairs (the oracle's RR table).  Lane i < 6 computes
+    // the angle of the pair it belongs to, so a round costs one chain of fp64 div/sqrt instead of three; the (c, s) of the
+    // three pairs are then broadcast, every lane rotates its row's columns, and partners exchange rows.
     for (int sweep = 0; sweep < 12; ++sweep) {
         double offmax = 0.0;
 #pragma unroll
-        for (int p = 0; p < 5; ++p)
+        for (int k = 0; k < 6; ++k)
+            if (k != lane && fabs(a[k]) > offmax) offmax = fabs(a[k]);          // lanes >= 6 hold zeros
 #pragma unroll
-            for (int q = p + 1; q < 6; ++q) {
-                const double apq = __shfl(a[q], p), app = __shfl(a[p], p), aqq = __shfl(a[q], q);
-                if (fabs(apq) > offmax) offmax = fabs(apq);
-                if (fabs(apq) < 1e-300) continue;                       // wave-uniform
+        for (int d = 1; d < 8; d <<= 1) offmax = fmax(offmax, __shfl_xor(offmax, d));
+        offmax = __shfl(offmax, 0);
+        if (!(offmax > 1e-15 * tr)) break;                          // wave-uniform; same rule as the oracle
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            // pairs of round r as compile-time constants
+            constexpr int RP[5][3] = {{0, 1, 2}, {0, 3, 1}, {0, 2, 1}, {0, 1, 4}, {0, 2, 3}};
+            constexpr int RQ[5][3] = {{5, 4, 3}, {4, 5, 2}, {3, 4, 5}, {2, 3, 5}, {1, 5, 4}};
+            int partner = lane;
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                if (lane == RP[r][u]) partner = RQ[r][u];
+                if (lane == RQ[r][u]) partner = RP[r][u];
+            }
+            const bool isp = lane < partner;
+            double my_diag = 0.0, my_off = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                if (k == lane) my_diag = a[k];
+                if (k == partner && partner != lane) my_off = a[k];
+            }
+            const double partner_diag = __shfl(my_diag, partner);
+            const double off_p = __shfl(my_off, partner);               // the lower lane's A[p][q] is the pivot for both
+            const double app = isp ? my_diag : partner_diag, aqq = isp ? partner_diag : my_diag;
+            const double apq = isp ? my_off : off_p;
+            double c = 1.0, sn = 0.0;
+            if (lane < 6 && !(fabs(apq) < 1e-300)) {
                 const double theta = (aqq - app) / (2.0 * apq);
                 const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
-                {   // columns p,q of every row
-                    const double akp = a[p], akq = a[q];
-                    a[p] = c * akp - sn * akq;
-                    a[q] = sn * akp + c * akq;
-                }
-                double rp[6], rq[6];                                    // rows p and q after the column step
-#pragma unroll
-                for (int k = 0; k < 6; ++k) { rp[k] = __shfl(a[k], p); rq[k] = __shfl(a[k], q); }
-#pragma unroll
-                for (int k = 0; k < 6; ++k) {
-                    const double np_ = c * rp[k] - sn * rq[k], nq_ = sn * rp[k] + c * rq[k];
-                    if (lane == p) a[k] = np_;
-                    if (lane == q) a[k] = nq_;
-                }
-                {
-                    const double vkp = v[p], vkq = v[q];
-                    v[p] = c * vkp - sn * vkq;
-                    v[q] = sn * vkp + c * vkq;
-                }
+                c = 1.0 / sqrt(t * t + 1.0);
+                sn = t * c;
             }
-        if (!(offmax > 1e-15 * tr)) break;                          // wave-uniform; same rule as the oracle
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {                               // columns of every row
+                const double cu = __shfl(c, RP[r][u]), su = __shfl(sn, RP[r][u]);
+                const double akp = a[RP[r][u]], akq = a[RQ[r][u]];
+                a[RP[r][u]] = cu * akp - su * akq;
+                a[RQ[r][u]] = su * akp + cu * akq;
+                const double vkp = v[RP[r][u]], vkq = v[RQ[r][u]];
+                v[RP[r][u]] = cu * vkp - su * vkq;
+                v[RQ[r][u]] = su * vkp + cu * vkq;
+            }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {                               // rows: partners exchange
+                const double other = __shfl(a[k], partner);
+                const double np_ = c * a[k] - sn * other;               // this lane is p: c*row_p - s*row_q
+                const double nq_ = sn * other + c * a[k];               // this lane is q: s*row_p + c*row_q
+                if (partner != lane) a[k] = isp ? np_ : nq_;
+            }
+        }
     }
     double lam_e[6], lmax = 0.0;
 #pragma unroll
