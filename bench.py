@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--height", type=int, default=1920)
     ap.add_argument("--centroid", action="store_true", help="also accumulate the voxel-centroid channel each frame")
     ap.add_argument("--icp", action="store_true", help="also run frame-to-frame ICP each frame (poses still analytic)")
+    ap.add_argument("--icp-iters", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="init torch.distributed (RCCL) even with one rank: exercises the merge path")
     ap.add_argument("--cpu-frames", type=int, default=4, help="distinct frames the CPU baseline cycles over")
@@ -100,18 +101,36 @@ def main():
         for i in range(n_res):
             ctx.build_normals(i)
 
+    T_rel = []
+    if args.icp:
+        for k in range(n_res):                       # analytic inter-frame motion as the ICP prior
+            r_rel, t_rel = synth.relative_pose(poses[(k - 1) % n_res], poses[k])
+            T0 = np.eye(4)
+            T0[:3, :3], T0[:3, 3] = r_rel, t_rel.ravel()
+            T_rel.append(T0)
+    LANES = tl3d.ICP_LANES
+
     def step(s):
-        for j in range(F):
-            k = (s * F + j) % n_res
+        # registration of group g+1 (half of the lanes) runs while group g is fused (the other half was collected before)
+        G = max(1, LANES // 2)
+        groups = [[(s * F + j) % n_res for j in range(j0, min(F, j0 + G))] for j0 in range(0, F, G)]
+
+        def enqueue(gi):
+            for i, k in enumerate(groups[gi]):
+                ctx.icp_enqueue((gi & 1) * G + i, (k - 1) % n_res, k, T_init=T_rel[k], iters=args.icp_iters, stride=4, max_dist=0.05)
+
+        if args.icp:
+            enqueue(0)
+        for gi, ks in enumerate(groups):
             if args.icp:
-                kp = (k - 1) % n_res
-                r_rel, t_rel = synth.relative_pose(poses[kp], poses[k])
-                T0 = np.eye(4)
-                T0[:3, :3], T0[:3, 3] = r_rel, t_rel.ravel()
-                ctx.icp(kp, k, T_init=T0, iters=5, stride=4, max_dist=0.05)
-            ctx.integrate(k, poses[k])
-            if args.centroid:
-                ctx.accumulate_centroid(k, poses[k], subsample=2)
+                if gi + 1 < len(groups):
+                    enqueue(gi + 1)
+                for i in range(len(ks)):
+                    ctx.icp_collect((gi & 1) * G + i)
+            for k in ks:
+                ctx.integrate(k, poses[k])
+                if args.centroid:
+                    ctx.accumulate_centroid(k, poses[k], subsample=2)
 
     def barrier():
         torch.cuda.synchronize(dev)

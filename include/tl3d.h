@@ -170,7 +170,7 @@ int tl3d_icp_p2plane(tl3d_ctx *ctx, int slot_src, double scale_src, int slot_tgt
 /* The same registration, asynchronous: one ICP run is a chain of short dependent kernels (latency-bound), but runs
  * for different frame pairs are independent, so up to TL3D_ICP_LANES of them may be in flight, each on its own
  * stream.  enqueue returns at once; collect blocks for that lane's result.  A lane holds one run at a time. */
-#define TL3D_ICP_LANES 8
+#define TL3D_ICP_LANES 16
 int tl3d_icp_enqueue(tl3d_ctx *ctx, int lane, int slot_src, double scale_src, int slot_tgt, const double T_init[16],
                      const tl3d_icp_params *prm);
 int tl3d_icp_collect(tl3d_ctx *ctx, int lane, tl3d_icp_result *out);

@@ -6,7 +6,7 @@ include/tl3d.h.  Import as `tl3d` (tl3d.py at the repo root maps the hyphenated 
 an importable package).
 """
 from . import _cabi  # noqa: F401
-from ._cabi import CH_CENTROID, CH_TSDF, EXTRACT_CENTROID, EXTRACT_TSDF, Tl3dError  # noqa: F401
+from ._cabi import CH_CENTROID, CH_TSDF, EXTRACT_CENTROID, EXTRACT_TSDF, ICP_LANES, Tl3dError  # noqa: F401
 from .fusion import FusionContext, GridSpec  # noqa: F401
 
 __all__ = ["FusionContext", "GridSpec", "Tl3dError", "CH_TSDF", "CH_CENTROID", "EXTRACT_CENTROID", "EXTRACT_TSDF"]

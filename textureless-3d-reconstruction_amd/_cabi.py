@@ -16,7 +16,7 @@ CH_TSDF, CH_CENTROID = 1, 2
 DEPTH_F32_M, DEPTH_U16_MM = 0, 1
 F_SCALE_F64, F_NO_POSE = 1, 2
 EXTRACT_CENTROID, EXTRACT_TSDF = 0, 1
-ICP_LANES = 8
+ICP_LANES = 16
 
 # every symbol include/tl3d.h declares (checked by tests/test_cabi_symbols.py against the header text)
 SYMBOLS = [
@@ -99,7 +99,7 @@ def load():
     # ICP lanes, the TSDF prep stream and the main stream want to run side by side; ROCm multiplexes streams onto
     # GPU_MAX_HW_QUEUES hardware queues (default 4).  Only a default: an explicit setting wins, and it has no effect if
     # the HIP runtime was already initialised by the host application.
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
     _preload_shared_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     lib.tl3d_last_error.restype = C.c_char_p

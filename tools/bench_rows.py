@@ -65,7 +65,7 @@ def icp(k, iters, stride):
 for iters, stride in ((10, 4), (10, 2), (10, 1)):
     timeit(f"ICP {iters} iters stride {stride} (incl. read-back)", lambda k: icp(k, iters, stride), 32,
            iters * (px / stride ** 2) * 20)
-def icp_lanes(k, iters, stride, lanes=8):
+def icp_lanes(k, iters, stride, lanes=tl3d.ICP_LANES):
     for l in range(lanes):
         a = (k * lanes + l) % (N - 1)
         r_rel, t_rel = synth.relative_pose(poses[a], poses[a + 1])
@@ -76,9 +76,9 @@ def icp_lanes(k, iters, stride, lanes=8):
 
 
 for iters, stride in ((10, 4), (10, 2)):
-    name = f"ICP x8 lanes, {iters} iters stride {stride} (8 pairs)"
-    timeit(name, lambda k: icp_lanes(k, iters, stride), 16, 8 * iters * (px / stride ** 2) * 20)
-    rows[name]["pairs_per_s"] = round(8 * rows[name]["per_s"], 1)
+    name = f"ICP x{tl3d.ICP_LANES} lanes, {iters} iters stride {stride} ({tl3d.ICP_LANES} pairs)"
+    timeit(name, lambda k: icp_lanes(k, iters, stride), 16, tl3d.ICP_LANES * iters * (px / stride ** 2) * 20)
+    rows[name]["pairs_per_s"] = round(tl3d.ICP_LANES * rows[name]["per_s"], 1)
     print(f"   -> {rows[name]['pairs_per_s']} pairs/s")
 res = icp(0, 10, 2)
 print("   ICP result: fitness %.3f rmse %.2e iters %d" % (res["fitness"], res["rmse"], res["iters_run"]))
