@@ -48,6 +48,11 @@ def parse():
 
 def main():
     args = parse()
+    # stdout carries exactly one line, the JSON; libraries that print banners with printf (RCCL at communicator creation)
+    # are sent to stderr at the file-descriptor level for the whole run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import numpy as np
     import torch
     import tl3d
@@ -247,7 +252,8 @@ def main():
                        "setup_s": round(t_gen, 1)},
             "roofline": roof, "cpu_baseline": cpu,
         }
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     ctx.close()
     if dist is not None:
         dist.barrier()
