@@ -327,3 +327,32 @@ def test_deferred_update_batches_never_change_results():
         orc.tsdf_integrate(d, p[0], p[1])
         orc.centroid_accumulate(d, b, p[0], p[1])
     assert np.array_equal(t, orc.tsdf) and np.array_equal(c, orc.centroid) and np.array_equal(via_view, orc.tsdf)
+
+
+def test_extract_size_query_is_reused_only_while_the_grid_is_untouched():
+    """tl3d_extract is called twice (size, then buffers); the second call skips the counting pass unless something touched
+    the grid or the shared scratch in between."""
+    import ctypes as C
+    from tl3d import _cabi as abi
+    poses, frames = small_scene_frames(n=2, deg=6.0)
+    ctx, orc = make_pair(dims=(64, 64, 64), voxel=0.04)
+    with ctx:
+        ctx.upload(0, *frames[0])
+        ctx.upload(1, *frames[1])
+        ctx.accumulate_centroid(0, poses[0])
+        n = C.c_int64(0)
+        abi.check(ctx._lib.tl3d_extract(ctx._h, 0, 1, 0, 1.0, None, None, 0, C.byref(n)))
+        n_first = n.value
+        a1, _ = ctx.extract()                                   # query + extraction back to back: counts reused
+        assert len(a1) == n_first
+        abi.check(ctx._lib.tl3d_extract(ctx._h, 0, 1, 0, 1.0, None, None, 0, C.byref(n)))       # query ...
+        ctx.accumulate_centroid(1, poses[1])                    # ... grid changes ...
+        ctx.backproject(0, pose=poses[0])                       # ... and the scratch is borrowed
+        cap = n.value + 200000
+        xyz, rgb = np.empty((cap, 3), np.float32), np.empty((cap, 3), np.uint8)
+        abi.check(ctx._lib.tl3d_extract(ctx._h, 0, 1, 0, 1.0, abi.ptr(xyz), abi.ptr(rgb), cap, C.byref(n)))
+    for (d, b), p in zip(frames, poses):
+        orc.centroid_accumulate(d, b, p[0], p[1])
+    ox, oc = orc.extract(0)
+    assert n.value == len(ox) > n_first
+    assert np.array_equal(xyz[:n.value], ox) and np.array_equal(rgb[:n.value], oc)

@@ -431,6 +431,7 @@ int tl3d_backproject(tl3d_ctx *ctx, int slot, const double R[9], const double t[
     const Slot &s = ctx->slots[slot];
     const long long ns = (long long)a.Ws * a.Hs;
     const int nblocks = (int)((ns + 255) / 256);
+    ctx->ext_valid = false;                             // the block-count scratch is shared with tl3d_extract
     rc = ensure_scratch_blocks(ctx, (size_t)nblocks + 1);
     if (rc) return rc;
     rc = launch_bp_count(ctx->stream, ctx->cam, a, s.depth, ctx->block_counts, nblocks);
@@ -478,6 +479,7 @@ int tl3d_accumulate_centroid(tl3d_ctx *ctx, int slot, const double R[9], const d
     TL3D_HIP(hipSetDevice(ctx->device));
     const Slot &s = ctx->slots[slot];
     const PoseD p = make_pose_d(R, t, (flags & TL3D_F_NO_POSE) != 0);
+    ctx->grid_epoch++;
     rc = launch_centroid_frame(ctx->stream, ctx->cam, ctx->grid, a, p, s.depth, s.has_color ? s.bgr : nullptr, ctx->centroid, ctx->d_cen_counters);
     if (rc) return rc;
     ctx->stats.centroid_launches++;
@@ -504,6 +506,7 @@ int tl3d_accumulate_points(tl3d_ctx *ctx, const float *xyz, const uint8_t *rgb, 
         dxyz = tx;
         drgb = tc;
     }
+    ctx->grid_epoch++;
     int rc = launch_centroid_points(ctx->stream, ctx->grid, dxyz, drgb, n, ctx->centroid, ctx->d_cen_counters);
     if (!direct) {
         hipError_t e = hipStreamSynchronize(ctx->stream);
@@ -580,6 +583,7 @@ static int ktimer_begin(tl3d_ctx *ctx) {
 // one completion event for the half of the scratch buffers the batch used.
 static int flush_updates(tl3d_ctx *ctx) {
     if (ctx->n_pend == 0) return TL3D_OK;
+    ctx->grid_epoch++;
     TL3D_HIP(hipSetDevice(ctx->device));
     const float mind = (float)ctx->cfg.min_depth, maxd = (float)ctx->cfg.max_depth;
     const int n = ctx->n_pend;
@@ -809,6 +813,7 @@ static int grid_sel(tl3d_ctx *ctx, uint32_t channel, void **p, size_t *bytes) {
 int tl3d_grid_reset(tl3d_ctx *ctx) {
     REQUIRE(ctx != nullptr, TL3D_E_INVALID, "null ctx");
     FLUSH_UPDATES(ctx);
+    ctx->grid_epoch++;
     TL3D_HIP(hipSetDevice(ctx->device));
     if (ctx->tsdf) TL3D_HIP(hipMemsetAsync(ctx->tsdf, 0, ctx->nvox * sizeof(int2), ctx->stream));
     if (ctx->centroid) TL3D_HIP(hipMemsetAsync(ctx->centroid, 0, ctx->nvox * 32, ctx->stream));
@@ -817,7 +822,10 @@ int tl3d_grid_reset(tl3d_ctx *ctx) {
 
 int tl3d_grid_device_ptr(tl3d_ctx *ctx, uint32_t channel, void **ptr, size_t *bytes) {
     REQUIRE(ptr && bytes, TL3D_E_INVALID, "null out pointer");
-    if (ctx) FLUSH_UPDATES(ctx);
+    if (ctx) {
+        FLUSH_UPDATES(ctx);
+        ctx->grid_epoch++;                  // the caller may write through the pointer (all-reduce)
+    }
     return grid_sel(ctx, channel, ptr, bytes);
 }
 
@@ -840,6 +848,7 @@ int tl3d_grid_upload(tl3d_ctx *ctx, uint32_t channel, const void *in, size_t byt
     int rc = grid_sel(ctx, channel, &p, &nb);
     if (rc) return rc;
     FLUSH_UPDATES(ctx);
+    ctx->grid_epoch++;
     REQUIRE(in && bytes == nb, TL3D_E_INVALID, "buffer is %zu B, grid channel is %zu B", bytes, nb);
     TL3D_HIP(hipSetDevice(ctx->device));
     TL3D_HIP(hipMemcpyAsync(p, in, nb, hipMemcpyDefault, ctx->stream));
@@ -853,6 +862,7 @@ int tl3d_grid_add(tl3d_ctx *ctx, uint32_t channel, const void *other, size_t byt
     int rc = grid_sel(ctx, channel, &p, &nb);
     if (rc) return rc;
     FLUSH_UPDATES(ctx);
+    ctx->grid_epoch++;
     REQUIRE(other && bytes == nb, TL3D_E_INVALID, "buffer is %zu B, grid channel is %zu B", bytes, nb);
     TL3D_HIP(hipSetDevice(ctx->device));
     const void *src = other;
@@ -886,13 +896,22 @@ int tl3d_extract(tl3d_ctx *ctx, int mode, int min_count, int min_weight, double 
     const int nblocks = (int)((ctx->nvox + EXTRACT_CHUNK - 1) / EXTRACT_CHUNK);
     int rc = ensure_scratch_blocks(ctx, (size_t)nblocks + 1);
     if (rc) return rc;
-    rc = launch_extract_count(ctx->stream, ctx->grid, mode, min_count, min_weight, max_abs_tsdf, ctx->tsdf, ctx->centroid, ctx->block_counts, nblocks);
-    if (rc) return rc;
-    rc = launch_scan(ctx->stream, ctx->block_counts, ctx->block_offsets, nblocks, ctx->block_offsets + nblocks);
-    if (rc) return rc;
     unsigned long long total = 0;
-    TL3D_HIP(hipMemcpyAsync(&total, ctx->block_offsets + nblocks, sizeof(total), hipMemcpyDeviceToHost, ctx->stream));
-    TL3D_HIP(hipStreamSynchronize(ctx->stream));
+    const bool reuse = ctx->ext_valid && ctx->ext_epoch == ctx->grid_epoch && ctx->ext_mode == mode && ctx->ext_min_count == min_count &&
+                       ctx->ext_min_weight == min_weight && ctx->ext_max_abs == max_abs_tsdf;
+    if (reuse) {                                        // the size query just before this call already counted and scanned
+        total = ctx->ext_total;
+    } else {
+        ctx->ext_valid = false;
+        rc = launch_extract_count(ctx->stream, ctx->grid, mode, min_count, min_weight, max_abs_tsdf, ctx->tsdf, ctx->centroid, ctx->block_counts, nblocks);
+        if (rc) return rc;
+        rc = launch_scan(ctx->stream, ctx->block_counts, ctx->block_offsets, nblocks, ctx->block_offsets + nblocks);
+        if (rc) return rc;
+        TL3D_HIP(hipMemcpyAsync(&total, ctx->block_offsets + nblocks, sizeof(total), hipMemcpyDeviceToHost, ctx->stream));
+        TL3D_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->ext_valid = true; ctx->ext_epoch = ctx->grid_epoch; ctx->ext_total = total;
+        ctx->ext_mode = mode; ctx->ext_min_count = min_count; ctx->ext_min_weight = min_weight; ctx->ext_max_abs = max_abs_tsdf;
+    }
     *out_n = (int64_t)total;
     if (!out_xyz || !out_rgb) return TL3D_OK;
     if ((int64_t)total > cap) return set_err(TL3D_E_CAPACITY, "need %llu points, capacity %lld", total, (long long)cap);

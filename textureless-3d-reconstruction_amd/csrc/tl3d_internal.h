@@ -109,6 +109,12 @@ struct tl3d_ctx {
     unsigned tsdf_seq, tsdf_batch_no;
     struct PendingUpdate { int slot, buf; tl3d::PoseF pose; float scale; } pend[TL3D_TSDF_MAXBATCH];
     int n_pend;                           // prepared frames whose update launch is deferred to the batch boundary
+    // extraction is called twice (size query, then with buffers): the block counts of the query are kept while nothing
+    // has touched the grids in between (every grid-modifying or pointer-exposing call bumps grid_epoch)
+    unsigned long long grid_epoch, ext_epoch, ext_total;
+    int ext_mode, ext_min_count, ext_min_weight;
+    double ext_max_abs;
+    bool ext_valid;
     unsigned *block_counts;      // compaction counts
     unsigned long long *block_offsets;
     size_t scratch_blocks;
