@@ -214,6 +214,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import c_oracle
+        c_oracle.Oracle.set_threads(c_oracle.usable_cpus())       # the box shows 256 CPUs and grants a quota of 16
         orc = c_oracle.Oracle(W, H, cam["fx"], cam["fy"], cam["cx"], cam["cy"], 0.1, 50.0, dims=spec.dims,
                               origin=spec.origin, voxel_size=spec.voxel_size, sdf_trunc=spec.sdf_trunc)
         orc.tsdf_integrate(host_keep[0][0], host_keep[0][1][0], host_keep[0][1][1])     # page in the 1 GiB grid

@@ -54,6 +54,24 @@ def lib():
     return _lib
 
 
+def usable_cpus() -> int:
+    """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota (containers show every core)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def _p(a, ty=C.c_void_p):
     return None if a is None else a.ctypes.data_as(ty)
 
@@ -82,6 +100,10 @@ class Oracle:
     @property
     def threads(self):
         return lib().orc_threads()
+
+    @staticmethod
+    def set_threads(n: int):
+        lib().orc_set_threads(C.c_int(int(n)))
 
     def _depth(self, depth):
         d = np.ascontiguousarray(depth, dtype=np.float32)

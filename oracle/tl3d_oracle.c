@@ -64,6 +64,15 @@ int orc_threads(void) {
 #endif
 }
 
+/* n > 0: number of OpenMP threads the parallel loops use from now on (the host may grant fewer CPUs than it shows) */
+void orc_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 /* brick-major record index: 8x8x8 voxels per brick, x fastest inside a brick and across bricks */
 static inline size_t vox_index(int i, int j, int k, int nbx, int nby) {
     size_t b = ((size_t)(k >> 3) * (size_t)nby + (size_t)(j >> 3)) * (size_t)nbx + (size_t)(i >> 3);
