@@ -16,3 +16,14 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _oracle_threads():
+    """The C oracle's OpenMP loops use the CPUs this container is actually granted (hosts show every core)."""
+    try:
+        from oracle import c_oracle
+        c_oracle.Oracle.set_threads(c_oracle.usable_cpus())
+    except Exception:       # the oracle library is built on first use by the tests that need it
+        pass
+    yield
