@@ -191,3 +191,31 @@ def test_relative_depth_with_sparse_anchors_recovers_the_metric_reconstruction()
         assert np.linalg.norm(r - rg) + np.linalg.norm(t - tg) < 3e-3
     ref_p, _ = _reference_cpu_path(frames, rel, cfg)
     assert rn.chamfer_mean(pts, ref_p) < 1e-3
+
+
+def test_coarse_to_fine_icp_registers_large_frame_steps():
+    """18-degree orbit steps (0.3 m between cameras), no motion prior: the default schedule (wide gate first) recovers
+    the analytic poses; the 5 cm gate alone does not (tools/icp_basin.py)."""
+    scene = synth.object_scene(with_room=True)
+    poses = synth.orbit_poses(5, 1.0, 18.0)
+    r0, t0 = poses[0]
+    rel = []
+    for r, t in poses:
+        rr = r @ r0.T
+        rel.append((rr, t.reshape(3, 1) - rr @ t0.reshape(3, 1)))
+    frames = [synth.render(scene, p, W, H, **CAM) for p in poses]
+
+    def run(**kw):
+        cfg = ReconstructionConfig(**CAM, voxel_size=0.01, subsample_factor=4, grid_dim=256, max_depth=6.0, **kw)
+        pipe = DepthToReconstructionPipeline(cfg)
+        pipe.set_frames([c for d, c in frames], [d for d, c in frames])
+        _, _, est = pipe.reconstruct()
+        return est
+
+    est = run()
+    assert len(est) == len(frames)
+    for (r, t), (rg, tg) in zip(est, rel):
+        assert np.linalg.norm(r - rg) + np.linalg.norm(t - tg) < 5e-3
+    est1 = run(icp_coarse=())
+    worst = max(np.linalg.norm(r - rg) + np.linalg.norm(t - tg) for (r, t), (rg, tg) in zip(est1, rel[:len(est1)]))
+    assert len(est1) < len(frames) or worst > 0.05

@@ -33,6 +33,7 @@ class ReconstructionConfig:
     # ---- additive: device fusion ------------------------------------------------------------------
     grid_dim: int = 512                 # voxels per axis of the dense grid (multiple of 8)
     sdf_trunc_voxels: float = 4.0       # TSDF truncation in voxels
+    icp_coarse: tuple = ((10, 4, 0.20),)   # levels before the final one: (iterations, pixel stride, gate in metres)
     icp_iters: int = 15
     icp_stride: int = 2
     icp_max_dist: float = 0.05

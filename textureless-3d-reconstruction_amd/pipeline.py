@@ -176,8 +176,23 @@ class DepthToReconstructionPipeline:
         lanes = abi.ICP_LANES
         if not isinstance(scales, (list, tuple)):
             scales = [float(scales)] * n
-        kw = dict(iters=cfg.icp_iters, stride=cfg.icp_stride, max_dist=cfg.icp_max_dist, damping=cfg.icp_damping,
-                  eig_rel=cfg.icp_eig_rel)
+        # coarse-to-fine: each level is (iterations, pixel stride, correspondence gate); every level starts from the
+        # previous level's pose.  A wide first gate takes frame steps of 0.5 m / 30 degrees that the 5 cm gate alone loses
+        # from 15 cm / 8 degrees on (tools/icp_basin.py); a level that has converged stops after one iteration.
+        levels = [tuple(l) for l in cfg.icp_coarse] + [(cfg.icp_iters, cfg.icp_stride, cfg.icp_max_dist)]
+        common = dict(damping=cfg.icp_damping, eig_rel=cfg.icp_eig_rel)
+
+        def level_kw(lv):
+            return dict(iters=int(lv[0]), stride=int(lv[1]), max_dist=float(lv[2]), **common)
+
+        def blocking(src, cur, T0):
+            res = None
+            for lv in levels:
+                res = ctx.icp(src, cur, T_init=T0, scale_src=scales[src], **level_kw(lv))
+                if res["status"] == 2 or res["n_corr"] < 8:
+                    break
+                T0 = res["T"]
+            return res
         poses = [(np.eye(3), np.zeros((3, 1)))]
         index = [0]
         prev = 0
@@ -198,16 +213,22 @@ class DepthToReconstructionPipeline:
         i = 1
         while i < n:
             batch = list(range(i, min(n, i + lanes)))
-            for lane, cur in enumerate(batch):
-                src = prev if cur == batch[0] else cur - 1
-                ctx.icp_enqueue(lane, src, cur, T_init=prior(src, cur), scale_src=scales[src], **kw)
-            results = [ctx.icp_collect(lane) for lane in range(len(batch))]
+            srcs = [prev if cur == batch[0] else cur - 1 for cur in batch]
+            T0s = [prior(src, cur) for src, cur in zip(srcs, batch)]
+            results = [None] * len(batch)
+            for li, lv in enumerate(levels):                    # all pairs of the batch advance level by level
+                live = [k for k in range(len(batch)) if li == 0 or not (results[k]["status"] == 2 or results[k]["n_corr"] < 8)]
+                for k in live:
+                    ctx.icp_enqueue(k, srcs[k], batch[k], T_init=T0s[k], scale_src=scales[srcs[k]], **level_kw(lv))
+                for k in live:
+                    results[k] = ctx.icp_collect(k)
+                    T0s[k] = results[k]["T"]
             for lane, cur in enumerate(batch):
                 print(f"\nProcessing image {cur}...")
                 res = results[lane]
                 src = prev if cur == batch[0] else cur - 1
                 if src != prev:                       # the frame this run started from was dropped: redo against `prev`
-                    res = ctx.icp(prev, cur, T_init=prior(prev, cur), scale_src=scales[prev], **kw)
+                    res = blocking(prev, cur, prior(prev, cur))
                 self.icp_log.append(dict(frame=cur, against=prev, **{k: res[k] for k in ("fitness", "rmse", "n_corr", "iters_run", "status")}))
                 if res["status"] == 2 or res["n_corr"] < 8:
                     print(f"  Skipping - registration failed (correspondences: {res['n_corr']})")
