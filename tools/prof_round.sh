@@ -21,6 +21,10 @@ for grp in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ
   timeout -k 5 120 rocprofv3 --pmc $grp --output-format csv -d "$OUT/pmc_$i" -- python3 bench.py "${PMC[@]}" > "$OUT/bench_pmc$i.log" 2>&1
   echo "rc=$?"
 done
+# calibration pass: FETCH_SIZE of the free-space bricks alone (16-B-per-lane reads are tallied at half their bytes)
+echo "[prof] pmc calibration pass: FETCH_SIZE, free-space bricks only"
+TL3D_DEBUG_ONLY=2 timeout -k 5 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_free" -- python3 bench.py "${PMC[@]}" > "$OUT/bench_pmc_free.log" 2>&1
+echo "rc=$?"
 python3 tools/prof_summary.py "$OUT" > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"
 # keep what is judged (stats csv, summary, traffic json, bench logs); drop the raw per-dispatch csvs (hundreds of MB)

@@ -53,18 +53,25 @@ if key and "FETCH_SIZE" in agg[key[0]] and "WRITE_SIZE" in agg[key[0]]:
     k = key[0]
     fetch_kb = agg[k]["FETCH_SIZE"] / cnt[k]["FETCH_SIZE"]
     write_kb = agg[k]["WRITE_SIZE"] / cnt[k]["WRITE_SIZE"]
-    traffic = (2.0 * fetch_kb + write_kb) * 1024.0
+    # FETCH_SIZE tallies 16-B-per-lane streaming reads (the free-space bricks) at half their bytes and this kernel's 8-B
+    # predicated loads and 4-B gathers at face value (calibrated: TL3D_DEBUG_ONLY=2 / =1 runs, see profiles/pmc_traffic.json);
+    # so the correction is one more copy of what the free-space bricks alone fetch (calibration pass pmc_free)
+    kfree = [q for q in agg if "tsdf_integrate_kernel<false, 2" in q and "FETCH_SIZE" in agg[q]]
+    fetch_free_kb = agg[kfree[0]]["FETCH_SIZE"] / cnt[kfree[0]]["FETCH_SIZE"] if kfree else None
+    traffic = ((fetch_kb + fetch_free_kb + write_kb) if fetch_free_kb is not None else (2.0 * fetch_kb + write_kb)) * 1024.0
     alg = None
     for f in glob.glob(os.path.join(out, "bench_pmc1.log")):
         for line in open(f):
             if line.startswith("{"):
                 alg = json.loads(line)["roofline"]["bytes_per_launch"]
     j = {"grid": 512, "width": 1080, "height": 1920, "kernel": "tsdf_integrate_kernel",
-         "fetch_size_kb": round(fetch_kb, 1), "write_size_kb": round(write_kb, 1),
+         "fetch_size_kb": round(fetch_kb, 1), "fetch_size_free_bricks_only_kb": None if fetch_free_kb is None else round(fetch_free_kb, 1),
+         "write_size_kb": round(write_kb, 1),
          "hbm_bytes_per_launch": int(traffic), "algorithmic_bytes_per_launch": alg,
-         "note": "traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE on gfx950 reports half the bytes of 16-B-per-lane "
-                 "streaming reads (MI355X_MICROARCH.md, HBM); the factor is exact for the FREE-brick stream and an upper "
-                 "bound for the predicated MIXED-brick loads and the 4-B depth gathers"}
+         "note": "traffic = (FETCH_SIZE + FETCH_SIZE of the free-space bricks alone + WRITE_SIZE) * 1024: FETCH_SIZE on gfx950 "
+                 "reports half the bytes of 16-B-per-lane streaming reads (MI355X_MICROARCH.md, HBM) -- the free-space bricks, "
+                 "calibrated x2.04 -- and this kernel's predicated 8-B loads and 4-B gathers at face value (calibrated x1.0); "
+                 "without the calibration pass the fallback is the upper bound 2*FETCH_SIZE + WRITE_SIZE"}
     with open(os.path.join(out, "pmc_traffic.json"), "w") as f:
         json.dump(j, f, indent=1)
     print("== traffic ==")
