@@ -44,7 +44,35 @@ __device__ __forceinline__ void record_half(int2 *__restrict__ grid, unsigned br
     for (int k = 0; k < 8; ++k) { r[k].x += q; r[k].y += 1; recs[k * 64 + lane] = r[k]; }
 }
 
+// 16-B-per-lane variant of the record half: 4 loads + 4 stores per brick
+__device__ __forceinline__ void record_half16(int2 *__restrict__ grid, unsigned brick, int lane, int q) {
+    int4 *recs = reinterpret_cast<int4 *>(grid + ((size_t)brick << 9));
+    int4 r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = recs[k * 64 + lane];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { r[k].x += q; r[k].y += 1; r[k].z += q; r[k].w += 1; recs[k * 64 + lane] = r[k]; }
+}
+
+// predicated variants: pred 1 = a pseudo-random half of the lanes of every instruction, pred 2 = half of the 64-B rows
+// (8 consecutive lanes) of every instruction, pred 3 = every other instruction entirely
+__device__ __forceinline__ void record_half_pred(int2 *__restrict__ grid, unsigned brick, int lane, int q, int pred) {
+    int2 *recs = grid + ((size_t)brick << 9);
+    int2 r[8];
+    bool on[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const unsigned h = (brick * 8u + (unsigned)k) * 2654435761u;
+        on[k] = pred == 1 ? (((h >> (lane & 31)) ^ (unsigned)lane) & 1u) != 0 : pred == 2 ? (((h >> (lane >> 3)) & 1u) != 0) : (k & 1) == 0;
+        if (on[k]) r[k] = recs[k * 64 + lane];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (on[k]) { r[k].x += q; r[k].y += 1; recs[k * 64 + lane] = r[k]; }
+}
+
 // mode 0: G, 1: R, 2: G then R per wave, 3: even waves G / odd waves R (each wave does twice as many bricks of its kind)
+// mode 4: R with 16 B per lane, 5/6/7: R with half the lanes / half the rows / half the instructions predicated off
 __global__ __launch_bounds__(256) void ub(const float *img, int2 *grid, const unsigned *bricks, unsigned nbricks, int mode, float spacing,
                                           float *sink) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -56,6 +84,12 @@ __global__ __launch_bounds__(256) void ub(const float *img, int2 *grid, const un
             if (mode != 1) g = gather_half(img, b, lane, spacing);
             if (mode != 0) record_half(grid, b, lane, mode == 2 ? (int)g & 7 : 3);
             acc += g;
+        }
+    } else if (mode >= 4) {
+        for (unsigned i = blockIdx.x * 4 + wid; i < nbricks; i += gridDim.x * 4) {
+            const unsigned b = bricks[i];
+            if (mode == 4) record_half16(grid, b, lane, 3);
+            else record_half_pred(grid, b, lane, 3, mode - 4);
         }
     } else {
         const bool is_g = (wid & 1) == 0;
@@ -80,10 +114,10 @@ int main() {
     for (unsigned i = 0; i < nb; ++i) { s = s * 1664525u + 1013904223u; hb[i] = (s >> 8) % 262144u; }
     CK(hipMemcpy(bricks, hb.data(), nb * 4, hipMemcpyHostToDevice));
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    const char *names[4] = {"G only", "R only", "G then R per wave", "G waves | R waves"};
-    for (int blocks : {512, 1024, 1536}) {
-        for (float spacing : {4.3f, 8.6f}) {
-            for (int mode = 0; mode < 4; ++mode) {
+    const char *names[8] = {"G only", "R only", "G then R per wave", "G waves | R waves", "R 16 B per lane", "R half the lanes", "R half the rows", "R half the instr."};
+    for (int blocks : {1024, 1536}) {
+        for (float spacing : {8.6f}) {
+            for (int mode = 0; mode < 8; ++mode) {
                 for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(ub, dim3(blocks), dim3(256), 0, 0, img, grid, bricks, nb, mode, spacing, sink);
                 CK(hipDeviceSynchronize());
                 const int reps = 20;
