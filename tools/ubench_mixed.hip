@@ -12,11 +12,13 @@
 
 constexpr int W = 1080, H = 1920;
 
-__device__ __forceinline__ float gather_half(const float *__restrict__ img, unsigned brick, int lane, float spacing) {
+__device__ __forceinline__ float gather_half(const float *__restrict__ img, unsigned brick, int lane, float spacing, bool swap = false) {
     // footprint origin from a hash of the brick id; lanes = 8 x 8 voxels, 8 layers along the image-vertical axis
     const unsigned h = brick * 2654435761u;
     const int u0 = (int)(h % (unsigned)(W - 96)), v0 = (int)((h >> 12) % (unsigned)(H - 96));
-    const int la = lane & 7, lb = lane >> 3;
+    // swap: the 8 lanes of a group walk along the view direction (sub-pixel parallax) and the groups across the image,
+    // so the 4 lanes the texture unit takes per step share a cache line
+    const int la = swap ? lane >> 3 : lane & 7, lb = swap ? lane & 7 : lane >> 3;
     float acc = 0.f;
     float d[8];
 #pragma unroll
@@ -85,6 +87,8 @@ __global__ __launch_bounds__(256) void ub(const float *img, int2 *grid, const un
             if (mode != 0) record_half(grid, b, lane, mode == 2 ? (int)g & 7 : 3);
             acc += g;
         }
+    } else if (mode == 8) {
+        for (unsigned i = blockIdx.x * 4 + wid; i < nbricks; i += gridDim.x * 4) acc += gather_half(img, bricks[i], lane, spacing, true);
     } else if (mode >= 4) {
         for (unsigned i = blockIdx.x * 4 + wid; i < nbricks; i += gridDim.x * 4) {
             const unsigned b = bricks[i];
@@ -114,10 +118,10 @@ int main() {
     for (unsigned i = 0; i < nb; ++i) { s = s * 1664525u + 1013904223u; hb[i] = (s >> 8) % 262144u; }
     CK(hipMemcpy(bricks, hb.data(), nb * 4, hipMemcpyHostToDevice));
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    const char *names[8] = {"G only", "R only", "G then R per wave", "G waves | R waves", "R 16 B per lane", "R half the lanes", "R half the rows", "R half the instr."};
-    for (int blocks : {1024, 1536}) {
-        for (float spacing : {8.6f}) {
-            for (int mode = 0; mode < 8; ++mode) {
+    const char *names[9] = {"G only", "R only", "G then R per wave", "G waves | R waves", "R 16 B per lane", "R half the lanes", "R half the rows", "R half the instr.", "G, depth-axis lanes adjacent"};
+    for (int blocks : {1024}) {
+        for (float spacing : {4.3f, 8.6f}) {
+            for (int mode = 0; mode < 9; ++mode) {
                 for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(ub, dim3(blocks), dim3(256), 0, 0, img, grid, bricks, nb, mode, spacing, sink);
                 CK(hipDeviceSynchronize());
                 const int reps = 20;
