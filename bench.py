@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--voxel", type=float, default=0.005)
     ap.add_argument("--width", type=int, default=1080)
     ap.add_argument("--height", type=int, default=1920)
+    ap.add_argument("--depth-format", choices=["u16", "f32"], default="u16",
+                    help="frames as 16-bit millimetres (the reference loader's PNG depth, D2R:85-90) or float32 metres (.npy)")
     ap.add_argument("--centroid", action="store_true", help="also accumulate the voxel-centroid channel each frame")
     ap.add_argument("--icp", action="store_true", help="also run frame-to-frame ICP each frame (poses still analytic)")
     ap.add_argument("--icp-iters", type=int, default=10)
@@ -95,10 +97,17 @@ def main():
     for i, p in enumerate(poses):
         d, c = synth.render(scene, p, W, H, cam["fx"], cam["fy"], cam["cx"], cam["cy"], xp=torch, device=dev)
         d, c = d.contiguous(), c.contiguous()
-        ctx.upload(i, d, c)
+        if args.depth_format == "u16":            # what a 16-bit PNG holds: round(metres * 1000), converted back by / 1000
+            mm = torch.clamp(torch.round(d * 1000.0), 0, 65535).to(torch.int32).to(torch.uint16).contiguous()
+            ctx.upload(i, mm, c)
+            d_host = (mm.cpu().numpy().astype(np.float32) / np.float32(1000.0)) if (rank == 0 and i < args.cpu_frames) else None
+            del mm
+        else:
+            ctx.upload(i, d, c)
+            d_host = d.cpu().numpy() if (rank == 0 and i < args.cpu_frames) else None
         stream.synchronize()                      # the tensors are freed right after: finish the copy first
-        if rank == 0 and i < args.cpu_frames:
-            host_keep.append((d.cpu().numpy(), p))
+        if d_host is not None:
+            host_keep.append((d_host, p))
         del d, c
     torch.cuda.synchronize(dev)
     t_gen = time.perf_counter() - t_gen
@@ -187,7 +196,8 @@ def main():
         st2 = ctx.stats()
         ctx.set_profile(False, False)
         k_ms = st2["tsdf_kernel_ms"] / max(1, st2["tsdf_kernel_timed"])
-        bytes_launch = 8.0 * rec_per_launch + 4.0 * H * W      # voxel records + the depth frame read once
+        depth_bpp = 2.0 if args.depth_format == "u16" else 4.0
+        bytes_launch = 8.0 * rec_per_launch + depth_bpp * H * W      # voxel records + the depth frame read once
         region_ms = dev_ms / launches
         # duration of the dominant kernel alone: hipEvent pairs recorded around every tsdf_integrate launch on the
         # launching stream, over a re-run of the same K steps (the timed region itself carries no extra events)
@@ -246,7 +256,9 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{W}x{H} ray-cast orbit (sphere-union object in a closed room, radius 1 m) "
                                    f"integrated into a {n}^3 TSDF @ {args.voxel * 1e3:g} mm, 8 B/voxel, "
-                                   f"1 frame per sweep; frames resident in HBM",
+                                   f"1 frame per sweep; frames resident in HBM as "
+                                   + ("16-bit millimetres (PNG depth)" if args.depth_format == "u16" else "float32 metres"),
+                       "depth_format": args.depth_format,
                        "frames_per_step_per_gpu": F, "resident_frames_per_gpu": n_res, "grid": n,
                        "voxel_m": args.voxel, "centroid_channel": bool(args.centroid), "icp_in_loop": bool(args.icp),
                        "parallelism": f"frame-shard x{world}" + (" + RCCL all-reduce of the grid" if world > 1 else ""),

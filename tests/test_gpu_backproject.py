@@ -119,3 +119,13 @@ def test_randomised_shapes_strides_and_limits_match_pinned_oracle():
         assert np.array_equal(c, rc)
         if len(p):
             assert ulp_diff(p, rp).max() <= 1, (case, ulp_diff(p, rp).max())
+
+
+def test_u16_millimetre_conversion_is_exact_for_every_value():
+    """uint16 mm -> float32 m on device == numpy's `.astype(float32) / 1000.0` (D2R:90) for all 65 536 inputs."""
+    import tl3d
+    mm = np.arange(65536, dtype=np.uint16).reshape(256, 256)
+    with tl3d.FusionContext(256, 256, 200.0, 200.0, 128.0, 128.0, n_slots=1) as ctx:
+        ctx.upload(0, mm, None)
+        got = ctx.download_depth(0)
+    assert np.array_equal(got, mm.astype(np.float32) / np.float32(1000.0))

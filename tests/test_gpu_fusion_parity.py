@@ -356,3 +356,30 @@ def test_extract_size_query_is_reused_only_while_the_grid_is_untouched():
     ox, oc = orc.extract(0)
     assert n.value == len(ox) > n_first
     assert np.array_equal(xyz[:n.value], ox) and np.array_equal(rgb[:n.value], oc)
+
+
+def test_tsdf_from_16bit_millimetre_frames_is_bit_exact():
+    """Frames uploaded as uint16 millimetres (the reference's 16-bit PNG depth, D2R:85-90): the TSDF kernels gather from
+    the 16-bit image and convert exactly as the upload conversion does, so the grid equals the oracle run
+    on the converted f32 frames -- for every lane mapping, with holes (0) and saturated pixels (65535)."""
+    from tl3d import synth
+    rng = np.random.default_rng(9)
+    cam = dict(width=200, height=152, fx=150.0, fy=160.0, cx=101.3, cy=70.7)
+    ctx, orc = make_pair(cam=cam, dims=(64, 48, 56), voxel=0.05, centre=(0.1, -0.1, 0.3), trunc=0.12, n_slots=2, max_depth=60.0)
+    scene = synth.object_scene(with_room=True)
+    views = [((1.0, -0.2, 0.3), (0, 0, 0), (0, 1, 0)), ((0.2, -0.3, -1.2), (0, 0, 0), (0, 1, 0)),
+             ((0.1, -1.1, 0.2), (0, 0, 0), (1, 0, 0)), ((0.9, -0.6, 0.7), (0.1, 0, 0), (0.3, 1, 0.2))]
+    with ctx:
+        for i, (eye, tgt, up) in enumerate(views):
+            pose = synth.look_at(np.array(eye), np.array(tgt), up=np.array(up, float))
+            depth, _ = synth.render(scene, pose, want_color=False, **cam)
+            mm = np.clip(np.rint(depth * 1000.0), 0, 65535).astype(np.uint16)
+            mm[rng.random(mm.shape) < 0.05] = 0
+            mm[10:14, 20:60] = 65535
+            ctx.upload(i & 1, mm, None)
+            assert np.array_equal(ctx.download_depth(i & 1), mm.astype(np.float32) / np.float32(1000.0))
+            ctx.integrate(i & 1, pose)
+            orc.tsdf_integrate(mm.astype(np.float32) / np.float32(1000.0), pose[0], pose[1])
+        g = ctx.download_grid(tl3d.CH_TSDF)
+    assert orc.tsdf[:, 1].sum() > 50000
+    assert np.array_equal(g, orc.tsdf)

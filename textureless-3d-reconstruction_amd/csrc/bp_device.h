@@ -6,6 +6,16 @@
 
 namespace tl3d {
 
+// uint16 millimetres -> float32 metres, bit-identical to numpy's `.astype(float32) / 1000.0` (D2R:90) for every uint16:
+// product with fl(1/1000), exact remainder, one correction (checked against exact rational arithmetic for all 65 536
+// inputs, and on the device by tests/test_gpu_backproject.py).  3 instructions instead of an IEEE division's ~10.
+__device__ __forceinline__ float mm_to_m(uint16_t v) {
+    const float f = (float)v;
+    const float q = f * 0.001f;
+    return fmaf(fmaf(-q, 1000.0f, f), 0.001f, q);
+}
+
+
 __device__ __forceinline__ bool bp_pixel(const Cam &cam, const BpArgs &a, const PoseD &p, const float *__restrict__ depth,
                                          int u, int v, float out[3]) {
     const float d32 = depth[(size_t)v * cam.W + u];

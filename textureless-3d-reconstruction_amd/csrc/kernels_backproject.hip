@@ -12,7 +12,7 @@ namespace tl3d {
 
 __global__ __launch_bounds__(256) void u16_to_f32_kernel(const uint16_t *__restrict__ in, float *__restrict__ out, size_t n) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) out[i] = (float)in[i] / 1000.0f;      // .astype(float32) / 1000.0 (D2R:90), IEEE f32 division
+    if (i < n) out[i] = mm_to_m(in[i]);              // == .astype(float32) / 1000.0 (D2R:90)
 }
 
 __global__ __launch_bounds__(256) void bp_count_kernel(Cam cam, BpArgs a, const float *__restrict__ depth,

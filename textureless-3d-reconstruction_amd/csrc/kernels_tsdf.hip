@@ -25,6 +25,7 @@
 #include <stdlib.h>
 
 #include "tl3d_internal.h"
+#include "bp_device.h"
 
 namespace tl3d {
 
@@ -46,8 +47,23 @@ struct Pyramid {
 
 // tile = (dmin, dmax, allvalid ? 1 : 0, unused)
 
+// Depth source of the TSDF kernels: the f32 frame, or the 16-bit millimetre image it was converted from (uploads of kind
+// TL3D_DEPTH_U16_MM keep it): same value through the same conversion as u16_to_f32_kernel (mm_to_m), half the bytes per pixel and
+// so half the cache lines under a brick's footprint (tools/ubench_mixed.hip: the gather half 17.9 -> 10.0 us).
+__device__ __forceinline__ float ld_depth(const float *__restrict__ p, size_t i) { return p[i]; }
+__device__ __forceinline__ float ld_depth(const uint16_t *__restrict__ p, size_t i) { return mm_to_m(p[i]); }
+__device__ __forceinline__ void ld_depth4(const float *__restrict__ p, size_t i, float dd[4]) {
+    const float4 t4 = *reinterpret_cast<const float4 *>(p + i);
+    dd[0] = t4.x; dd[1] = t4.y; dd[2] = t4.z; dd[3] = t4.w;
+}
+__device__ __forceinline__ void ld_depth4(const uint16_t *__restrict__ p, size_t i, float dd[4]) {
+    const ushort4 t4 = *reinterpret_cast<const ushort4 *>(p + i);
+    dd[0] = mm_to_m(t4.x); dd[1] = mm_to_m(t4.y); dd[2] = mm_to_m(t4.z); dd[3] = mm_to_m(t4.w);
+}
+
 // ---- 1. depth tiles --------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void depth_tiles_kernel(Cam cam, TsdfConst c, const float *__restrict__ depth, int ntx, int nty,
+template <typename DT>
+__global__ __launch_bounds__(256) void depth_tiles_kernel(Cam cam, TsdfConst c, const DT *__restrict__ depth, int ntx, int nty,
                                                           float4 *__restrict__ tiles, unsigned *__restrict__ list_counts) {
     __shared__ float smin[4], smax[4];
     __shared__ int sbad[4];
@@ -64,10 +80,9 @@ __global__ __launch_bounds__(256) void depth_tiles_kernel(Cam cam, TsdfConst c, 
             float dd[4];
             int nv = min(4, cam.W - u0);
             if (vec) {
-                const float4 t4 = *reinterpret_cast<const float4 *>(depth + (size_t)v * cam.W + u0);
-                dd[0] = t4.x; dd[1] = t4.y; dd[2] = t4.z; dd[3] = t4.w;
+                ld_depth4(depth, (size_t)v * cam.W + u0, dd);
             } else {
-                for (int k = 0; k < 4; ++k) dd[k] = (k < nv) ? depth[(size_t)v * cam.W + u0 + k] : 0.0f;
+                for (int k = 0; k < 4; ++k) dd[k] = (k < nv) ? ld_depth(depth, (size_t)v * cam.W + u0 + k) : 0.0f;
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -267,9 +282,9 @@ __device__ __forceinline__ bool tsdf_finish(const Grid &g, const TsdfConst &c, b
 //   MAP 1: lanes = (x, y), lane loop over z   records k*64 + lane          (512 B contiguous per instruction)
 //   MAP 2: lanes = (x, z), lane loop over y   records z*64 + k*8 + x       (8 segments of 64 B)
 //   MAP 0: lanes = (x pair, y, z pair), 16-B pairs -- the generic layout, used when x is the vertical axis
-template <bool COUNT, int DBG, int MAP>
+template <bool COUNT, int DBG, int MAP, typename DT>
 __global__ __launch_bounds__(256) void tsdf_integrate_kernel(Cam cam, Grid g, PoseF pose, TsdfConst c,
-                                                             const float *__restrict__ depth,
+                                                             const DT *__restrict__ depth,
                                                              const unsigned *__restrict__ list,
                                                              const unsigned *__restrict__ list_counts,
                                                              int2 *__restrict__ grid, unsigned long long *__restrict__ counters) {
@@ -344,7 +359,7 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(Cam cam, Grid g, Po
                     zc[2 * it + hh] = fmaf(pose.r[6], px, az);
                     int pix;
                     ok[2 * it + hh] = tsdf_project(cam, c, xc, yc, zc[2 * it + hh], pix);
-                    dv[2 * it + hh] = depth[pix];
+                    dv[2 * it + hh] = ld_depth(depth, (size_t)pix);
                 }
             }
             // phase 2: decide; phase 3: load the 16-B pairs that change; phase 4: add and store them
@@ -383,7 +398,7 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(Cam cam, Grid g, Po
                 zc[k] = fmaf(pose.r[6], px, fmaf(pose.r[7], py, fmaf(pose.r[8], pz, pose.t[2])));
                 int pix;
                 ok[k] = tsdf_project(cam, c, xc, yc, zc[k], pix);
-                dv[k] = (DBG == 3) ? 1.0f + 1e-6f * (float)(pix & 1023) : depth[pix];
+                dv[k] = (DBG == 3) ? 1.0f + 1e-6f * (float)(pix & 1023) : ld_depth(depth, (size_t)pix);
             }
             int q[8];
 #pragma unroll
@@ -474,13 +489,17 @@ static TsdfConst make_const(const Cam &cam, float scale, float mind, float maxd)
 }
 
 // depth tiles + pyramid + brick classification -> compact brick list in scratch
-int launch_tsdf_prepare(hipStream_t s, const Cam &cam, const Grid &g, const PoseF &p, const Frustum &fr, const float *depth,
+int launch_tsdf_prepare(hipStream_t s, const Cam &cam, const Grid &g, const PoseF &p, const Frustum &fr, const void *depth, bool depth_u16,
                         float scale, float mind, float maxd, void *scratch) {
     const TsdfConst c = make_const(cam, scale, mind, maxd);
     const TsdfScratch t = carve(cam, scratch);
     const int ntiles = t.py.ntx[0] * t.py.nty[0];
-    hipLaunchKernelGGL(depth_tiles_kernel, dim3(ntiles < 1024 ? ntiles : 1024), dim3(256), 0, s, cam, c, depth, t.py.ntx[0], t.py.nty[0],
-                       t.tiles, t.list_counts);
+    if (depth_u16)
+        hipLaunchKernelGGL(depth_tiles_kernel<uint16_t>, dim3(ntiles < 1024 ? ntiles : 1024), dim3(256), 0, s, cam, c,
+                           static_cast<const uint16_t *>(depth), t.py.ntx[0], t.py.nty[0], t.tiles, t.list_counts);
+    else
+        hipLaunchKernelGGL(depth_tiles_kernel<float>, dim3(ntiles < 1024 ? ntiles : 1024), dim3(256), 0, s, cam, c,
+                           static_cast<const float *>(depth), t.py.ntx[0], t.py.nty[0], t.tiles, t.list_counts);
     TL3D_HIP(hipGetLastError());
     if (t.py.nlev > 1) {
         hipLaunchKernelGGL(tile_pyramid_kernel, dim3(1), dim3(256), 0, s, t.py, t.tiles);
@@ -494,7 +513,7 @@ int launch_tsdf_prepare(hipStream_t s, const Cam &cam, const Grid &g, const Pose
 }
 
 // the dominant kernel: read-modify-write of the listed bricks
-int launch_tsdf_update(hipStream_t s, const Cam &cam, const Grid &g, const PoseF &p, const float *depth, float scale, float mind,
+int launch_tsdf_update(hipStream_t s, const Cam &cam, const Grid &g, const PoseF &p, const void *depth, bool depth_u16, float scale, float mind,
                        float maxd, int2 *grid, void *scratch, unsigned long long *counters, bool count) {
     const TsdfConst c = make_const(cam, scale, mind, maxd);
     const TsdfScratch t = carve(cam, scratch);
@@ -512,8 +531,14 @@ int launch_tsdf_update(hipStream_t s, const Cam &cam, const Grid &g, const PoseF
     int map = (ay >= ax && ay >= az) ? 2 : (az >= ax ? 1 : 0);
     if (force_map >= 0 && force_map <= 2) map = force_map;
 #define TL3D_LAUNCH_UPD(C_, D_, M_)                                                                                              \
-    hipLaunchKernelGGL((tsdf_integrate_kernel<C_, D_, M_>), dim3(nblk), dim3(256), 0, s, cam, g, p, c, depth, t.list, t.list_counts, \
-                       grid, counters)
+    do {                                                                                                                         \
+        if (depth_u16)                                                                                                           \
+            hipLaunchKernelGGL((tsdf_integrate_kernel<C_, D_, M_, uint16_t>), dim3(nblk), dim3(256), 0, s, cam, g, p, c,         \
+                               static_cast<const uint16_t *>(depth), t.list, t.list_counts, grid, counters);                      \
+        else                                                                                                                     \
+            hipLaunchKernelGGL((tsdf_integrate_kernel<C_, D_, M_, float>), dim3(nblk), dim3(256), 0, s, cam, g, p, c,            \
+                               static_cast<const float *>(depth), t.list, t.list_counts, grid, counters);                         \
+    } while (0)
 #define TL3D_LAUNCH_MAP(C_, D_)                        \
     do {                                               \
         if (map == 2) TL3D_LAUNCH_UPD(C_, D_, 2);      \

@@ -140,6 +140,7 @@ static int alloc_grid(tl3d_ctx *ctx, const tl3d_config *cfg) {
                 if (!ctx->prep_stream[q] && hipStreamCreateWithPriority(&ctx->prep_stream[q], hipStreamNonBlocking, hi) != hipSuccess)
                     return set_err(TL3D_E_HIP, "stream create failed");
         }
+        ctx->tsdf_use_u16 = !(getenv("TL3D_U16_GATHER") && atoi(getenv("TL3D_U16_GATHER")) == 0);
         const char *nb = getenv("TL3D_TSDF_BATCH");
         ctx->tsdf_batch = nb ? atoi(nb) : 8;
         if (ctx->tsdf_batch < 1) ctx->tsdf_batch = 1;
@@ -252,6 +253,7 @@ int tl3d_destroy(tl3d_ctx *ctx) {
     if (ctx->slots) {
         for (int i = 0; i < ctx->cfg.n_slots; ++i) {
             if (ctx->slots[i].depth) (void)hipFree(ctx->slots[i].depth);
+            if (ctx->slots[i].depth_u16) (void)hipFree(ctx->slots[i].depth_u16);
             if (ctx->slots[i].bgr) (void)hipFree(ctx->slots[i].bgr);
             if (ctx->slots[i].nmap) (void)hipFree(ctx->slots[i].nmap);
             if (ctx->slots[i].ev_upload) (void)hipEventDestroy(ctx->slots[i].ev_upload);
@@ -261,7 +263,6 @@ int tl3d_destroy(tl3d_ctx *ctx) {
     }
     if (ctx->own_tsdf && ctx->tsdf) (void)hipFree(ctx->tsdf);
     if (ctx->own_centroid && ctx->centroid) (void)hipFree(ctx->centroid);
-    if (ctx->stage_u16) (void)hipFree(ctx->stage_u16);
     for (int q = 0; q < 2; ++q)
         if (ctx->prep_stream[q]) (void)hipStreamSynchronize(ctx->prep_stream[q]);
     for (int b = 0; b < TL3D_TSDF_NBUF; ++b) {
@@ -331,11 +332,15 @@ static int upload_impl(tl3d_ctx *ctx, int slot, const void *depth_hd, int depth_
     if (!s.depth && hipMalloc(&s.depth, npx * sizeof(float)) != hipSuccess) return set_err(TL3D_E_NOMEM, "frame alloc failed");
     if (depth_kind == TL3D_DEPTH_F32_M) {
         TL3D_HIP(hipMemcpyAsync(s.depth, depth_hd, npx * sizeof(float), hipMemcpyDefault, ctx->stream));
+        s.has_u16 = false;
     } else {
-        if (!ctx->stage_u16 && hipMalloc(&ctx->stage_u16, npx * sizeof(uint16_t)) != hipSuccess) return set_err(TL3D_E_NOMEM, "staging alloc failed");
-        TL3D_HIP(hipMemcpyAsync(ctx->stage_u16, depth_hd, npx * sizeof(uint16_t), hipMemcpyDefault, ctx->stream));
-        rc = launch_u16_to_f32(ctx->stream, ctx->stage_u16, s.depth, npx);
+        // the millimetre image stays beside its f32 conversion: the TSDF kernels gather from it (half the cache lines
+        // under a brick's footprint) and convert with the same IEEE division, every other kernel reads the f32 copy
+        if (!s.depth_u16 && hipMalloc(&s.depth_u16, npx * sizeof(uint16_t)) != hipSuccess) return set_err(TL3D_E_NOMEM, "frame alloc failed");
+        TL3D_HIP(hipMemcpyAsync(s.depth_u16, depth_hd, npx * sizeof(uint16_t), hipMemcpyDefault, ctx->stream));
+        rc = launch_u16_to_f32(ctx->stream, s.depth_u16, s.depth, npx);
         if (rc) return rc;
+        s.has_u16 = true;
     }
     if (bgr_hd) {
         if (!s.bgr && hipMalloc(&s.bgr, npx * 3) != hipSuccess) return set_err(TL3D_E_NOMEM, "frame alloc failed");
@@ -598,7 +603,9 @@ static int flush_updates(tl3d_ctx *ctx) {
     int launched = 0;
     for (int k = 0; k < n && rc == TL3D_OK; ++k) {
         const tl3d_ctx::PendingUpdate &u = ctx->pend[k];
-        rc = launch_tsdf_update(ctx->stream, ctx->cam, ctx->grid, u.pose, ctx->slots[u.slot].depth, u.scale, mind, maxd, ctx->tsdf,
+        const Slot &us = ctx->slots[u.slot];
+        const bool u16 = us.has_u16 && ctx->tsdf_use_u16;
+        rc = launch_tsdf_update(ctx->stream, ctx->cam, ctx->grid, u.pose, u16 ? (const void *)us.depth_u16 : (const void *)us.depth, u16, u.scale, mind, maxd, ctx->tsdf,
                                 ctx->tsdf_scratch[u.buf], ctx->d_counters, ctx->count_records);
         if (rc == TL3D_OK) { ctx->stats.tsdf_launches++; ++launched; }
     }
@@ -622,12 +629,14 @@ int tl3d_integrate(tl3d_ctx *ctx, int slot, const double R[9], const double t[3]
     const Frustum fr = make_frustum(ctx->cam);
     const float mind = (float)ctx->cfg.min_depth, maxd = (float)ctx->cfg.max_depth;
     Slot &sl = ctx->slots[slot];
+    const bool u16 = sl.has_u16 && ctx->tsdf_use_u16;
+    const void *dptr = u16 ? (const void *)sl.depth_u16 : (const void *)sl.depth;
     static const bool single = getenv("TL3D_SINGLE_STREAM") && atoi(getenv("TL3D_SINGLE_STREAM")) != 0;
     if (single) {                                       // everything in order on the caller's stream
-        rc = launch_tsdf_prepare(ctx->stream, ctx->cam, ctx->grid, p, fr, sl.depth, (float)scale, mind, maxd, ctx->tsdf_scratch[0]);
+        rc = launch_tsdf_prepare(ctx->stream, ctx->cam, ctx->grid, p, fr, dptr, u16, (float)scale, mind, maxd, ctx->tsdf_scratch[0]);
         if (rc) return rc;
         const int kt = ktimer_begin(ctx);
-        rc = launch_tsdf_update(ctx->stream, ctx->cam, ctx->grid, p, sl.depth, (float)scale, mind, maxd, ctx->tsdf,
+        rc = launch_tsdf_update(ctx->stream, ctx->cam, ctx->grid, p, dptr, u16, (float)scale, mind, maxd, ctx->tsdf,
                                 ctx->tsdf_scratch[0], ctx->d_counters, ctx->count_records);
         if (kt >= 0) {
             ctx->ktimers[kt].launches = 1;
@@ -644,7 +653,7 @@ int tl3d_integrate(tl3d_ctx *ctx, int slot, const double R[9], const double t[3]
     hipStream_t ps = ctx->prep_stream[ctx->tsdf_seq++ % (unsigned)ctx->n_prep_streams];
     if (sl.ev_upload) TL3D_HIP(hipStreamWaitEvent(ps, sl.ev_upload, 0));
     if (ctx->upd_recorded[half]) TL3D_HIP(hipStreamWaitEvent(ps, ctx->ev_upd[half], 0));
-    rc = launch_tsdf_prepare(ps, ctx->cam, ctx->grid, p, fr, sl.depth, (float)scale, mind, maxd, ctx->tsdf_scratch[b]);
+    rc = launch_tsdf_prepare(ps, ctx->cam, ctx->grid, p, fr, dptr, u16, (float)scale, mind, maxd, ctx->tsdf_scratch[b]);
     if (rc) return rc;
     TL3D_HIP(hipEventRecord(ctx->ev_prep[b], ps));
     tl3d_ctx::PendingUpdate &u = ctx->pend[ctx->n_pend++];

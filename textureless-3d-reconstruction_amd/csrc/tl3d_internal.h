@@ -64,6 +64,8 @@ struct IcpRun {                  // per-run arguments of the ICP kernels, read f
 
 struct Slot {
     float *depth = nullptr;      // [H][W] f32
+    uint16_t *depth_u16 = nullptr;   // [H][W] millimetres, kept when the frame was uploaded as TL3D_DEPTH_U16_MM (TSDF gathers read it)
+    bool has_u16 = false;
     uint8_t *bgr = nullptr;      // [H][W][3]
     float4 *nmap = nullptr;      // [H][W] (nx,ny,nz,d), lazily allocated
     hipEvent_t ev_upload = nullptr;   // recorded on the main stream after the slot's last upload
@@ -96,7 +98,6 @@ struct tl3d_ctx {
     unsigned long long *centroid;// [nvox][4]
     bool own_tsdf, own_centroid;
     // scratch
-    uint16_t *stage_u16;         // u16 depth staging
     // TSDF integration is double-buffered over two streams: the tile/pyramid/cull kernels of frame i+1 run on
     // prep_stream while the update kernel of frame i streams the grid on the main stream.
     hipStream_t prep_stream[2];  // consecutive frames alternate, so two prep chains are in flight
@@ -105,6 +106,7 @@ struct tl3d_ctx {
     hipEvent_t ev_prep[TL3D_TSDF_NBUF];   // prep of the frame using scratch b is done (recorded on its prep stream)
     hipEvent_t ev_upd[2];                 // all updates of the last batch that used half h are done (main stream)
     bool upd_recorded[2];
+    bool tsdf_use_u16;                    // gather from the millimetre image when the slot has one (env TL3D_U16_GATHER=0: never)
     int tsdf_batch;                       // frames per batch (env TL3D_TSDF_BATCH, default 8; 1 = no deferral)
     unsigned tsdf_seq, tsdf_batch_no;
     struct PendingUpdate { int slot, buf; tl3d::PoseF pose; float scale; } pend[TL3D_TSDF_MAXBATCH];
@@ -178,9 +180,9 @@ int launch_centroid_points(hipStream_t s, const Grid &g, const float *xyz, const
 int launch_bounds(hipStream_t s, const float *xyz, long long n, float *slab, int nblocks);
 // tsdf
 size_t tsdf_scratch_bytes(const Cam &cam, const Grid &g);
-int launch_tsdf_prepare(hipStream_t s, const Cam &cam, const Grid &g, const PoseF &p, const Frustum &fr, const float *depth,
+int launch_tsdf_prepare(hipStream_t s, const Cam &cam, const Grid &g, const PoseF &p, const Frustum &fr, const void *depth, bool depth_u16,
                         float scale, float mind, float maxd, void *scratch);
-int launch_tsdf_update(hipStream_t s, const Cam &cam, const Grid &g, const PoseF &p, const float *depth, float scale, float mind,
+int launch_tsdf_update(hipStream_t s, const Cam &cam, const Grid &g, const PoseF &p, const void *depth, bool depth_u16, float scale, float mind,
                        float maxd, int2 *grid, void *scratch, unsigned long long *counters, bool count);
 // normals + icp
 int launch_normals(hipStream_t s, const Cam &cam, const float *depth, float scale, float mind, float maxd, float jump, float4 *nmap);

@@ -46,6 +46,29 @@ __device__ __forceinline__ void record_half(int2 *__restrict__ grid, unsigned br
     for (int k = 0; k < 8; ++k) { r[k].x += q; r[k].y += 1; recs[k * 64 + lane] = r[k]; }
 }
 
+// gather half reading a 16-bit (millimetre) depth image: half the bytes under the same footprint
+__device__ __forceinline__ float gather_half_u16(const unsigned short *__restrict__ img, unsigned brick, int lane, float spacing) {
+    const unsigned h = brick * 2654435761u;
+    const int u0 = (int)(h % (unsigned)(W - 96)), v0 = (int)((h >> 12) % (unsigned)(H - 96));
+    const int la = lane & 7, lb = lane >> 3;
+    float acc = 0.f;
+    float d[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int u = u0 + (int)(spacing * (float)la + 0.37f * (float)lb);
+        const int v = v0 + (int)(spacing * (float)k + 0.61f * (float)lb);
+        d[k] = (float)img[v * W + u] * 0.001f;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float x = d[k];
+#pragma unroll
+        for (int r = 0; r < 20; ++r) x = fmaf(x, 1.0001f, 0.5f) * 0.999f;
+        acc += x;
+    }
+    return acc;
+}
+
 // 16-B-per-lane variant of the record half: 4 loads + 4 stores per brick
 __device__ __forceinline__ void record_half16(int2 *__restrict__ grid, unsigned brick, int lane, int q) {
     int4 *recs = reinterpret_cast<int4 *>(grid + ((size_t)brick << 9));
@@ -87,6 +110,9 @@ __global__ __launch_bounds__(256) void ub(const float *img, int2 *grid, const un
             if (mode != 0) record_half(grid, b, lane, mode == 2 ? (int)g & 7 : 3);
             acc += g;
         }
+    } else if (mode == 9) {
+        for (unsigned i = blockIdx.x * 4 + wid; i < nbricks; i += gridDim.x * 4)
+            acc += gather_half_u16(reinterpret_cast<const unsigned short *>(img), bricks[i], lane, spacing);
     } else if (mode == 8) {
         for (unsigned i = blockIdx.x * 4 + wid; i < nbricks; i += gridDim.x * 4) acc += gather_half(img, bricks[i], lane, spacing, true);
     } else if (mode >= 4) {
@@ -118,10 +144,10 @@ int main() {
     for (unsigned i = 0; i < nb; ++i) { s = s * 1664525u + 1013904223u; hb[i] = (s >> 8) % 262144u; }
     CK(hipMemcpy(bricks, hb.data(), nb * 4, hipMemcpyHostToDevice));
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    const char *names[9] = {"G only", "R only", "G then R per wave", "G waves | R waves", "R 16 B per lane", "R half the lanes", "R half the rows", "R half the instr.", "G, depth-axis lanes adjacent"};
+    const char *names[10] = {"G only", "R only", "G then R per wave", "G waves | R waves", "R 16 B per lane", "R half the lanes", "R half the rows", "R half the instr.", "G, depth-axis lanes adjacent", "G, 16-bit depth image"};
     for (int blocks : {1024}) {
         for (float spacing : {4.3f, 8.6f}) {
-            for (int mode = 0; mode < 9; ++mode) {
+            for (int mode = 0; mode < 10; ++mode) {
                 for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(ub, dim3(blocks), dim3(256), 0, 0, img, grid, bricks, nb, mode, spacing, sink);
                 CK(hipDeviceSynchronize());
                 const int reps = 20;
