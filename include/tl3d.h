@@ -155,7 +155,7 @@ int tl3d_points_bounds(tl3d_ctx *ctx, const float *xyz_hd, int64_t n, double out
 
 /* a11: TSDF integration of one frame (no reference code; convention in DESIGN.md).
  * The frame's classification kernels are enqueued at once on side streams; its grid update is issued together with
- * those of the following calls (batches of 8 by default, TL3D_TSDF_BATCH) so that the main stream pays one cross-stream
+ * those of the following calls (batches of up to 32 by default, TL3D_TSDF_BATCH) so that the main stream pays one cross-stream
  * wait per batch.  Every other call that touches the grid or the slot, tl3d_sync, tl3d_event_record and
  * tl3d_grid_device_ptr issue the outstanding updates first, so results never depend on the batching; a caller that
  * works on a grid pointer obtained EARLIER must call tl3d_grid_device_ptr (or tl3d_sync) again before using it. */

@@ -142,7 +142,7 @@ static int alloc_grid(tl3d_ctx *ctx, const tl3d_config *cfg) {
         }
         ctx->tsdf_use_u16 = !(getenv("TL3D_U16_GATHER") && atoi(getenv("TL3D_U16_GATHER")) == 0);
         const char *nb = getenv("TL3D_TSDF_BATCH");
-        ctx->tsdf_batch = nb ? atoi(nb) : 8;
+        ctx->tsdf_batch = nb ? atoi(nb) : 32;
         if (ctx->tsdf_batch < 1) ctx->tsdf_batch = 1;
         if (ctx->tsdf_batch > TL3D_TSDF_MAXBATCH) ctx->tsdf_batch = TL3D_TSDF_MAXBATCH;
         for (int b = 0; b < 2 * ctx->tsdf_batch; ++b) {

@@ -83,7 +83,7 @@ constexpr int ICP_SLAB = 32;     // doubles per block partial
 // TSDF updates are issued in batches of up to TL3D_TSDF_MAXBATCH frames: the prep chains run ahead on the side streams,
 // the main stream waits once per batch and then runs the updates back to back (a cross-stream hand-over costs ~10 us,
 // about a fifth of an update).  Two halves of scratch buffers alternate between consecutive batches.
-#define TL3D_TSDF_MAXBATCH 8
+#define TL3D_TSDF_MAXBATCH 32
 #define TL3D_TSDF_NBUF (2 * TL3D_TSDF_MAXBATCH)
 struct tl3d_ctx {
     tl3d_config cfg;
@@ -107,7 +107,7 @@ struct tl3d_ctx {
     hipEvent_t ev_upd[2];                 // all updates of the last batch that used half h are done (main stream)
     bool upd_recorded[2];
     bool tsdf_use_u16;                    // gather from the millimetre image when the slot has one (env TL3D_U16_GATHER=0: never)
-    int tsdf_batch;                       // frames per batch (env TL3D_TSDF_BATCH, default 8; 1 = no deferral)
+    int tsdf_batch;                       // frames per batch (env TL3D_TSDF_BATCH, default 32; 1 = no deferral)
     unsigned tsdf_seq, tsdf_batch_no;
     struct PendingUpdate { int slot, buf; tl3d::PoseF pose; float scale; } pend[TL3D_TSDF_MAXBATCH];
     int n_pend;                           // prepared frames whose update launch is deferred to the batch boundary
