@@ -36,8 +36,9 @@ def parse():
     ap.add_argument("--voxel", type=float, default=0.005)
     ap.add_argument("--width", type=int, default=1080)
     ap.add_argument("--height", type=int, default=1920)
-    ap.add_argument("--depth-format", choices=["u16", "f32"], default="u16",
-                    help="frames as 16-bit millimetres (the reference loader's PNG depth, D2R:85-90) or float32 metres (.npy)")
+    ap.add_argument("--depth-format", choices=["f32", "u16"], default="f32",
+                    help="frames as float32 metres (BASELINE.md's headline input) or as 16-bit millimetres (the reference "
+                         "loader's PNG depth, D2R:85-90; the TSDF kernels then gather from the 16-bit image)")
     ap.add_argument("--centroid", action="store_true", help="also accumulate the voxel-centroid channel each frame")
     ap.add_argument("--icp", action="store_true", help="also run frame-to-frame ICP each frame (poses still analytic)")
     ap.add_argument("--icp-iters", type=int, default=10)

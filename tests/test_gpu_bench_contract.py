@@ -35,12 +35,14 @@ def test_bench_json_contract():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["achieved"] > 0
-    assert d["config"]["depth_format"] == "u16" and r["bytes_per_launch"] == 8 * r["records_per_launch"] + 2 * 270 * 480
+    assert d["config"]["depth_format"] == "f32" and r["bytes_per_launch"] == 8 * r["records_per_launch"] + 4 * 270 * 480
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert d["value"] > 0 and abs(d["ms_per_step"] - 1e3 * 4 / d["value"]) / d["ms_per_step"] < 0.05
 
 
 def test_single_rank_rccl_merge_rehearsal():
-    d = _run(["--force-dist", "--no-cpu-baseline", "--centroid"], env={"MASTER_PORT": "29541"})
-    assert d["value"] > 0 and d["config"]["centroid_channel"] is True
+    d = _run(["--force-dist", "--no-cpu-baseline", "--centroid", "--depth-format", "u16"], env={"MASTER_PORT": "29541"})
+    assert d["value"] > 0 and d["config"]["centroid_channel"] is True and d["config"]["depth_format"] == "u16"
+    r = d["roofline"]
+    assert r["bytes_per_launch"] == 8 * r["records_per_launch"] + 2 * 270 * 480
