@@ -38,6 +38,7 @@ class ReconstructionConfig:
     icp_stride: int = 2
     icp_max_dist: float = 0.05
     icp_damping: float = 1e-6
+    icp_eps: float = 1e-7               # a level stops once the largest component of its pose update is below this (rad / m)
     icp_eig_rel: float = 1e-4           # relative eigenvalue cutoff: unobservable DOFs keep the motion prior
     tsdf_min_weight: int = 0            # > 0: gate the emitted centroids by the TSDF (outlier suppression)
     tsdf_max_abs: float = 1.0

@@ -180,7 +180,7 @@ class DepthToReconstructionPipeline:
         # previous level's pose.  A wide first gate takes frame steps of 0.5 m / 30 degrees that the 5 cm gate alone loses
         # from 15 cm / 8 degrees on (tools/icp_basin.py); a level that has converged stops after one iteration.
         levels = [tuple(l) for l in cfg.icp_coarse] + [(cfg.icp_iters, cfg.icp_stride, cfg.icp_max_dist)]
-        common = dict(damping=cfg.icp_damping, eig_rel=cfg.icp_eig_rel)
+        common = dict(damping=cfg.icp_damping, eig_rel=cfg.icp_eig_rel, eps=cfg.icp_eps)
 
         def level_kw(lv):
             return dict(iters=int(lv[0]), stride=int(lv[1]), max_dist=float(lv[2]), **common)
