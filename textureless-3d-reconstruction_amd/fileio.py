@@ -132,6 +132,19 @@ def load_data(rgb_folder, depth_folder, verbose: bool = True):
     return images, depths, names
 
 
+def usable_cpus() -> int:
+    """CPUs this process may use: affinity mask capped by the cgroup CPU quota (containers show every core of the host)."""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 class FramePrefetcher:
     """Row f2: decode files on worker threads into pinned staging buffers and hand them to the device with asynchronous
     uploads, so decode, PCIe copy and GPU work overlap and host RAM holds `n_staging` frames instead of all of them
@@ -141,14 +154,17 @@ class FramePrefetcher:
     Slots are assigned round-robin over ctx.n_slots; with n_slots >= number of frames every frame stays resident.
     """
 
-    def __init__(self, ctx, rgb_files, depth_files, n_staging: int = 4, workers: int = 4, raw_u16: bool = True):
+    def __init__(self, ctx, rgb_files, depth_files, n_staging: int = 0, workers: int = 0, raw_u16: bool = True):
         from concurrent.futures import ThreadPoolExecutor
         from .fusion import PinnedArray
         assert len(rgb_files) == len(depth_files)
         self.ctx, self.rgb_files, self.depth_files = ctx, list(rgb_files), list(depth_files)
         self.raw_u16 = raw_u16
         h, w = ctx.height, ctx.width
-        self.n_staging = max(2, int(n_staging))
+        # decode is the bottleneck of a file-fed run (JPEG ~10 ms, 16-bit PNG ~15 ms per 1080p frame and thread): one
+        # worker per granted CPU but two, as many staging buffers as can be in flight
+        workers = int(workers) if workers else min(16, max(2, usable_cpus() - 2))
+        self.n_staging = max(2, int(n_staging) if n_staging else workers + 2)
         self._f32 = [PinnedArray((h, w), np.float32) for _ in range(self.n_staging)]
         self._u16 = [PinnedArray((h, w), np.uint16) for _ in range(self.n_staging)]
         self._bgr = [PinnedArray((h, w, 3), np.uint8) for _ in range(self.n_staging)]
