@@ -29,7 +29,7 @@ def main(argv=None):
     parser.add_argument("--no-hybrid", action="store_true", help="Disable hybrid features")
     # additive
     parser.add_argument("--depth-folder", type=str, default=None)
-    parser.add_argument("--grid", type=int, default=512)
+    parser.add_argument("--grid", type=int, default=1024, help="fusion volume budget: at most GRID^3 voxels in total")
     parser.add_argument("--device", type=int, default=0)
     args = parser.parse_args(argv)
 
@@ -48,7 +48,8 @@ def main(argv=None):
         return 1
     cands = [args.depth_folder] if args.depth_folder else [inp / "depth", Path(str(inp) + "_depth"), inp / "depth_images", inp]
     config = ReconstructionConfig(fx=args.fx, fy=args.fy, cx=args.cx, cy=args.cy, min_depth=0.1, max_depth=100.0,
-                                  voxel_size=0.005, subsample_factor=4, grid_dim=args.grid, device=args.device)
+                                  voxel_size=0.005, subsample_factor=4, grid_dim=args.grid, device=args.device,
+                                  outlier_filter=False)                   # DER's merge_pointclouds has no outlier filter (DER:615-645)
     pipeline = DepthToReconstructionPipeline(config)
     loaded = 0
     for c in cands:

@@ -27,7 +27,8 @@ def main(argv=None):
     parser.add_argument("--subsample", type=int, default=2)
     parser.add_argument("--no-vis", action="store_true")
     # additive
-    parser.add_argument("--grid", type=int, default=512, help="cap on voxels per axis of the fusion grid")
+    parser.add_argument("--grid", type=int, default=1024,
+                        help="fusion volume budget: at most GRID^3 voxels in total, spread over the axes as the scene needs")
     parser.add_argument("--sdf-trunc", type=float, default=4.0, help="TSDF truncation in voxels")
     parser.add_argument("--icp-iters", type=int, default=15)
     parser.add_argument("--icp-stride", type=int, default=2)

@@ -86,3 +86,72 @@ def test_config4_cylinder_orbit_icp_chain_reduced():
     total_motion = np.linalg.norm(np.eye(3) - rg) + np.linalg.norm(tg)
     assert err < 0.1 * total_motion + 2e-3, (err, total_motion)
     assert len(pts) > 5000
+
+
+def test_config3_corridor_dolly_icp_chain_in_a_budgeted_grid():
+    """BASELINE config 3 (stand-in for exp_tunnel_set1_images_1_fps): textureless rectangular
+    corridor 2 m x 2.4 m, 640x480, fx = fy = 512, camera advancing 10 cm per frame, 5 mm voxels.  Sliding along the
+    axis is observable only through the far wall and two small spheres, so the chain leans on the eigenvalue cutoff and
+    the constant-velocity prior.  The fusion grid is planned from the data under a voxel BUDGET: ~400 x 480 x 2000+
+    voxels, nothing clipped.  Fused cloud vs the restated reference CPU path (back-project with the analytic poses ->
+    vstack -> Open3D voxel centroid; DER-style: no outlier filter) and vs the analytic walls."""
+    W, H = 640, 480
+    cfg = ReconstructionConfig(fx=512.0, fy=512.0, cx=320.0, cy=240.0, voxel_size=0.005, subsample_factor=2, grid_dim=1024,
+                               outlier_filter=False)
+    scene = synth.corridor_scene()
+    n = 40
+    poses = synth.dolly_poses(n, (0.0, 0.0, 0.0), (0.0, 0.0, 0.1))
+    assert np.allclose(poses[0][0], np.eye(3)) and np.allclose(poses[0][1], 0)            # camera 0 is the world frame
+    frames = [synth.render(scene, p, W, H, cfg.fx, cfg.fy, cfg.cx, cfg.cy) for p in poses]
+    assert all((d > 0).all() for d, _ in frames)                                           # closed corridor: every ray hits
+    pipe = DepthToReconstructionPipeline(cfg)
+    pipe.set_frames([c for d, c in frames], [d for d, c in frames])
+    pts, col, est = pipe.reconstruct()
+    assert len(est) == n and all(r["status"] != 2 for r in pipe.icp_log)
+    # the grid follows the corridor: longer than the old 512-per-axis cap, nothing dropped
+    assert pipe.grid.dims[2] > 1536 and pipe.grid.dims[0] <= 416 and pipe.grid.dims[1] <= 496
+    assert pipe.stats["points_dropped"] == 0 and pipe.stats["voxels"] == len(pts)          # and no outlier filter ran
+    # chain drift over 3.9 m of travel
+    err = max(np.linalg.norm(r - rg) + np.linalg.norm(t.reshape(3) - tg.reshape(3)) for (r, t), (rg, tg) in zip(est, poses))
+    assert err < 5e-3, err
+    # fused points lie on the analytic corridor (side walls, floor/ceiling, far wall, spheres)
+    (lo, hi) = scene.room
+    d_wall = np.min(np.stack([np.abs(pts[:, 0] - lo[0]), np.abs(pts[:, 0] - hi[0]), np.abs(pts[:, 1] - lo[1]),
+                              np.abs(pts[:, 1] - hi[1]), np.abs(pts[:, 2] - hi[2])]), axis=0)
+    d_sph = np.min([np.abs(np.linalg.norm(pts - np.asarray(c), axis=1) - r) for c, r in scene.spheres], axis=0)
+    d = np.minimum(d_wall, d_sph)
+    assert d.mean() < 1e-3 and np.percentile(d, 99) < 5e-3, (d.mean(), np.percentile(d, 99))
+    # the reference CPU path on the same frames with the analytic poses
+    clouds = [rn.backproject(dd, cc, cfg.fx, cfg.fy, cfg.cx, cfg.cy, pose=p, subsample=2) for (dd, cc), p in zip(frames, poses)]
+    ref_p, _ = rn.merge_open3d(clouds, cfg.voxel_size, sor=False)
+    assert abs(len(pts) - len(ref_p)) < 0.05 * len(ref_p)
+    ch = rn.chamfer_mean(pts, ref_p)
+    assert ch < 1e-3, ch                                 # north-star bar: 1 mm mean Chamfer
+
+
+def test_icp_at_the_headline_resolution_matches_oracle():
+    """1080x1920 (fx = fy = 1719, the reference defaults): normal map bit for bit, ICP at pixel strides 2 and 4 vs the C
+    oracle -- same source count, same iteration count, pose within the north-star 1e-4 Frobenius (and in fact ~1e-9)."""
+    W, H = 1080, 1920
+    cam = dict(width=W, height=H, fx=1719.0, fy=1719.0, cx=540.0, cy=960.0)
+    scene = synth.object_scene(with_room=True)
+    poses = synth.orbit_poses(2, 1.0, 1.5)
+    frames = [synth.render(scene, p, want_color=False, **cam) for p in poses]
+    orc = c_oracle.Oracle(W, H, cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+    with tl3d.FusionContext(W, H, cam["fx"], cam["fy"], cam["cx"], cam["cy"], n_slots=2, grid=None) as ctx:
+        ctx.upload(0, frames[0][0], None)
+        ctx.upload(1, frames[1][0], None)
+        ctx.build_normals(1)
+        onm = orc.normals(frames[1][0])
+        assert np.array_equal(ctx.download_normals(1), onm)
+        r_rel, t_rel = synth.relative_pose(poses[0], poses[1])
+        T_true = np.eye(4); T_true[:3, :3] = r_rel; T_true[:3, 3] = t_rel.ravel()
+        for stride, iters in ((4, 10), (2, 10), (1, 4)):
+            res = ctx.icp(0, 1, iters=iters, stride=stride, max_dist=0.1)
+            ores = orc.icp(frames[0][0], onm, iters=iters, stride=stride, max_dist=0.1)
+            assert res["n_src"] == ores["n_src"] == -(-H // stride) * -(-W // stride)
+            assert abs(res["n_corr"] - ores["n_corr"]) <= 2 and res["iters_run"] == ores["iters_run"]
+            dT = np.linalg.norm(res["T"] - ores["T"])
+            assert dT <= 1e-4 and dT <= 1e-8, (stride, dT)
+            assert abs(res["rmse"] - ores["rmse"]) < 1e-9
+            assert np.linalg.norm(res["T"] - T_true) < 2e-3, stride

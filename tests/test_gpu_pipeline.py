@@ -219,3 +219,43 @@ def test_coarse_to_fine_icp_registers_large_frame_steps():
     est1 = run(icp_coarse=())
     worst = max(np.linalg.norm(r - rg) + np.linalg.norm(t - tg) for (r, t), (rg, tg) in zip(est1, rel[:len(est1)]))
     assert len(est1) < len(frames) or worst > 0.05
+
+
+def test_outlier_filter_switch_d2r_on_der_off(tmp_path):
+    """D2R's merge runs remove_statistical_outlier(20, 2.0) (D2R:412-415); DER's merge_pointclouds has none (DER:615-645).
+    ReconstructionConfig.outlier_filter selects; the DER command line switches it off, so its .ply is the unfiltered
+    extraction."""
+    scene, poses, rel, frames = _sequence(n=4)
+    noisy = []
+    rng = np.random.default_rng(4)
+    for d, c in frames:                                   # a few flying pixels for the filter to remove
+        d = d.copy()
+        idx = rng.integers(0, d.size, 150)
+        d.reshape(-1)[idx] *= rng.uniform(0.6, 0.9, 150).astype(np.float32)
+        noisy.append((d, c))
+    out = {}
+    for flt in (True, False):
+        cfg = ReconstructionConfig(**CAM, voxel_size=0.005, subsample_factor=2, grid_dim=1024, outlier_filter=flt)
+        pipe = DepthToReconstructionPipeline(cfg)
+        pipe.set_frames([c for d, c in noisy], [d for d, c in noisy])
+        pts, col, _ = pipe.reconstruct(poses=rel)
+        out[flt] = (pts, dict(pipe.stats))
+        ref_p, _ = _reference_cpu_path(noisy, rel, cfg, sor=flt)
+        assert abs(len(pts) - len(ref_p)) <= max(3, 2e-3 * len(ref_p)) and rn.chamfer_mean(pts, ref_p) < 5e-5
+    assert out[False][1]["voxels"] == out[False][1]["after_outlier_filter"] == len(out[False][0])
+    assert out[True][1]["voxels"] == out[False][1]["voxels"] and len(out[True][0]) < len(out[False][0]) - 50
+    # the DER command line: same frames from files -> unfiltered count
+    from PIL import Image
+    inp = tmp_path / "images"
+    inp.mkdir()
+    for i, (d, c) in enumerate(noisy):
+        Image.fromarray(c[..., ::-1]).save(inp / f"frame_{i:04d}.png")
+        np.save(inp / f"frame_{i:04d}_depth.npy", d)
+    import depth_enhanced_reconstruction as cli
+    assert cli.main(["--input", str(inp), "--output", str(tmp_path / "o"), "--fx", "525", "--fy", "525", "--cx", "320", "--cy", "240"]) == 0
+    pts_cli, _ = rn.read_ply(tmp_path / "o" / "reconstruction.ply")
+    cfg4 = ReconstructionConfig(**CAM, min_depth=0.1, max_depth=100.0, voxel_size=0.005, subsample_factor=4, outlier_filter=False)
+    pipe = DepthToReconstructionPipeline(cfg4)
+    pipe.set_frames([c for d, c in noisy], [d for d, c in noisy])
+    pts4, _, _ = pipe.reconstruct()
+    assert len(pts_cli) == len(pts4) == pipe.stats["voxels"]

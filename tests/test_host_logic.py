@@ -88,12 +88,22 @@ def test_ply_writers_roundtrip(tmp_path, capsys, golden_dir):
     assert "No points to save" in capsys.readouterr().out and not (tmp_path / "never.ply").exists()
 
 
-def test_plan_grid_uses_open3d_origin_and_caps():
+def test_plan_grid_uses_open3d_origin_and_caps_a_voxel_budget():
     spec, clipped = plan_grid([-0.5, -0.2, 1.0], [0.5, 0.3, 1.4], 0.005, 512)
     assert not clipped and np.allclose(spec.origin, [-0.5025, -0.2025, 0.9975])
     assert all(d % 8 == 0 for d in spec.dims) and spec.dims[0] >= 201 and spec.dims[0] < 216
+    # the cap is a voxel budget (grid_dim^3 in total), not a per-axis cube: a long thin scene keeps its full length
     spec, clipped = plan_grid([-5, -0.2, 1.0], [5, 0.3, 1.4], 0.005, 512)
-    assert clipped and spec.dims[0] == 512 and abs(spec.origin[0] + 1.28) < 1e-9
+    assert not clipped and spec.dims[0] >= 2001 and spec.nvox <= 512 ** 3 and abs(spec.origin[0] + 5.0025) < 1e-9
+    # BASELINE config 3: a 2 m x 2.4 m corridor seen 12.5 m deep at 5 mm fits the default budget unclipped
+    spec, clipped = plan_grid([-1.0, -1.2, -0.5], [1.0, 1.2, 12.0], 0.005, 1024)
+    assert not clipped and spec.dims == (408, 488, 2504)
+    # over budget: the longest axis is shaved about the scene centre, the others stay whole, the caller is told
+    spec, clipped = plan_grid([-1.0, -1.2, -0.5], [1.0, 1.2, 12.0], 0.005, 512)
+    assert clipped and spec.dims[:2] == (408, 488) and spec.nvox <= 512 ** 3 < spec.nvox + 8 * 408 * 488
+    assert abs((spec.origin[2] + 0.5 * spec.dims[2] * 0.005) - 5.75) < 1e-9 and np.allclose(spec.origin[:2], [-1.0025, -1.2025])
+    spec, clipped = plan_grid([0, 0, 0], [10, 10, 10], 0.005, 256, max_voxels=64 ** 3)
+    assert clipped and spec.dims == (64, 64, 64)
 
 
 def test_sharding_covers_every_frame_once():
@@ -169,3 +179,28 @@ def test_scale_tracker_is_the_references_running_average(capsys):
     assert abs(got[0] - 2.1) < 1e-6 and abs(got[1] - 2.1) < 1e-6            # (2.0 + 2.2) / 2
     assert abs(got[2] - (0.7 * 2.1 + 0.3 * 1.8)) < 1e-6 and got[3] == got[2]
     assert per_frame_scales(depths, None, default=1.25) == [1.25] * 4
+
+
+def test_product_scale_estimators_equal_the_reference_goldens(golden_dir, capsys):
+    """Row a6: the functions the pipeline actually calls (dense.estimate_scale_d2r, DenseReconstructor.estimate_scale,
+    DepthScaleEstimator.estimate_scale) on the 12 values captured from the reference (D2R:297-326, DER:659-697):
+    int() truncation of pixel coordinates, out-of-bounds and zero-depth pixels, negative Z, the D2R-only (0.001, 1000)
+    clamp, fewer than 3 samples, DER's >= 5 input points rule, even-count median.  Bit-equal."""
+    import make_golden as mg
+    from tl3d import dense
+    g = np.load(os.path.join(golden_dir, "misc.npz"))
+    rec = dense.DenseReconstructor(ReconstructionConfig())
+    n = 0
+    for name, (p3, p2, dm) in mg.scale_cases().items():
+        want_d2r, want_der = g[f"scale/{name}_d2r"], g[f"scale/{name}_der"]
+        assert np.float64(dense.estimate_scale_d2r(p3, p2, dm)) == want_d2r, name
+        assert np.float64(rec.estimate_scale(p3, p2, dm)) == want_d2r, name
+        assert np.float64(dense.DepthScaleEstimator.estimate_scale(p3, p2, dm, np.eye(3))) == want_der, name
+        assert np.float64(dense.DepthScaleEstimator.estimate_scale(p3, p2, dm)) == want_der, name      # K is optional
+        n += 2
+    assert n == 12
+    out = capsys.readouterr().out                       # the reference's progress lines (D2R:319, 324; DER:696)
+    assert "Warning: Too few scale samples, using default scale=1.0" in out
+    assert "Estimated depth scale:" in out and "  Depth scale:" in out
+    # four points are enough for D2R only (DER:673 wants >= 5 input points)
+    assert g["scale/four_der"] == 1.0 and g["scale/four_d2r"] != 1.0 and g["scale/too_few_d2r"] == 1.0

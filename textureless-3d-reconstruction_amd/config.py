@@ -31,7 +31,8 @@ class ReconstructionConfig:
     subsample_factor: int = 2
 
     # ---- additive: device fusion ------------------------------------------------------------------
-    grid_dim: int = 512                 # voxels per axis of the dense grid (multiple of 8)
+    grid_dim: int = 1024                # fusion volume budget: at most grid_dim^3 voxels IN TOTAL, spread over the axes as
+                                        # the scene needs (a corridor gets 400 x 480 x 2500, not a clipped cube)
     sdf_trunc_voxels: float = 4.0       # TSDF truncation in voxels
     icp_coarse: tuple = ((10, 4, 0.20),)   # levels before the final one: (iterations, pixel stride, gate in metres)
     icp_iters: int = 15
@@ -42,6 +43,11 @@ class ReconstructionConfig:
     icp_eig_rel: float = 1e-4           # relative eigenvalue cutoff: unobservable DOFs keep the motion prior
     tsdf_min_weight: int = 0            # > 0: gate the emitted centroids by the TSDF (outlier suppression)
     tsdf_max_abs: float = 1.0
+    # statistical outlier removal after the voxel merge: D2R's merge_pointclouds runs it (20 neighbours, 2 sigma,
+    # D2R:412-415); DER's merge_pointclouds has none (DER:615-645) -- the DER command line switches it off
+    outlier_filter: bool = True
+    outlier_nb_neighbors: int = 20
+    outlier_std_ratio: float = 2.0
     device: int = 0
 
     @property

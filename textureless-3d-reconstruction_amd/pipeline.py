@@ -29,21 +29,32 @@ def compose(r_rel, t_rel, r_prev, t_prev):
     return r_rel @ np.asarray(r_prev, np.float64), r_rel @ np.asarray(t_prev, np.float64).reshape(3, 1) + np.asarray(t_rel, np.float64).reshape(3, 1)
 
 
-def plan_grid(bounds_min, bounds_max, voxel_size, grid_dim, channels=abi.CH_TSDF | abi.CH_CENTROID, trunc_voxels=4.0):
-    """Grid with Open3D's voxel origin (min_bound - voxel/2) covering the bounds, capped at grid_dim^3; when the
-    scene is larger than the cap the grid is centred on it and points outside are dropped (and counted)."""
+def plan_grid(bounds_min, bounds_max, voxel_size, grid_dim, channels=abi.CH_TSDF | abi.CH_CENTROID, trunc_voxels=4.0,
+              max_voxels=None):
+    """Grid with Open3D's voxel origin (min_bound - voxel/2) covering the bounds.
+
+    The cap is a voxel BUDGET (default grid_dim^3 voxels in total, never more than the library's 2^32), not a cube: a
+    2 m x 2.4 m x 12 m corridor at 5 mm becomes 400 x 480 x 2400 voxels.  Only when the bounds need more than the budget
+    is the grid shrunk about the scene centre -- longest axis first -- and `clipped` returned True (points outside are
+    dropped and counted by the accumulation kernels; the caller prints the warning)."""
     v = float(voxel_size)
     mn, mx = np.asarray(bounds_min, np.float64), np.asarray(bounds_max, np.float64)
     origin = mn - 0.5 * v
     dims = np.floor((mx - origin) / v).astype(np.int64) + 1
-    dims = ((dims + 7) // 8) * 8
+    dims = np.maximum(8, ((dims + 7) // 8) * 8)
+    budget = int(grid_dim) ** 3 if max_voxels is None else int(max_voxels)
+    budget = max(512, min(budget, 1 << 32))
     clipped = False
+    want = dims.copy()
+    while int(dims[0]) * int(dims[1]) * int(dims[2]) > budget:       # shave the (currently) longest axis, 8 voxels at a time
+        a = int(np.argmax(dims))
+        if dims[a] <= 8:
+            break
+        dims[a] -= 8
+        clipped = True
     for a in range(3):
-        if dims[a] > grid_dim:
-            centre = 0.5 * (mn[a] + mx[a])
-            origin[a] = centre - 0.5 * grid_dim * v
-            dims[a] = grid_dim
-            clipped = True
+        if dims[a] < want[a]:
+            origin[a] = 0.5 * (mn[a] + mx[a]) - 0.5 * dims[a] * v
     return GridSpec(tuple(int(d) for d in dims), tuple(float(o) for o in origin), v, trunc_voxels * v, channels), clipped
 
 
@@ -128,6 +139,7 @@ class DepthToReconstructionPipeline:
         self.frame_index: List[int] = []          # which loaded frame each pose belongs to
         self.icp_log: List[dict] = []
         self.stats: dict = {}
+        self.grid: Optional[GridSpec] = None      # the fusion volume of the last reconstruct()
 
     # ---- a2 --------------------------------------------------------------------------------------
     def load_data(self, rgb_folder: str, depth_folder: str) -> int:
@@ -303,9 +315,11 @@ class DepthToReconstructionPipeline:
                     return None, None, None
                 grid, clipped = plan_grid(mn, mx, cfg.voxel_size, cfg.grid_dim, trunc_voxels=cfg.sdf_trunc_voxels)
                 if clipped:
-                    print(f"  Warning: scene extent {np.round(mx - mn, 3)} m exceeds {cfg.grid_dim} voxels of {cfg.voxel_size} m; "
-                          "points outside the grid are dropped")
+                    print(f"  Warning: scene extent {np.round(mx - mn, 3)} m at {cfg.voxel_size} m voxels exceeds the budget of "
+                          f"{cfg.grid_dim}^3 voxels; the grid {grid.dims} is centred on the scene and points outside it are dropped "
+                          "(raise --grid or --voxel-size)")
             print(f"  Grid {grid.dims} @ {grid.voxel_size * 1e3:g} mm, origin {np.round(grid.origin, 4)}")
+            self.grid = grid
             ctx.attach_grid(grid)
             print("\n--- Step 3: Fuse depth frames (TSDF + voxel centroids) ---")
             for pose, fi in zip(self.camera_poses, self.frame_index):
@@ -318,8 +332,8 @@ class DepthToReconstructionPipeline:
             xyz, rgb = ctx.extract(abi.EXTRACT_CENTROID, min_count=1, min_weight=cfg.tsdf_min_weight,
                                    max_abs_tsdf=cfg.tsdf_max_abs)
             n_vox = len(xyz)
-            if len(xyz) > 0:
-                keep = ctx.statistical_outlier(xyz, 20, 2.0, cell_size=2.0 * grid.voxel_size)     # D2R:413-415
+            if len(xyz) > 0 and cfg.outlier_filter:         # D2R:413-415; DER's merge has none (DER:615-645)
+                keep = ctx.statistical_outlier(xyz, cfg.outlier_nb_neighbors, cfg.outlier_std_ratio, cell_size=2.0 * grid.voxel_size)
                 xyz, rgb = xyz[keep], rgb[keep]
             self.stats = dict(points_accumulated=st["centroid_points"], points_dropped=st["centroid_dropped"],
                               voxels=n_vox, after_outlier_filter=len(xyz))
