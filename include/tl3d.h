@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TL3D_ABI_VERSION 1
+#define TL3D_ABI_VERSION 2
 
 /* error codes */
 #define TL3D_OK 0
@@ -45,6 +45,12 @@ extern "C" {
 
 /* fixed-point formats of the accumulators (exact, order-free sums => bit-identical multi-GPU merge) */
 #define TL3D_TSDF_QSCALE 32767          /* tsdf in [-1,1] -> rint(tsdf * 32767)                  */
+#define TL3D_TSDF_MAX_WEIGHT 65536      /* observations one voxel may hold: |sum| <= weight * 32767 < 2^31.  Free-space
+                                           voxels seen by every camera reach it first.  tl3d_integrate and tl3d_grid_add
+                                           return TL3D_E_STATE instead of wrapping; a merge done outside the library
+                                           (all-reduce on tl3d_grid_device_ptr memory) must check the sum of the ranks'
+                                           tl3d_grid_max_weight itself (tl3d.distributed does).  The centroid channel's
+                                           limit is 2^20 points per voxel.                                        */
 #define TL3D_CENTROID_FRAC_BITS 12      /* in-voxel offset in units of voxel/4096                */
 #define TL3D_BRICK 8                    /* grid is stored brick-major, 8x8x8 voxels per brick    */
 
@@ -118,6 +124,13 @@ typedef struct tl3d_stats {
 const char *tl3d_last_error(void);
 int tl3d_version(void);
 int tl3d_device_count(int *n);
+/* HIP_VERSION the library was compiled with, and the runtime / driver versions it is running on (the binding refuses a
+ * different major version: PyTorch-ROCm wheels bundle their own runtime and both must resolve to one copy). */
+int tl3d_runtime_info(int *hip_compiled, int *hip_runtime, int *hip_driver);
+/* Measurement aid: n_streams one-wave kernels of spin_ms each, one per fresh stream; elapsed_ms ~ ceil(n_streams / Q) *
+ * spin_ms where Q is the number of hardware queues the runtime really multiplexes streams onto (GPU_MAX_HW_QUEUES is
+ * read when the HIP runtime initialises -- setting it later has no effect; the ICP lanes and prep streams want >= 20). */
+int tl3d_probe_hw_queues(int device, int n_streams, double spin_ms, double *elapsed_ms);
 
 /* lifetime */
 int tl3d_create(const tl3d_config *cfg, int device, tl3d_ctx **out);
@@ -171,6 +184,8 @@ int tl3d_icp_p2plane(tl3d_ctx *ctx, int slot_src, double scale_src, int slot_tgt
  * for different frame pairs are independent, so up to TL3D_ICP_LANES of them may be in flight, each on its own
  * stream.  enqueue returns at once; collect blocks for that lane's result.  A lane holds one run at a time. */
 #define TL3D_ICP_LANES 16
+/* A run reads slot_src's depth and slot_tgt's normal map until it is collected.  tl3d_upload_frame* into slot_src and
+ * tl3d_build_normals of slot_tgt issued meanwhile are ordered behind the run on the device (they do not corrupt it). */
 int tl3d_icp_enqueue(tl3d_ctx *ctx, int lane, int slot_src, double scale_src, int slot_tgt, const double T_init[16],
                      const tl3d_icp_params *prm);
 int tl3d_icp_collect(tl3d_ctx *ctx, int lane, tl3d_icp_result *out);
@@ -184,6 +199,8 @@ int tl3d_grid_device_ptr(tl3d_ctx *ctx, uint32_t channel, void **ptr, size_t *by
 int tl3d_grid_download(tl3d_ctx *ctx, uint32_t channel, void *out_hd, size_t bytes);
 int tl3d_grid_upload(tl3d_ctx *ctx, uint32_t channel, const void *in_hd, size_t bytes);
 int tl3d_grid_add(tl3d_ctx *ctx, uint32_t channel, const void *other_hd, size_t bytes);   /* grid += other (merge) */
+/* largest number of observations any voxel of the TSDF channel holds (one reduction over the grid, blocks) */
+int tl3d_grid_max_weight(tl3d_ctx *ctx, int64_t *out);
 
 /* a7 (read-back half) + N4: fused grid -> point list. min_count: centroid occupancy threshold;
  * tsdf gate (centroid mode, only if the TSDF channel exists and min_weight > 0): keep voxels with

@@ -383,3 +383,77 @@ def test_tsdf_from_16bit_millimetre_frames_is_bit_exact():
         g = ctx.download_grid(tl3d.CH_TSDF)
     assert orc.tsdf[:, 1].sum() > 50000
     assert np.array_equal(g, orc.tsdf)
+
+
+def test_tsdf_int32_headroom_is_guarded_not_wrapped():
+    """A voxel's sum of rint(tsdf * 32767) stays inside int32 for TL3D_TSDF_MAX_WEIGHT = 65536 observations (free-space
+    voxels add +32767 every frame).  tl3d_integrate / tl3d_grid_add refuse the step that could wrap instead of wrapping."""
+    from tl3d import _cabi as abi
+    cam = dict(width=64, height=48, fx=60.0, fy=60.0, cx=31.5, cy=23.5)
+    depth = np.full((48, 64), 3.0, np.float32)                        # a wall 3 m away: the whole grid is free space
+    spec = tl3d.GridSpec.cube(16, 0.02, centre=(0.0, 0.0, 1.0), channels=tl3d.CH_TSDF)
+    pose = (np.eye(3), np.zeros(3))
+    with tl3d.FusionContext(n_slots=1, grid=spec, **cam) as ctx:
+        ctx.upload(0, depth, None)
+        ctx.integrate(0, pose)
+        g = ctx.download_grid(tl3d.CH_TSDF)
+        assert (g[:, 1] == 1).all() and (g[:, 0] == 32767).all() and ctx.max_weight() == 1
+        g[:, 1] = abi.TSDF_MAX_WEIGHT - 1
+        g[:, 0] = 32767 * (abi.TSDF_MAX_WEIGHT - 1)
+        ctx.upload_grid(tl3d.CH_TSDF, g)                              # contents unknown to the library: re-measured lazily
+        ctx.integrate(0, pose)                                        # 65536th observation: still representable
+        g2 = ctx.download_grid(tl3d.CH_TSDF)
+        assert (g2[:, 1] == abi.TSDF_MAX_WEIGHT).all() and (g2[:, 0].astype(np.int64) == 32767 * abi.TSDF_MAX_WEIGHT).all()
+        with pytest.raises(tl3d.Tl3dError) as e:
+            ctx.integrate(0, pose)
+        assert e.value.code == abi.E_STATE and "overflow" in str(e.value)
+        assert np.array_equal(ctx.download_grid(tl3d.CH_TSDF), g2)    # refused, nothing changed
+        # merges: 40000 + 30000 observations do not fit, 30000 + 30000 do
+        ctx.reset()
+        a = np.zeros_like(g); a[:, 1] = 40000; a[:, 0] = 40000 * 32767 // 2
+        b = np.zeros_like(g); b[:, 1] = 30000; b[:, 0] = -30000 * 32767 // 2
+        ctx.upload_grid(tl3d.CH_TSDF, a)
+        with pytest.raises(tl3d.Tl3dError) as e:
+            ctx.add_grid(tl3d.CH_TSDF, b)
+        assert e.value.code == abi.E_STATE
+        ctx.upload_grid(tl3d.CH_TSDF, b)
+        ctx.add_grid(tl3d.CH_TSDF, b)
+        assert np.array_equal(ctx.download_grid(tl3d.CH_TSDF), 2 * b) and ctx.max_weight() == 60000
+
+
+def test_slot_rewrites_are_ordered_behind_uncollected_icp_runs():
+    """An ICP lane reads its source slot's depth and its target slot's normal map until it is collected.  Re-uploading
+    into the source slot (a ring of fewer slots than frames) or rebuilding the target's normals meanwhile must not change
+    the run's result: the library orders those writes behind the run on the device."""
+    cam = dict(width=640, height=480, fx=525.0, fy=525.0, cx=320.0, cy=240.0)
+    from tl3d import synth
+    scene = synth.object_scene(with_room=True)
+    poses = synth.orbit_poses(3, 1.0, 2.0)
+    frames = [synth.render(scene, p, want_color=False, **cam)[0] for p in poses]
+    other = np.roll(frames[2], 37, axis=1) * np.float32(1.3)          # something quite different
+    kw = dict(iters=30, stride=1, max_dist=0.1, eps=0.0)
+    with tl3d.FusionContext(n_slots=2, grid=None, **cam) as ctx:
+        ctx.upload(0, frames[0], None)
+        ctx.upload(1, frames[1], None)
+        ctx.build_normals(1)
+        ref = ctx.icp(0, 1, **kw)
+        for _ in range(3):
+            ctx.upload(0, frames[0], None)
+            ctx.upload(1, frames[1], None)
+            ctx.build_normals(1)
+            ctx.icp_enqueue(3, 0, 1, **kw)
+            ctx.upload(0, other, None)              # rewrites the depth the run is reading
+            ctx.upload(1, other, None)
+            ctx.build_normals(1)                    # rewrites the normal map the run is reading
+            got = ctx.icp_collect(3)
+            assert np.array_equal(got["T"], ref["T"]) and got["n_corr"] == ref["n_corr"] and got["iters_run"] == ref["iters_run"]
+
+
+def test_streams_get_their_own_hardware_queues():
+    """`import tl3d` sets GPU_MAX_HW_QUEUES before the process's first HIP call (the runtime reads it once); with ROCm's
+    default of 4 the 16 ICP lanes + 2 prep streams + main stream would share 4 hardware queues."""
+    from tl3d import _cabi as abi
+    info = abi.probe_hw_queues(0)
+    assert info["GPU_MAX_HW_QUEUES"] is not None
+    if int(info["GPU_MAX_HW_QUEUES"]) >= 16:
+        assert info["effective_queues"] >= 12, info

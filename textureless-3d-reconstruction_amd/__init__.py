@@ -6,6 +6,8 @@ include/tl3d.h.  Import as `tl3d` (tl3d.py at the repo root maps the hyphenated 
 an importable package).
 """
 from . import _cabi  # noqa: F401
+
+_cabi.ensure_hw_queues()        # before the process's first HIP call (the runtime reads it once): see _cabi.ensure_hw_queues
 from ._cabi import CH_CENTROID, CH_TSDF, EXTRACT_CENTROID, EXTRACT_TSDF, ICP_LANES, Tl3dError  # noqa: F401
 from .fusion import FusionContext, GridSpec  # noqa: F401
 

@@ -10,17 +10,18 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtl3d.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 OK, E_INVALID, E_HIP, E_NOMEM, E_CAPACITY, E_STATE, E_NODEVICE = 0, -1, -2, -3, -4, -5, -6
 CH_TSDF, CH_CENTROID = 1, 2
 DEPTH_F32_M, DEPTH_U16_MM = 0, 1
 F_SCALE_F64, F_NO_POSE = 1, 2
 EXTRACT_CENTROID, EXTRACT_TSDF = 0, 1
 ICP_LANES = 16
+TSDF_MAX_WEIGHT = 65536
 
 # every symbol include/tl3d.h declares (checked by tests/test_cabi_symbols.py against the header text)
 SYMBOLS = [
-    "tl3d_last_error", "tl3d_version", "tl3d_device_count", "tl3d_create", "tl3d_destroy", "tl3d_sync",
+    "tl3d_last_error", "tl3d_version", "tl3d_device_count", "tl3d_runtime_info", "tl3d_probe_hw_queues", "tl3d_grid_max_weight", "tl3d_create", "tl3d_destroy", "tl3d_sync",
     "tl3d_upload_frame", "tl3d_download_depth", "tl3d_pinned_alloc", "tl3d_pinned_free", "tl3d_upload_frame_async",
     "tl3d_slot_wait", "tl3d_attach_grid", "tl3d_backproject", "tl3d_accumulate_centroid",
     "tl3d_accumulate_points", "tl3d_points_bounds", "tl3d_integrate", "tl3d_build_normals",
@@ -65,11 +66,22 @@ class Stats(C.Structure):
 _lib = None
 
 
+def ensure_hw_queues(default: str = "24") -> str:
+    """ICP lanes (16), the two TSDF prep streams and the main stream want to run side by side; ROCm multiplexes HIP streams
+    onto GPU_MAX_HW_QUEUES hardware queues (default 4) and reads the variable ONCE, when the HIP runtime initialises (the
+    first HIP call of the process, whoever makes it -- `torch.cuda.set_device` counts).  Called at `import tl3d`, so an
+    application that imports the package before its first GPU call gets the setting; an explicit value always wins.
+    Returns the value in effect for a runtime initialised from now on (tl3d_probe_hw_queues measures the real one)."""
+    return os.environ.setdefault("GPU_MAX_HW_QUEUES", default)
+
+
 def _preload_shared_hip_runtime():
     """Keep ONE HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so / libhsa-runtime64.so
     (same SONAME as /opt/rocm's).  If libtl3d.so pulled in /opt/rocm's copy first, a later `import torch` would load a
-    second runtime into the process, and the second one intermittently finds no GPU.  Loading torch's copy first (when
-    torch is installed) makes both libtl3d.so and torch resolve to the same runtime whatever the import order."""
+    second runtime into the process, and the second one finds no GPU (`RuntimeError: No HIP GPUs are available`: two HSA
+    runtimes cannot both open /dev/kfd's queues for one process).  Loading torch's copy first (when torch is installed) makes
+    libtl3d.so's DT_NEEDED libamdhip64.so resolve to the copy already in the process, whatever the import order.
+    Returns the directory loaded from, or None when torch is not installed (then /opt/rocm's runtime is the only one)."""
     import importlib.util
     try:
         spec = importlib.util.find_spec("torch")
@@ -78,14 +90,34 @@ def _preload_shared_hip_runtime():
     if spec is None or not spec.origin:
         return None
     libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+    loaded = None
     for name in ("libhsa-runtime64.so", "libamdhip64.so"):
         path = os.path.join(libdir, name)
         if os.path.exists(path):
             try:
                 C.CDLL(path, mode=C.RTLD_GLOBAL)
-            except OSError:
-                return None
-    return libdir
+            except OSError as e:            # falling through would recreate the two-runtimes state: say so instead
+                raise ImportError(f"cannot pre-load PyTorch's bundled HIP runtime {path} ({e}); libtl3d.so and torch must share "
+                                  "one runtime per process") from e
+            loaded = libdir
+    return loaded
+
+
+RUNTIME = {}
+
+
+def _check_runtime(lib):
+    """libtl3d.so is compiled by /opt/rocm's hipcc and runs on whichever libamdhip64.so the process resolved (PyTorch's
+    bundled one when torch is installed -- an older minor release in this image).  The host stubs and code-object format
+    are stable within a major release; a different MAJOR version is refused, a minor skew is recorded (RUNTIME) and a
+    kernel that the runtime could not load would fail loudly at its first launch (every launch is error-checked)."""
+    comp, run, drv = C.c_int(0), C.c_int(0), C.c_int(0)
+    lib.tl3d_runtime_info(C.byref(comp), C.byref(run), C.byref(drv))
+    RUNTIME.update(hip_compiled=comp.value, hip_runtime=run.value, hip_driver=drv.value,
+                   GPU_MAX_HW_QUEUES=os.environ.get("GPU_MAX_HW_QUEUES"))
+    if run.value and comp.value // 10_000_000 != run.value // 10_000_000:
+        raise ImportError(f"libtl3d.so was built for HIP {comp.value} but the process runs HIP runtime {run.value}: "
+                          "rebuild it with the ROCm release of the runtime in use")
 
 
 def load():
@@ -96,10 +128,7 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build it with `bash {os.path.join(_HERE, 'csrc', 'build.sh')}` "
                           "(there is no CPU fallback for the HIP path)")
-    # ICP lanes, the TSDF prep stream and the main stream want to run side by side; ROCm multiplexes streams onto
-    # GPU_MAX_HW_QUEUES hardware queues (default 4).  Only a default: an explicit setting wins, and it has no effect if
-    # the HIP runtime was already initialised by the host application.
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+    ensure_hw_queues()
     _preload_shared_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     lib.tl3d_last_error.restype = C.c_char_p
@@ -107,6 +136,9 @@ def load():
     sig = {
         "tl3d_version": [],
         "tl3d_device_count": [C.POINTER(C.c_int)],
+        "tl3d_runtime_info": [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)],
+        "tl3d_probe_hw_queues": [i32, i32, dbl, C.POINTER(dbl)],
+        "tl3d_grid_max_weight": [vp, C.POINTER(i64)],
         "tl3d_create": [C.POINTER(Config), i32, C.POINTER(vp)],
         "tl3d_destroy": [vp],
         "tl3d_sync": [vp],
@@ -146,8 +178,19 @@ def load():
         fn.restype = C.c_int
     if lib.tl3d_version() != ABI_VERSION:
         raise ImportError(f"libtl3d ABI {lib.tl3d_version()} != binding {ABI_VERSION}: rebuild the library")
+    _check_runtime(lib)
     _lib = lib
     return lib
+
+
+def probe_hw_queues(device: int = 0, n_streams: int = 48, spin_ms: float = 1.0) -> dict:
+    """How many hardware queues HIP streams really get in this process (needs a GPU): n_streams kernels of spin_ms on
+    n_streams fresh streams take ceil(n_streams / Q) * spin_ms."""
+    ms = C.c_double(0.0)
+    check(load().tl3d_probe_hw_queues(int(device), int(n_streams), float(spin_ms), C.byref(ms)))
+    rounds = max(1, int(round(ms.value / spin_ms - 0.2)))          # ~0.2 ms of launch overhead ride on the last round
+    return dict(streams=int(n_streams), spin_ms=float(spin_ms), elapsed_ms=round(ms.value, 3),
+                effective_queues=-(-int(n_streams) // rounds), GPU_MAX_HW_QUEUES=os.environ.get("GPU_MAX_HW_QUEUES"))
 
 
 def check(rc):

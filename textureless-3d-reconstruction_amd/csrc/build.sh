@@ -10,7 +10,7 @@ FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-ma
 OBJS=()
 PIDS=()
 mkdir -p "${HERE}/build"
-for f in tl3d_api kernels_backproject kernels_centroid kernels_tsdf kernels_icp kernels_extract kernels_sor; do
+for f in tl3d_api kernels_backproject kernels_centroid kernels_tsdf kernels_icp kernels_extract kernels_sor kernels_grid; do
   src="${HERE}/${f}.hip"; obj="${HERE}/build/${f}.o"
   if [[ ! -f "$obj" || "$src" -nt "$obj" || "${HERE}/tl3d_internal.h" -nt "$obj" || "${HERE}/bp_device.h" -nt "$obj" || "${HERE}/../../include/tl3d.h" -nt "$obj" ]]; then
     rm -f "$obj"                                   # a failed compile must not leave a stale object to link

@@ -290,11 +290,13 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(Cam cam, Grid g, Po
                                                              int2 *__restrict__ grid, unsigned long long *__restrict__ counters) {
     const int lane = threadIdx.x & 63;
     const int wid = threadIdx.x >> 6;
-    unsigned nmixed = list_counts[0], nfree = list_counts[1];
+    const unsigned nbricks = (unsigned)(g.nbx * g.nby * g.nbz);
+    // the trip count below comes from device memory: clamp it to what the list can hold, so that no ordering mistake
+    // upstream can ever turn into an unbounded loop or an out-of-range list read
+    unsigned nmixed = min(list_counts[0], nbricks), nfree = min(list_counts[1], nbricks - nmixed);
     if (DBG == 1 || DBG == 3 || DBG == 4) nfree = 0;
     if (DBG == 2) nmixed = 0;        // (list offsets below stay valid: FREE entries are addressed from the back)
     const unsigned nlist = nmixed + nfree;
-    const unsigned nbricks = (unsigned)(g.nbx * g.nby * g.nbz);
     unsigned nread = 0, nwritten = 0;
     // Blocks with the same blockIdx % 8 share an XCD and its L2 (a placement habit of the dispatcher: a speed choice, never
     // a correctness one).  Each such group consumes one contiguous eighth of the list -- the classification emits bricks

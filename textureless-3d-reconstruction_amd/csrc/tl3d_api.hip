@@ -92,6 +92,7 @@ static int check_slot(tl3d_ctx *ctx, int slot, bool need_loaded) {
 }
 
 static int upload_impl(tl3d_ctx *ctx, int slot, const void *depth_hd, int depth_kind, const uint8_t *bgr_hd, bool wait);
+static void icp_lane_free(tl3d_ctx::IcpLane &ln);
 static int flush_updates(tl3d_ctx *ctx);
 // every call that reads or writes the TSDF grid, re-uses a frame slot, synchronises or time-stamps first issues the deferred updates
 #define FLUSH_UPDATES(ctx_)                      \
@@ -99,6 +100,30 @@ static int flush_updates(tl3d_ctx *ctx);
         const int rc_ = flush_updates(ctx_);     \
         if (rc_) return rc_;                     \
     } while (0)
+
+// ICP lanes read slots[src].depth and slots[tgt].nmap on their own streams.  A call that rewrites one of those buffers on
+// the main stream (a new upload into the slot, a rebuilt normal map) is ordered behind every uncollected run that reads it.
+static int order_after_lanes(tl3d_ctx *ctx, int slot, bool rewrites_depth, bool rewrites_nmap) {
+    for (int l = 0; l < TL3D_ICP_LANES; ++l) {
+        tl3d_ctx::IcpLane &ln = ctx->icp_lanes[l];
+        if (!ln.stream || !ln.busy || !ln.ev_done) continue;
+        if ((rewrites_depth && ln.src_slot == slot) || (rewrites_nmap && ln.tgt_slot == slot))
+            TL3D_HIP(hipStreamWaitEvent(ctx->stream, ln.ev_done, 0));
+    }
+    return TL3D_OK;
+}
+
+// exact largest voxel weight of the TSDF channel (blocks; the deferred updates must have been issued)
+static int measure_max_weight(tl3d_ctx *ctx, const int2 *grid, long long *out) {
+    if (!ctx->d_maxw && hipMalloc(&ctx->d_maxw, sizeof(int)) != hipSuccess) return set_err(TL3D_E_NOMEM, "alloc failed");
+    int rc = launch_max_weight(ctx->stream, grid, ctx->nvox, ctx->d_maxw);
+    if (rc) return rc;
+    int h = 0;
+    TL3D_HIP(hipMemcpyAsync(&h, ctx->d_maxw, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    TL3D_HIP(hipStreamSynchronize(ctx->stream));
+    *out = (long long)h;
+    return TL3D_OK;
+}
 
 static int validate_grid(const tl3d_config *cfg) {
     REQUIRE((cfg->channels & ~(TL3D_CH_TSDF | TL3D_CH_CENTROID)) == 0 && cfg->channels != 0, TL3D_E_INVALID, "bad channel bits 0x%x", cfg->channels);
@@ -121,9 +146,12 @@ static int alloc_grid(tl3d_ctx *ctx, const tl3d_config *cfg) {
     g.trunc = (float)cfg->sdf_trunc;
     g.inv_trunc = (cfg->channels & TL3D_CH_TSDF) ? 1.0f / g.trunc : 0.0f;
     ctx->nvox = (size_t)g.nx * g.ny * g.nz;
+    ctx->tsdf_w_upper = 0;
+    ctx->tsdf_w_unknown = false;
     if (cfg->channels & TL3D_CH_TSDF) {
         if (cfg->ext_tsdf) {
             ctx->tsdf = (int2 *)cfg->ext_tsdf;
+            ctx->tsdf_w_unknown = true;                 // caller-owned memory: contents unknown
         } else {
             if (hipMalloc(&ctx->tsdf, ctx->nvox * sizeof(int2)) != hipSuccess) return set_err(TL3D_E_NOMEM, "TSDF grid alloc (%zu B) failed", ctx->nvox * 8);
             ctx->own_tsdf = true;
@@ -173,6 +201,28 @@ extern "C" {
 
 const char *tl3d_last_error(void) { return g_err; }
 int tl3d_version(void) { return TL3D_ABI_VERSION; }
+
+int tl3d_runtime_info(int *hip_compiled, int *hip_runtime, int *hip_driver) {
+    REQUIRE(hip_compiled && hip_runtime && hip_driver, TL3D_E_INVALID, "null out pointer");
+    *hip_compiled = HIP_VERSION;
+    *hip_runtime = *hip_driver = 0;
+    if (hipRuntimeGetVersion(hip_runtime) != hipSuccess) (void)hipGetLastError();
+    if (hipDriverGetVersion(hip_driver) != hipSuccess) (void)hipGetLastError();
+    return TL3D_OK;
+}
+
+int tl3d_probe_hw_queues(int device, int n_streams, double spin_ms, double *elapsed_ms) {
+    REQUIRE(elapsed_ms != nullptr, TL3D_E_INVALID, "null out pointer");
+    REQUIRE(n_streams >= 1 && n_streams <= 256 && spin_ms > 0 && spin_ms <= 50, TL3D_E_INVALID, "bad probe arguments");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        return set_err(TL3D_E_NODEVICE, "no HIP device visible");
+    }
+    REQUIRE(device >= 0 && device < ndev, TL3D_E_INVALID, "device %d out of range [0,%d)", device, ndev);
+    TL3D_HIP(hipSetDevice(device));
+    return probe_hw_queues(n_streams, spin_ms, elapsed_ms);
+}
 
 int tl3d_device_count(int *n) {
     REQUIRE(n != nullptr, TL3D_E_INVALID, "null out pointer");
@@ -275,16 +325,11 @@ int tl3d_destroy(tl3d_ctx *ctx) {
     if (ctx->block_offsets) (void)hipFree(ctx->block_offsets);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->d_cen_counters) (void)hipFree(ctx->d_cen_counters);
+    if (ctx->d_maxw) (void)hipFree(ctx->d_maxw);
     for (int l = 0; l < TL3D_ICP_LANES; ++l) {
         tl3d_ctx::IcpLane &ln = ctx->icp_lanes[l];
         if (ln.stream) (void)hipStreamSynchronize(ln.stream);
-        if (ln.slab) (void)hipFree(ln.slab);
-        if (ln.state) (void)hipFree(ln.state);
-        if (ln.graph) (void)hipGraphExecDestroy(ln.graph);
-        if (ln.host) (void)hipHostFree(ln.host);
-        if (ln.run) (void)hipFree(ln.run);
-        if (ln.run_host) (void)hipHostFree(ln.run_host);
-        if (ln.stream) (void)hipStreamDestroy(ln.stream);
+        icp_lane_free(ln);
     }
     if (ctx->bounds_slab) (void)hipFree(ctx->bounds_slab);
     for (int i = 0; i < 2; ++i)
@@ -327,6 +372,8 @@ static int upload_impl(tl3d_ctx *ctx, int slot, const void *depth_hd, int depth_
     REQUIRE(depth_kind == TL3D_DEPTH_F32_M || depth_kind == TL3D_DEPTH_U16_MM, TL3D_E_INVALID, "bad depth_kind %d", depth_kind);
     FLUSH_UPDATES(ctx);
     TL3D_HIP(hipSetDevice(ctx->device));
+    rc = order_after_lanes(ctx, slot, true, false);     // an uncollected ICP run may still read this slot's depth
+    if (rc) return rc;
     Slot &s = ctx->slots[slot];
     const size_t npx = (size_t)ctx->cam.W * ctx->cam.H;
     if (!s.depth && hipMalloc(&s.depth, npx * sizeof(float)) != hipSuccess) return set_err(TL3D_E_NOMEM, "frame alloc failed");
@@ -628,6 +675,19 @@ int tl3d_integrate(tl3d_ctx *ctx, int slot, const double R[9], const double t[3]
     const PoseF p = make_pose_f(R, t);
     const Frustum fr = make_frustum(ctx->cam);
     const float mind = (float)ctx->cfg.min_depth, maxd = (float)ctx->cfg.max_depth;
+    // int32 headroom: one more observation must keep every |sum_q| <= weight * 32767 below 2^31
+    if (ctx->tsdf_w_unknown || ctx->tsdf_w_upper + 1 > TL3D_TSDF_MAX_WEIGHT) {
+        FLUSH_UPDATES(ctx);
+        long long w = 0;
+        rc = measure_max_weight(ctx, ctx->tsdf, &w);
+        if (rc) return rc;
+        ctx->tsdf_w_upper = w;
+        ctx->tsdf_w_unknown = false;
+        REQUIRE(w + 1 <= TL3D_TSDF_MAX_WEIGHT, TL3D_E_STATE,
+                "a voxel already holds %lld observations: one more could overflow its int32 TSDF sum (limit %d); extract or reset the grid",
+                w, TL3D_TSDF_MAX_WEIGHT);
+    }
+    ctx->tsdf_w_upper++;
     Slot &sl = ctx->slots[slot];
     const bool u16 = sl.has_u16 && ctx->tsdf_use_u16;
     const void *dptr = u16 ? (const void *)sl.depth_u16 : (const void *)sl.depth;
@@ -670,6 +730,8 @@ int tl3d_build_normals(tl3d_ctx *ctx, int slot, double scale, double depth_jump)
     Slot &s = ctx->slots[slot];
     const size_t npx = (size_t)ctx->cam.W * ctx->cam.H;
     if (!s.nmap && hipMalloc(&s.nmap, npx * sizeof(float4)) != hipSuccess) return set_err(TL3D_E_NOMEM, "normal map alloc failed");
+    rc = order_after_lanes(ctx, slot, false, true);     // an uncollected ICP run may still read this slot's normal map
+    if (rc) return rc;
     rc = launch_normals(ctx->stream, ctx->cam, s.depth, (float)scale, (float)ctx->cfg.min_depth, (float)ctx->cfg.max_depth,
                         (float)depth_jump, s.nmap);
     if (rc) return rc;
@@ -690,18 +752,38 @@ int tl3d_download_normals(tl3d_ctx *ctx, int slot, float *out) {
     return TL3D_OK;
 }
 
+static void icp_lane_free(tl3d_ctx::IcpLane &ln) {
+    if (ln.slab) (void)hipFree(ln.slab);
+    if (ln.state) (void)hipFree(ln.state);
+    if (ln.graph) (void)hipGraphExecDestroy(ln.graph);
+    if (ln.host) (void)hipHostFree(ln.host);
+    if (ln.run) (void)hipFree(ln.run);
+    if (ln.run_host) (void)hipHostFree(ln.run_host);
+    if (ln.ev_done) (void)hipEventDestroy(ln.ev_done);
+    if (ln.stream) (void)hipStreamDestroy(ln.stream);
+    memset(&ln, 0, sizeof(ln));
+}
+
+// all or nothing: a lane whose stream exists has every buffer (a half-built lane would launch kernels on null pointers)
 static int icp_lane_init(tl3d_ctx *ctx, int lane) {
     tl3d_ctx::IcpLane &ln = ctx->icp_lanes[lane];
     if (ln.stream) return TL3D_OK;
-    TL3D_HIP(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
-    if (hipMalloc(&ln.slab, (size_t)ICP_MAX_BLOCKS * ICP_SLAB * sizeof(double)) != hipSuccess) return set_err(TL3D_E_NOMEM, "alloc failed");
-    if (hipMalloc(&ln.state, sizeof(IcpState)) != hipSuccess) return set_err(TL3D_E_NOMEM, "alloc failed");
-    if (hipHostMalloc(&ln.host, sizeof(IcpState), hipHostMallocDefault) != hipSuccess) return set_err(TL3D_E_NOMEM, "pinned alloc failed");
-    if (hipMalloc(&ln.run, sizeof(IcpRun)) != hipSuccess) return set_err(TL3D_E_NOMEM, "alloc failed");
-    if (hipHostMalloc(&ln.run_host, sizeof(IcpRun), hipHostMallocDefault) != hipSuccess) return set_err(TL3D_E_NOMEM, "pinned alloc failed");
+    bool ok = hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipMalloc(&ln.slab, (size_t)ICP_MAX_BLOCKS * ICP_SLAB * sizeof(double)) == hipSuccess;
+    ok = ok && hipMalloc(&ln.state, sizeof(IcpState)) == hipSuccess;
+    ok = ok && hipHostMalloc(&ln.host, sizeof(IcpState), hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipMalloc(&ln.run, sizeof(IcpRun)) == hipSuccess;
+    ok = ok && hipHostMalloc(&ln.run_host, sizeof(IcpRun), hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&ln.ev_done, hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        icp_lane_free(ln);
+        return set_err(TL3D_E_NOMEM, "ICP lane %d: stream / buffer allocation failed", lane);
+    }
     ln.graph = nullptr;
     ln.graph_iters = -1;
     ln.busy = false;
+    ln.src_slot = ln.tgt_slot = -1;
     return TL3D_OK;
 }
 
@@ -771,7 +853,10 @@ int tl3d_icp_enqueue(tl3d_ctx *ctx, int lane, int slot_src, double scale_src, in
         ln.graph_iters = prm->iters;
     }
     TL3D_HIP(hipGraphLaunch(ln.graph, ln.stream));
+    TL3D_HIP(hipEventRecord(ln.ev_done, ln.stream));
     ln.busy = true;
+    ln.src_slot = slot_src;
+    ln.tgt_slot = slot_tgt;
     return TL3D_OK;
 }
 
@@ -826,6 +911,8 @@ int tl3d_grid_reset(tl3d_ctx *ctx) {
     TL3D_HIP(hipSetDevice(ctx->device));
     if (ctx->tsdf) TL3D_HIP(hipMemsetAsync(ctx->tsdf, 0, ctx->nvox * sizeof(int2), ctx->stream));
     if (ctx->centroid) TL3D_HIP(hipMemsetAsync(ctx->centroid, 0, ctx->nvox * 32, ctx->stream));
+    ctx->tsdf_w_upper = 0;
+    ctx->tsdf_w_unknown = false;
     return TL3D_OK;
 }
 
@@ -834,6 +921,7 @@ int tl3d_grid_device_ptr(tl3d_ctx *ctx, uint32_t channel, void **ptr, size_t *by
     if (ctx) {
         FLUSH_UPDATES(ctx);
         ctx->grid_epoch++;                  // the caller may write through the pointer (all-reduce)
+        if (channel == TL3D_CH_TSDF) ctx->tsdf_w_unknown = true;
     }
     return grid_sel(ctx, channel, ptr, bytes);
 }
@@ -860,6 +948,7 @@ int tl3d_grid_upload(tl3d_ctx *ctx, uint32_t channel, const void *in, size_t byt
     ctx->grid_epoch++;
     REQUIRE(in && bytes == nb, TL3D_E_INVALID, "buffer is %zu B, grid channel is %zu B", bytes, nb);
     TL3D_HIP(hipSetDevice(ctx->device));
+    if (channel == TL3D_CH_TSDF) ctx->tsdf_w_unknown = true;
     TL3D_HIP(hipMemcpyAsync(p, in, nb, hipMemcpyDefault, ctx->stream));
     TL3D_HIP(hipStreamSynchronize(ctx->stream));
     return TL3D_OK;
@@ -882,15 +971,40 @@ int tl3d_grid_add(tl3d_ctx *ctx, uint32_t channel, const void *other, size_t byt
         if (e != hipSuccess) { (void)hipFree(tmp); return set_err(TL3D_E_HIP, "grid upload failed"); }
         src = tmp;
     }
-    if (channel == TL3D_CH_TSDF)
-        rc = launch_add_i32(ctx->stream, (int *)p, (const int *)src, nb / 4);
-    else
+    if (channel == TL3D_CH_TSDF) {
+        // the merged weights must keep the int32 sums in range: largest weight here + largest weight there
+        long long wa = ctx->tsdf_w_upper, wb = 0;
+        if (ctx->tsdf_w_unknown) rc = measure_max_weight(ctx, ctx->tsdf, &wa);
+        if (rc == TL3D_OK) rc = measure_max_weight(ctx, (const int2 *)src, &wb);
+        if (rc == TL3D_OK && wa + wb > TL3D_TSDF_MAX_WEIGHT)
+            rc = set_err(TL3D_E_STATE, "merging grids with up to %lld + %lld observations per voxel could overflow the int32 TSDF sums (limit %d)",
+                         wa, wb, TL3D_TSDF_MAX_WEIGHT);
+        if (rc == TL3D_OK) {
+            ctx->tsdf_w_upper = wa + wb;
+            ctx->tsdf_w_unknown = false;
+            rc = launch_add_i32(ctx->stream, (int *)p, (const int *)src, nb / 4);
+        }
+    } else
         rc = launch_add_u64(ctx->stream, (unsigned long long *)p, (const unsigned long long *)src, nb / 8);
     if (tmp) {
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipFree(tmp);
     }
     return rc;
+}
+
+int tl3d_grid_max_weight(tl3d_ctx *ctx, int64_t *out) {
+    REQUIRE(ctx && out, TL3D_E_INVALID, "null argument");
+    REQUIRE(ctx->tsdf != nullptr, TL3D_E_STATE, "TSDF channel not enabled");
+    FLUSH_UPDATES(ctx);
+    TL3D_HIP(hipSetDevice(ctx->device));
+    long long w = 0;
+    const int rc = measure_max_weight(ctx, ctx->tsdf, &w);
+    if (rc) return rc;
+    ctx->tsdf_w_upper = w;
+    ctx->tsdf_w_unknown = false;
+    *out = (int64_t)w;
+    return TL3D_OK;
 }
 
 // ------------------------------------------------------------------------------------------- extraction

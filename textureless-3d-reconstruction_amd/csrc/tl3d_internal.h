@@ -120,6 +120,12 @@ struct tl3d_ctx {
     unsigned *block_counts;      // compaction counts
     unsigned long long *block_offsets;
     size_t scratch_blocks;
+    // int32 headroom of the TSDF sums: |sum_q| <= weight * 32767 stays below 2^31 while weight <= TL3D_TSDF_MAX_WEIGHT.
+    // tsdf_w_upper bounds the largest voxel weight from above (+1 per integrated frame); when it reaches the limit, or after
+    // a merge the library could not see (grid upload, grid pointer handed out), it is re-measured by a reduction over the grid
+    long long tsdf_w_upper;
+    bool tsdf_w_unknown;
+    int *d_maxw;
     unsigned long long *d_counters;   // device counters [16]
     unsigned long long *d_cen_counters;   // centroid statistics, sharded: [256 lines][8] (points kept, points dropped)
     struct IcpLane {             // one in-flight ICP run: own stream, device state, partial-sum slab, pinned read-back
@@ -131,7 +137,9 @@ struct tl3d_ctx {
         tl3d::IcpRun *run_host;  // pinned
         hipGraphExec_t graph;    // captured chain: descriptor + state upload, (iters+1) x (reduce, solve), state download
         int graph_iters;
-        bool busy;
+        bool busy;               // a run was enqueued and not collected yet
+        hipEvent_t ev_done;      // recorded on the lane's stream behind the run: writers of the slots it reads wait on it
+        int src_slot, tgt_slot;  // the run reads slots[src].depth and slots[tgt].nmap
     };
     IcpLane icp_lanes[TL3D_ICP_LANES];
     float *bounds_slab;
@@ -194,6 +202,8 @@ int launch_extract_write(hipStream_t s, const Grid &g, int mode, int min_count, 
                          const int2 *tsdf, const unsigned long long *cen, const unsigned long long *offsets, int nblocks,
                          float *xyz, uint8_t *rgb, unsigned long long cap);
 // grids
+int launch_max_weight(hipStream_t s, const int2 *grid, size_t nvox, int *d_out);
+int probe_hw_queues(int n_streams, double spin_ms, double *elapsed_ms);
 int launch_add_i32(hipStream_t s, int *dst, const int *src, size_t n);
 int launch_add_u64(hipStream_t s, unsigned long long *dst, const unsigned long long *src, size_t n);
 // outlier filter

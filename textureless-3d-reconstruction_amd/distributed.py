@@ -81,6 +81,13 @@ def allreduce_context_grids(ctx, dist) -> None:
     import torch
     ctx.sync()
     if ctx.grid.channels & abi.CH_TSDF:
+        # int32 headroom (tl3d.h: TL3D_TSDF_MAX_WEIGHT): the sum over ranks of each rank's largest voxel weight bounds the
+        # merged grid's; refuse the merge instead of wrapping
+        w = torch.tensor([ctx.max_weight()], dtype=torch.int64, device=torch.device("cuda", ctx.device))
+        dist.all_reduce(w)
+        if int(w.item()) > abi.TSDF_MAX_WEIGHT:
+            raise OverflowError(f"merged TSDF grid could hold {int(w.item())} observations per voxel (limit {abi.TSDF_MAX_WEIGHT}): "
+                                "merge more often or extract between scans")
         dist.all_reduce(ctx.grid_tensor(abi.CH_TSDF))
     if ctx.grid.channels & abi.CH_CENTROID:
         dist.all_reduce(ctx.grid_tensor(abi.CH_CENTROID))

@@ -279,6 +279,12 @@ class FusionContext:
             assert arr.nbytes == nb
         abi.check(self._lib.tl3d_grid_add(self._h, int(channel), abi.ptr(arr), nb))
 
+    def max_weight(self) -> int:
+        """Largest number of observations any TSDF voxel holds (int32 headroom: _cabi.TSDF_MAX_WEIGHT)."""
+        w = C.c_int64(0)
+        abi.check(self._lib.tl3d_grid_max_weight(self._h, C.byref(w)))
+        return int(w.value)
+
     def grid_tensor(self, channel: int):
         """Zero-copy torch view of a grid channel (for torch.distributed all_reduce over RCCL)."""
         import torch
