@@ -57,7 +57,7 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
     # before anything can initialise the HIP runtime (it reads the variable once; `import tl3d` sets the same default)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     import numpy as np
     import tl3d
     import torch
@@ -96,7 +96,6 @@ def main():
     ctx = tl3d.FusionContext(W, H, cam["fx"], cam["fy"], cam["cx"], cam["cy"], min_depth=0.1, max_depth=50.0,
                              n_slots=n_res, grid=spec, device=local_rank, stream=stream.cuda_stream)
 
-    hwq = abi.probe_hw_queues(local_rank) if rank == 0 else None      # effective stream concurrency of THIS process
     t_gen = time.perf_counter()
     host_keep = []
     n_invalid = 0
@@ -271,6 +270,8 @@ def main():
 
     if rank == 0:
         total = world * total_frames_rank
+        # effective stream concurrency of THIS process, measured after everything that is timed (the probe creates streams)
+        hwq = abi.probe_hw_queues(local_rank, 16, 1.0)
         out = {
             "metric": "depth frames/sec fused into TSDF (1080x1920)",
             "value": round(total / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,

@@ -449,11 +449,17 @@ def test_slot_rewrites_are_ordered_behind_uncollected_icp_runs():
             assert np.array_equal(got["T"], ref["T"]) and got["n_corr"] == ref["n_corr"] and got["iters_run"] == ref["iters_run"]
 
 
-def test_streams_get_their_own_hardware_queues():
-    """`import tl3d` sets GPU_MAX_HW_QUEUES before the process's first HIP call (the runtime reads it once); with ROCm's
-    default of 4 the 16 ICP lanes + 2 prep streams + main stream would share 4 hardware queues."""
+def test_streams_run_side_by_side_without_scheduler_stalls():
+    """`import tl3d` sets GPU_MAX_HW_QUEUES = 16 before the process's first HIP call (the runtime reads it once).  With
+    ROCm's default of 4 the 16 ICP lanes would share 4 hardware queues; from 24 live queues on, the GPU's queue slots are
+    over-subscribed and every hand-over can stall for a ~10 ms scheduler quantum.  The probe runs
+    n one-wave kernels of `spin` ms on n fresh streams: ceil(n / Q) rounds when healthy."""
     from tl3d import _cabi as abi
-    info = abi.probe_hw_queues(0)
-    assert info["GPU_MAX_HW_QUEUES"] is not None
-    if int(info["GPU_MAX_HW_QUEUES"]) >= 16:
-        assert info["effective_queues"] >= 12, info
+    one = abi.probe_hw_queues(0, 1, 0.5)
+    assert 0.45 < one["elapsed_ms"] < 2.0, one                      # the spin kernel keeps the 100 MHz clock
+    info = abi.probe_hw_queues(0, 16, 0.5)
+    assert info["GPU_MAX_HW_QUEUES"] is not None and 1 <= info["effective_queues"] <= 16
+    if int(info["GPU_MAX_HW_QUEUES"]) == 16:
+        assert info["elapsed_ms"] < 1.6, info                       # 16 streams, 16 queues: one round (+ launch overhead)
+        many = abi.probe_hw_queues(0, 48, 0.25)
+        assert many["elapsed_ms"] < 4.0, many                       # 3 rounds; the over-subscribed regime takes 10-20 ms

@@ -66,11 +66,17 @@ class Stats(C.Structure):
 _lib = None
 
 
-def ensure_hw_queues(default: str = "24") -> str:
+def ensure_hw_queues(default: str = "16") -> str:
     """ICP lanes (16), the two TSDF prep streams and the main stream want to run side by side; ROCm multiplexes HIP streams
     onto GPU_MAX_HW_QUEUES hardware queues (default 4) and reads the variable ONCE, when the HIP runtime initialises (the
     first HIP call of the process, whoever makes it -- `torch.cuda.set_device` counts).  Called at `import tl3d`, so an
     application that imports the package before its first GPU call gets the setting; an explicit value always wins.
+
+    Why 16 and not more (measured, tools/probe_queues.py, profiles/r02_probe_queues.txt): streams multiplexed onto Q <= 22
+    queues behave exactly like ceil(n / Q) rounds; from 24 live queues per process on, the GPU's hardware-queue slots are
+    over-subscribed and the firmware scheduler time-slices them with a ~10.3 ms quantum -- every cross-stream hand-over can
+    then stall for 10 ms (round 1's "intermittent cross-stream hang").  16 keeps the ICP lanes
+    concurrent and leaves room for the queues torch and RCCL create in the same process.
     Returns the value in effect for a runtime initialised from now on (tl3d_probe_hw_queues measures the real one)."""
     return os.environ.setdefault("GPU_MAX_HW_QUEUES", default)
 

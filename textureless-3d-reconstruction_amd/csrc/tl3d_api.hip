@@ -157,15 +157,16 @@ static int alloc_grid(tl3d_ctx *ctx, const tl3d_config *cfg) {
             ctx->own_tsdf = true;
             if (hipMemsetAsync(ctx->tsdf, 0, ctx->nvox * sizeof(int2), ctx->stream) != hipSuccess) return set_err(TL3D_E_HIP, "memset failed");
         }
-        {   // the prep kernels are short and latency-bound: give them dispatch priority over the streaming update
-            int lo = 0, hi = 0;
-            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        {   // two side streams for the per-frame prep chains (tiles, pyramid, classification).  Default priority: a priority
+            // stream gets a hardware queue outside the GPU_MAX_HW_QUEUES pool, and hardware queues are the scarce resource
+            // (24 live queues per process over-subscribe the GPU's slots: 10 ms scheduler quanta);
+            // highest / lowest / default priority measured the same frame rate.
             const char *ns = getenv("TL3D_PREP_STREAMS");
             ctx->n_prep_streams = ns ? atoi(ns) : 2;
             if (ctx->n_prep_streams < 1) ctx->n_prep_streams = 1;
             if (ctx->n_prep_streams > 2) ctx->n_prep_streams = 2;
             for (int q = 0; q < ctx->n_prep_streams; ++q)
-                if (!ctx->prep_stream[q] && hipStreamCreateWithPriority(&ctx->prep_stream[q], hipStreamNonBlocking, hi) != hipSuccess)
+                if (!ctx->prep_stream[q] && hipStreamCreateWithFlags(&ctx->prep_stream[q], hipStreamNonBlocking) != hipSuccess)
                     return set_err(TL3D_E_HIP, "stream create failed");
         }
         ctx->tsdf_use_u16 = !(getenv("TL3D_U16_GATHER") && atoi(getenv("TL3D_U16_GATHER")) == 0);
