@@ -160,10 +160,10 @@ def main():
         torch.cuda.synchronize(dev)
 
     def merge():
+        # the product's merge: int32-headroom check + RCCL sum all-reduce on the library's own grid memory (zero-copy)
         if dist is not None:
-            dist.all_reduce(ctx.grid_tensor(tl3d.CH_TSDF))
-            if args.centroid:
-                dist.all_reduce(ctx.grid_tensor(tl3d.CH_CENTROID))
+            from tl3d.distributed import allreduce_context_grids
+            allreduce_context_grids(ctx, dist)
 
     # int32 headroom of the TSDF sums: a voxel may hold TL3D_TSDF_MAX_WEIGHT (65 536) observations, the merged grid included.
     # A job longer than that is a sequence of scans: merge, hand the grid on (here: drop it), start the next scan.  All of it

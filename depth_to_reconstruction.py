@@ -14,6 +14,38 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
+def _spawn_ranks(n, argv):
+    """--gpus N outside torchrun: start N copies of this command line, one per GPU, BEFORE anything touches a GPU here
+    (children are fresh processes; the parent only waits).  Rendezvous on 127.0.0.1."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    return max(p.wait() for p in procs)
+
+
+def _init_rank(args):
+    """This process is one rank: bind it to its GPU and join the group (backend "nccl" = RCCL over xGMI; TL3D_DIST_BACKEND=gloo
+    and TL3D_SHARE_DEVICE=1 let several ranks share one GPU for tests)."""
+    import tl3d  # noqa: F401  (GPU_MAX_HW_QUEUES before the first HIP call)
+    import torch
+    import torch.distributed as dist
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    args.device = 0 if os.environ.get("TL3D_SHARE_DEVICE") == "1" else local
+    torch.cuda.set_device(args.device)
+    backend = os.environ.get("TL3D_DIST_BACKEND", "nccl")
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", args.device))
+    else:
+        dist.init_process_group(backend)
+    return dist
+
+
 def main(argv=None):
     parser = argparse.ArgumentParser(description="Depth to 3D Reconstruction")
     parser.add_argument("--rgb-folder", type=str, required=True, help="Folder with RGB images")
@@ -41,7 +73,17 @@ def main(argv=None):
     parser.add_argument("--device", type=int, default=0)
     parser.add_argument("--stream", action="store_true",
                         help="decode on worker threads into pinned buffers with asynchronous uploads; host RAM never holds the sequence")
+    parser.add_argument("--gpus", type=int, default=1,
+                        help="one process per GPU: frames shard across ranks, the per-GPU grids are summed with one RCCL all-reduce "
+                             "(also honoured under torchrun: RANK / WORLD_SIZE in the environment)")
     args = parser.parse_args(argv)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world == 1:
+        return _spawn_ranks(args.gpus, sys.argv[1:] if argv is None else list(argv))
+    dist = None
+    if world > 1:
+        dist = _init_rank(args)
 
     from tl3d.config import ReconstructionConfig
     from tl3d.pipeline import DepthToReconstructionPipeline
@@ -51,16 +93,34 @@ def main(argv=None):
                                   sdf_trunc_voxels=args.sdf_trunc, icp_iters=args.icp_iters, icp_stride=args.icp_stride,
                                   icp_max_dist=args.icp_max_dist, tsdf_min_weight=args.tsdf_min_weight, device=args.device)
     pipeline = DepthToReconstructionPipeline(config)
-    num_loaded = (pipeline.load_data_streaming if args.stream else pipeline.load_data)(args.rgb_folder, args.depth_folder)
+    # a rank decodes every frame on its host (pose chain and scale rule run over the whole sequence) and uploads its share
+    streaming = args.stream and dist is None
+    if dist is not None and dist.get_rank() != 0:
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):
+            num_loaded = pipeline.load_data(args.rgb_folder, args.depth_folder)
+    else:
+        num_loaded = (pipeline.load_data_streaming if streaming else pipeline.load_data)(args.rgb_folder, args.depth_folder)
     if num_loaded < 2:
-        print("Failed to load sufficient data")
+        if dist is None or dist.get_rank() == 0:
+            print("Failed to load sufficient data")
+        if dist is not None:
+            dist.destroy_process_group()
         return 0
     anchors = None
     if args.anchors:
         import numpy as np
         z = np.load(args.anchors)
         anchors = {int(k[3:]): (z[k], z["p2_" + k[3:]]) for k in z.files if k.startswith("p3_")}
-    points, colors, poses = pipeline.reconstruct(anchors=anchors)
+    if dist is not None:
+        points, colors, poses = pipeline.reconstruct_sharded(dist, anchors=anchors)
+        rank = dist.get_rank()
+        dist.barrier()
+        dist.destroy_process_group()
+        if rank != 0:                                   # rank 0 holds the merged cloud and writes the file
+            return 0
+    else:
+        points, colors, poses = pipeline.reconstruct(anchors=anchors)
     if points is not None and len(points) > 0:
         pipeline.save_reconstruction(points, colors, args.output, ascii=args.ascii)
         if not args.no_vis:

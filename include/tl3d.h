@@ -157,6 +157,13 @@ int tl3d_backproject(tl3d_ctx *ctx, int slot, const double R[9], const double t[
                      uint32_t flags, int subsample, double min_depth, double max_depth,
                      float *out_xyz_hd, uint8_t *out_rgb_hd, int64_t cap, int64_t *out_n);
 
+/* The same, asynchronous and device-only: points, colours AND the count go to device memory (out_n_dev: one int64),
+ * nothing is read back and the call returns as soon as its one kernel is enqueued.  cap is the capacity of the buffers in
+ * points (ceil(H/s) * ceil(W/s) always suffices); points beyond cap are not written, the count is the true one. */
+int tl3d_backproject_device(tl3d_ctx *ctx, int slot, const double R[9], const double t[3], double scale,
+                            uint32_t flags, int subsample, double min_depth, double max_depth,
+                            float *out_xyz_dev, uint8_t *out_rgb_dev, int64_t cap, int64_t *out_n_dev);
+
 /* a7 (fusion half): accumulate the same points straight into the centroid channel, no point list
  * (replaces np.vstack + Open3D voxel_down_sample's hash-map insert, D2R:401-410). */
 int tl3d_accumulate_centroid(tl3d_ctx *ctx, int slot, const double R[9], const double t[3], double scale,

@@ -449,6 +449,54 @@ static void icp_pass(const orc_cfg *c, const float *depth_s, float sc, const flo
  * fixed 12 sweeps), dropping directions whose eigenvalue is below eig_rel * (largest eigenvalue): degrees of freedom
  * the geometry does not observe (a plane slides, a cylinder spins, a sphere-on-plane rotates about its axis) are left
  * at the caller's prior instead of drifting (hard part H3).  Returns 0 on success. */
+/* Direct path.  When NO eigenvalue can fall under the cutoff, the truncated eigen-solution is simply -A^-1 b, and that
+ * can be known without eigenvalues: lambda_min >= 1 / trace(A^-1) and lambda_max <= trace(A), so
+ * 1 / trace(A^-1) > eig_rel * trace(A) implies lambda_min > eig_rel * lambda_max.  LDL^T without pivoting (A is symmetric
+ * positive definite here, or the test fails), the inverse of the unit-triangular factor gives diag(A^-1).  Returns 1 and x
+ * when it applies, 0 otherwise (ill-conditioned or degenerate: the caller runs the eigen-decomposition).  Every loop is
+ * in fixed index order; the device runs the same sequence. */
+static int solve6_direct(double A[6][6], const double b[6], double eig_rel, double x[6]) {
+    double L[6][6], M[6][6], d[6];
+    double tr = 0.0;
+    for (int i = 0; i < 6; ++i) tr += A[i][i];
+    for (int j = 0; j < 6; ++j) {
+        double s = A[j][j];
+        for (int k = 0; k < j; ++k) s -= (L[j][k] * L[j][k]) * d[k];
+        if (!(s > 0.0)) return 0;
+        d[j] = s;
+        for (int i = j + 1; i < 6; ++i) {
+            double t = A[i][j];
+            for (int k = 0; k < j; ++k) t -= (L[i][k] * L[j][k]) * d[k];
+            L[i][j] = t / s;
+        }
+    }
+    for (int i = 0; i < 6; ++i)                                  /* M = L^-1 (unit lower triangular) */
+        for (int j = 0; j < i; ++j) {
+            double t = L[i][j];
+            for (int k = j + 1; k < i; ++k) t += L[i][k] * M[k][j];
+            M[i][j] = -t;
+        }
+    double tinv = 0.0;                                           /* trace(A^-1) = sum_j sum_{i>=j} M[i][j]^2 / d[i] */
+    for (int j = 0; j < 6; ++j) {
+        double s = 1.0 / d[j];
+        for (int i = j + 1; i < 6; ++i) s += (M[i][j] * M[i][j]) / d[i];
+        tinv += s;
+    }
+    if (!(tinv > 0.0) || !(1.0 / tinv > eig_rel * tr)) return 0;
+    double y[6];                                                 /* y = M (-b);  z = y / d;  x = M^T z */
+    for (int i = 0; i < 6; ++i) {
+        double t = -b[i];
+        for (int j = 0; j < i; ++j) t += M[i][j] * -b[j];
+        y[i] = t / d[i];
+    }
+    for (int j = 0; j < 6; ++j) {
+        double t = y[j];
+        for (int i = j + 1; i < 6; ++i) t += M[i][j] * y[i];
+        x[j] = t;
+    }
+    return 1;
+}
+
 static int solve6(const double a21[21], const double b[6], double damping, double eig_rel, double x[6]) {
     double A[6][6], V[6][6];
     int m = 0;
@@ -462,6 +510,7 @@ static int solve6(const double a21[21], const double b[6], double damping, doubl
         A[i][i] += lam;
         for (int j = 0; j < 6; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
     }
+    if (solve6_direct(A, b, eig_rel, x)) return 0;               /* well conditioned: nothing would be truncated */
     /* Cyclic Jacobi in round-robin order: a sweep is 5 rounds of 3 rotations on disjoint index pairs.  The three
      * angles of a round are taken from the same matrix, then all column rotations are applied, then all row rotations
      * (disjoint pairs commute, so this is the sequential sweep up to rounding) -- the order the device's wave executes

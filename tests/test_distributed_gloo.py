@@ -86,3 +86,62 @@ def test_two_rank_merge_equals_single_process(tmp_path):
     # the chained poses follow the analytic orbit
     for i in range(N_FRAMES):
         assert np.linalg.norm(a["poses"][i][:, :3] - poses[i][0]) + np.linalg.norm(a["poses"][i][:, 3] - poses[i][1].ravel()) < 5e-3
+
+
+def _chain_worker(rank, world, port, out_dir):
+    """The product path's exchange protocol (tl3d.distributed: exchange_registrations / resolve_chain / chain_from_table /
+    allreduce_bounds / allreduce_counts) with a stand-in registration: the analytic relative pose, and frame 3 made to fail."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tl3d import distributed as dd, synth
+    n = 7
+    poses = synth.orbit_poses(n, 1.0, 5.0)
+
+    def register(a, b, fail=False):
+        r, t = synth.relative_pose(poses[a], poses[b])
+        T = np.eye(4); T[:3, :3] = r; T[:3, 3] = t.ravel()
+        return dict(T=T, against=a, fitness=0.9, rmse=1e-4, n_corr=3 if fail else 5000, n_src=6000, iters_run=4, status=0)
+
+    lo, hi = dd.shard_range(n, world, rank)
+    local = {b: register(a, b, fail=(b == 3)) for a, b in dd.pairs_for_rank(n, world, rank)}
+    table = dd.exchange_registrations(local, n, dist)
+    rounds = 0
+    for _ in range(n):
+        kept, redo = dd.resolve_chain(table, n)
+        if redo is None:
+            break
+        want, cur = redo
+        fixed = {cur: register(want, cur)} if lo <= cur < hi else {}       # the owner of `cur` repairs
+        dd.exchange_registrations(fixed, n, dist, into=table)
+        rounds += 1
+    chained, index, log = dd.chain_from_table(table, n)
+    mn, mx = dd.allreduce_bounds(np.array([rank, -rank, 5.0]), np.array([rank + 1.0, 0.5, 5.0 + rank]), dist)
+    cnt = dd.allreduce_counts([10 + rank, 1], dist)
+    np.savez(os.path.join(out_dir, f"chain{rank}.npz"), index=np.array(index), rounds=rounds, mn=mn, mx=mx, cnt=np.array(cnt),
+             poses=np.array([np.hstack([r, t.reshape(3, 1)]) for r, t in chained]), dropped=np.array([e["dropped"] for e in log]),
+             against=np.array([e["against"] for e in log]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_registration_exchange_and_skip_rule(tmp_path):
+    """Two ranks register the pairs they own, exchange them, agree on the dropped frame (D2R:598-615: frame 3 fails, frame 4 is
+    re-registered against frame 2 by its owner) and chain the same poses; bounds and counters reduce exactly."""
+    world = 2
+    mp.spawn(_chain_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    a, b = np.load(tmp_path / "chain0.npz"), np.load(tmp_path / "chain1.npz")
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k                                  # every rank took the same decisions
+    assert a["index"].tolist() == [0, 1, 2, 4, 5, 6] and int(a["rounds"]) == 1
+    assert a["dropped"].tolist() == [False, False, True, False, False, False] and a["against"].tolist() == [0, 1, 2, 2, 4, 5]
+    sys.path.insert(0, ROOT)
+    from tl3d import synth
+    poses = synth.orbit_poses(7, 1.0, 5.0)
+    r0, t0 = poses[0]
+    for row, k in zip(a["poses"], a["index"]):                               # the analytic orbit, relative to camera 0
+        rg = poses[k][0] @ r0.T
+        tg = poses[k][1].reshape(3) - rg @ t0.reshape(3)
+        assert np.linalg.norm(row[:, :3] - rg) + np.linalg.norm(row[:, 3] - tg) < 1e-12
+    assert a["mn"].tolist() == [0.0, -1.0, 5.0] and a["mx"].tolist() == [2.0, 0.5, 6.0] and a["cnt"].tolist() == [21, 2]

@@ -129,3 +129,70 @@ def test_u16_millimetre_conversion_is_exact_for_every_value():
         ctx.upload(0, mm, None)
         got = ctx.download_depth(0)
     assert np.array_equal(got, mm.astype(np.float32) / np.float32(1000.0))
+
+
+def test_device_only_backprojection_offsets_alignment_and_capacity():
+    """tl3d_backproject_device: one kernel, points / colours / count stay on the device.  Output ranges start at arbitrary
+    point offsets inside a tile and the caller's base pointers need not be 16-byte aligned (the kernel stages through LDS and
+    writes 16-byte chunks where the destination allows): every combination must equal the blocking host-output call, which
+    itself is checked against the reference goldens above.  cap smaller than the count: nothing beyond cap is written."""
+    import torch
+    rng = np.random.default_rng(11)
+    h, w = 203, 517                                    # several tiles of 2048 samples, ragged last tile
+    depth = (0.5 + 3.0 * rng.random((h, w))).astype(np.float32)
+    depth[rng.random((h, w)) < 0.37] = 0.0             # holes: tiles start at arbitrary output offsets
+    depth[:, 100:180] = 0.0                            # and whole runs without survivors
+    color = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+    q *= np.sign(np.linalg.det(q))
+    pose = (q, rng.normal(size=3))
+    dev = torch.device("cuda", 0)
+    with tl3d.FusionContext(w, h, 300.0, 310.0, 250.5, 99.25, n_slots=2) as ctx:
+        ctx.upload(0, depth, color)
+        ctx.upload(1, np.zeros((h, w), np.float32), color)
+        for sub in (1, 2, 3):
+            ref_p, ref_c = ctx.backproject(0, pose=pose, scale=1.1, subsample=sub)
+            ref_p, ref_c = ref_p.copy(), ref_c.copy()
+            n = len(ref_p)
+            assert n > 1000
+            op, oc = rn.backproject(depth, color, 300.0, 310.0, 250.5, 99.25, pose=pose, scale=1.1, subsample=sub)
+            assert len(op) == n and np.array_equal(oc, ref_c) and ulp_diff(ref_p, op).max() <= 1
+            cap = -(-h // sub) * -(-w // sub)
+            for off_f, off_b in ((0, 0), (1, 1), (2, 7), (3, 13)):          # base pointers at odd dword / byte phases
+                bx = torch.full((3 * cap + 8,), -7.0, dtype=torch.float32, device=dev)
+                bc = torch.full((3 * cap + 32,), 201, dtype=torch.uint8, device=dev)
+                nn = torch.zeros(1, dtype=torch.int64, device=dev)
+                xv, cv = bx[off_f:off_f + 3 * cap].view(cap, 3), bc[off_b:off_b + 3 * cap].view(cap, 3)
+                ctx.backproject_device(0, xv, cv, nn, pose=pose, scale=1.1, subsample=sub)
+                ctx.sync()
+                assert int(nn.item()) == n
+                assert np.array_equal(xv[:n].cpu().numpy().view(np.int32), ref_p.view(np.int32)) and np.array_equal(cv[:n].cpu().numpy(), ref_c)
+                # nothing outside [0, n) was touched, guard words included
+                assert (bx[:off_f] == -7.0).all() and (bx[off_f + 3 * n:] == -7.0).all()
+                assert (bc[:off_b] == 201).all() and (bc[off_b + 3 * n:] == 201).all()
+            # capacity smaller than the count: true count reported, writes stop at cap
+            small = n // 2 + 1
+            bx = torch.full((3 * small + 64,), -7.0, dtype=torch.float32, device=dev)
+            bc = torch.full((3 * small + 64,), 201, dtype=torch.uint8, device=dev)
+            nn = torch.zeros(1, dtype=torch.int64, device=dev)
+            ctx.backproject_device(0, bx[:3 * small].view(small, 3), bc[:3 * small].view(small, 3), nn, pose=pose, scale=1.1, subsample=sub, cap=small)
+            ctx.sync()
+            assert int(nn.item()) == n
+            assert np.array_equal(bx[:3 * small].cpu().numpy().view(np.int32), ref_p[:small].reshape(-1).view(np.int32))
+            assert (bx[3 * small:] == -7.0).all() and (bc[3 * small:] == 201).all()
+            with pytest.raises(tl3d.Tl3dError) as e:                      # the blocking call reports it as an error
+                x_small, c_small = np.empty((small, 3), np.float32), np.empty((small, 3), np.uint8)
+                from tl3d import _cabi as abi
+                import ctypes as C
+                got = C.c_int64(0)
+                r9, t3 = abi.d9(pose[0]), abi.d3(pose[1])
+                abi.check(ctx._lib.tl3d_backproject(ctx._h, 0, abi.ptr(r9), abi.ptr(t3), 1.1, 0, sub, 0.1, 50.0, abi.ptr(x_small), abi.ptr(c_small),
+                                                    small, C.byref(got)))
+            assert e.value.code == abi.E_CAPACITY and got.value == n
+        # a frame without survivors: count 0, nothing written
+        bx = torch.full((64,), -7.0, dtype=torch.float32, device=dev)
+        bc = torch.full((64,), 201, dtype=torch.uint8, device=dev)
+        nn = torch.full((1,), 5, dtype=torch.int64, device=dev)
+        ctx.backproject_device(1, bx[:63].view(21, 3), bc[:63].view(21, 3), nn, pose=pose)
+        ctx.sync()
+        assert int(nn.item()) == 0 and (bx == -7.0).all() and (bc == 201).all()

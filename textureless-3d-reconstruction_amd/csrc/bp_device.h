@@ -16,21 +16,37 @@ __device__ __forceinline__ float mm_to_m(uint16_t v) {
 }
 
 
+__device__ __forceinline__ bool bp_point(const Cam &cam, const BpArgs &a, const PoseD &p, float d32, int u, int v, float out[3]);
+
 __device__ __forceinline__ bool bp_pixel(const Cam &cam, const BpArgs &a, const PoseD &p, const float *__restrict__ depth,
                                          int u, int v, float out[3]) {
-    const float d32 = depth[(size_t)v * cam.W + u];
+    return bp_point(cam, a, p, depth[(size_t)v * cam.W + u], u, v, out);
+}
+
+// the same two steps on a depth value already in a register
+__device__ __forceinline__ bool bp_valid_value(const BpArgs &a, float d32) {
+    if (a.flags & TL3D_F_SCALE_F64) {
+        const double d = (double)d32 * a.scale;
+        return d > a.min_d && d < a.max_d;
+    }
+    const float d = d32 * (float)a.scale;
+    return d > (float)a.min_d && d < (float)a.max_d;
+}
+
+// back-projection of one depth value given the pixel's projection factors xf = (u - cx) / fx, yf = (v - cy) / fy
+__device__ __forceinline__ bool bp_point_f(const BpArgs &a, const PoseD &p, float d32, double xf, double yf, float out[3]) {
     double z;
     if (a.flags & TL3D_F_SCALE_F64) {
         const double d = (double)d32 * a.scale;
-        if (!(d > a.min_d && d < a.max_d)) return false;       // NaN and +-inf fail the strict compares
+        if (!(d > a.min_d && d < a.max_d)) return false;
         z = d;
     } else {
         const float d = d32 * (float)a.scale;
         if (!(d > (float)a.min_d && d < (float)a.max_d)) return false;
         z = (double)d;
     }
-    const double x = (((double)u - cam.cxd) / cam.fxd) * z;
-    const double y = (((double)v - cam.cyd) / cam.fyd) * z;
+    const double x = xf * z;
+    const double y = yf * z;
     if (a.flags & TL3D_F_NO_POSE) {
         out[0] = (float)x; out[1] = (float)y; out[2] = (float)z;
     } else {
@@ -39,6 +55,10 @@ __device__ __forceinline__ bool bp_pixel(const Cam &cam, const BpArgs &a, const 
         out[2] = (float)(((p.r[2] * x + p.r[5] * y) + p.r[8] * z) - p.ct[2]);
     }
     return true;
+}
+
+__device__ __forceinline__ bool bp_point(const Cam &cam, const BpArgs &a, const PoseD &p, float d32, int u, int v, float out[3]) {
+    return bp_point_f(a, p, d32, ((double)u - cam.cxd) / cam.fxd, ((double)v - cam.cyd) / cam.fyd, out);
 }
 
 __device__ __forceinline__ bool bp_valid_only(const Cam &cam, const BpArgs &a, const float *__restrict__ depth, int u, int v) {

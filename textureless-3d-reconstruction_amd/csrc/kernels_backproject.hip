@@ -5,6 +5,15 @@
 // Arithmetic: fp64 intermediates, exactly the reference's sequence (xf=(u-cx)/fx in fp64, x=xf*z,
 // P_w = R^T P_c - R^T t, cast to f32).  MI355X fp64 VALU is full rate enough that this kernel stays
 // bound by its 15 B/point of output; bytes per frame: read H*W*(4+3)/s^2, write N*15.
+//
+// ONE launch (bp_fused_kernel): every workgroup takes a ticket (its position in sample order), counts the survivors of
+// its 2048 samples, publishes the count as an 8-byte {status, value} granule and finds its output offset by a decoupled
+// look-back over its predecessors' granules (64 at a time, one per lane).  Survivors are then computed and staged
+// through LDS in output order, so xyz leaves as 16-byte stores of a contiguous range
+// and rgb as 16-byte stores of packed bytes (the round-1 kernel wrote 12-byte-strided floats and single bytes per lane,
+// after a count kernel, a single-workgroup scan and a host round trip for the size: 77 us per 1080x1920 frame).
+#include <stdlib.h>
+
 #include "tl3d_internal.h"
 #include "bp_device.h"
 
@@ -13,19 +22,6 @@ namespace tl3d {
 __global__ __launch_bounds__(256) void u16_to_f32_kernel(const uint16_t *__restrict__ in, float *__restrict__ out, size_t n) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) out[i] = mm_to_m(in[i]);              // == .astype(float32) / 1000.0 (D2R:90)
-}
-
-__global__ __launch_bounds__(256) void bp_count_kernel(Cam cam, BpArgs a, const float *__restrict__ depth,
-                                                       unsigned *__restrict__ block_counts) {
-    const long long s = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long ns = (long long)a.Ws * a.Hs;
-    bool ok = false;
-    if (s < ns) {
-        const int vs = (int)(s / a.Ws), us = (int)(s - (long long)vs * a.Ws);
-        ok = bp_valid_only(cam, a, depth, us * a.sub, vs * a.sub);
-    }
-    const int c = __syncthreads_count(ok);
-    if (threadIdx.x == 0) block_counts[blockIdx.x] = (unsigned)c;
 }
 
 // single-block exclusive scan of n block counts -> 64-bit offsets (+ total)
@@ -53,46 +49,283 @@ __global__ __launch_bounds__(1024) void scan_kernel(const unsigned *__restrict__
     if (t == 1023) *total = part[1023];
 }
 
-__global__ __launch_bounds__(256) void bp_write_kernel(Cam cam, BpArgs a, PoseD p, const float *__restrict__ depth,
-                                                       const uint8_t *__restrict__ bgr,
-                                                       const unsigned long long *__restrict__ offsets,
-                                                       float *__restrict__ xyz, uint8_t *__restrict__ rgb,
-                                                       unsigned long long cap) {
-    __shared__ unsigned wave_tot[4];
-    const long long s = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long ns = (long long)a.Ws * a.Hs;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    bool ok = false;
-    float pt[3];
-    int u = 0, v = 0;
-    if (s < ns) {
-        const int vs = (int)(s / a.Ws), us = (int)(s - (long long)vs * a.Ws);
-        u = us * a.sub;
-        v = vs * a.sub;
-        ok = bp_pixel(cam, a, p, depth, u, v, pt);
+// ---- one-launch back-projection -------------------------------------------------------------------------------
+#ifndef TL3D_BP_PAD
+#define TL3D_BP_PAD 0                          // diagnostic builds only: unused LDS bytes in front of and behind the block
+#endif
+constexpr int BP_TILE = 2048;                  // samples per workgroup (8 per thread)
+constexpr int BP_PER = BP_TILE / 256;
+constexpr int BP_WIN = 1024;                   // predecessors one look-back round inspects (4 per thread)
+constexpr unsigned long long BP_AGG = 1ull << 62, BP_PFX = 2ull << 62, BP_VAL = (1ull << 62) - 1ull;
+constexpr unsigned BP_SPIN_LIMIT = 1u << 17;   // polls of one granule (~0.1 s) before giving up (sets the error word)
+// state words: [0] ticket, [1] error word, [8 + 8 g] finished tiles of shard g (g = tile % 8, one 64-byte line each),
+// [72] finished shards, [BP_HDR + b] granule of tile b
+constexpr int BP_HDR = 80;
+constexpr unsigned BP_F_STATIC_ORDER = 0x40000000u;   // internal BpArgs.flags bit: tile = blockIdx.x (see launch_bp_fused)
+
+// Granule of tile b = {status << 62 | value}: AGG | own count as soon as the tile has counted, PFX | inclusive prefix
+// once it knows its offset.  Written by ONE 8-byte agent-scope store, polled by 8-byte agent-scope loads: the data is the
+// flag, no fence needed (MI355X guide, Guideline 16, form R2).  All words are zero between launches: the buffer is zeroed
+// when allocated and the tile that FINISHES last re-arms it (by then every tile has stopped polling), so a launch needs
+// no memset in front of it and has no per-launch arguments (it can be captured and replayed).
+template <bool WRITE>
+__global__ __launch_bounds__(256) void bp_fused_kernel(Cam cam, BpArgs a, PoseD p, const float *__restrict__ depth,
+                                                       const uint8_t *__restrict__ bgr, const double *__restrict__ xf,
+                                                       const double *__restrict__ yf, unsigned long long *state,
+                                                       float *__restrict__ xyz, uint8_t *__restrict__ rgb, unsigned long long cap,
+                                                       unsigned long long *__restrict__ total_out) {
+    // one LDS block, carved by hand: [xyz staging | rgb staging | per-(iteration, wave) counts | reduction scratch | scalars]
+    constexpr int XYZ_B = WRITE ? (3 * BP_TILE + 4) * 4 : 16, RGB_B = WRITE ? 3 * BP_TILE + 16 : 16;
+    constexpr int O_WAVE = TL3D_BP_PAD + XYZ_B + RGB_B, O_RED = O_WAVE + BP_PER * 16, O_SC = O_RED + 64;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[O_SC + 32 + TL3D_BP_PAD];
+    float *const s_xyz = reinterpret_cast<float *>(smem + TL3D_BP_PAD);
+    uint8_t *const s_rgb = smem + TL3D_BP_PAD + XYZ_B;
+    unsigned *const s_wave = reinterpret_cast<unsigned *>(smem + O_WAVE);          // [j * 4 + w]: survivors, then exclusive prefix
+    unsigned long long *const s_red = reinterpret_cast<unsigned long long *>(smem + O_RED);   // [0..3] per-wave partials, [4] result
+    unsigned long long &s_excl = *reinterpret_cast<unsigned long long *>(smem + O_SC);
+    unsigned &s_tile = *reinterpret_cast<unsigned *>(smem + O_SC + 8);
+    unsigned &s_cnt = *reinterpret_cast<unsigned *>(smem + O_SC + 12);
+    unsigned &s_flag = *reinterpret_cast<unsigned *>(smem + O_SC + 16);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    unsigned long long *const gran = state + BP_HDR;
+    // A tile waits for the COUNTS of all its predecessors, which every started tile publishes without waiting for anybody.
+    // So the only requirement is that a tile's predecessors have started.  Dynamic order: tiles are numbered by a ticket
+    // taken at workgroup start -- unconditional, but 1000 returning atomics on one word retire at ~88 per microsecond
+    // (12 us of a 1080p frame).  Static order (tile = blockIdx.x) is used when every tile of the launch fits on the chip at
+    // once (then nobody can wait for a workgroup that has no slot) -- see launch_bp_fused for the fallback.
+    if (tid == 0) {
+        s_tile = (a.flags & BP_F_STATIC_ORDER) ? blockIdx.x : (unsigned)__hip_atomic_fetch_add(state, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_flag = 0u;
     }
-    const unsigned long long m = __ballot(ok);
-    const unsigned below = __popcll(m & ((1ull << lane) - 1ull));
-    if (lane == 0) wave_tot[wid] = __popcll(m);
     __syncthreads();
-    unsigned base = 0;
-    for (int w = 0; w < wid; ++w) base += wave_tot[w];
-    if (ok) {
-        const unsigned long long o = offsets[blockIdx.x] + base + below;
-        if (o < cap) {
-            xyz[3 * o + 0] = pt[0];
-            xyz[3 * o + 1] = pt[1];
-            xyz[3 * o + 2] = pt[2];
-            uint8_t r = 0, g = 0, b = 0;
-            if (bgr) {
-                const uint8_t *px = bgr + 3 * ((size_t)v * cam.W + u);
-                b = px[0]; g = px[1]; r = px[2];
+    const unsigned tile = s_tile;
+    const long long ns = (long long)a.Ws * a.Hs;
+    const long long base = (long long)tile * BP_TILE;
+    // ---- phase 1: this thread's samples (sample = base + j * 256 + tid): depth AND colour loads issued together (the
+    // colours of rejected pixels are loaded too: one round trip instead of two on the tile's critical path), validity,
+    // survivors per wave
+    unsigned long long ball[BP_PER];
+    float dval[BP_PER];
+    unsigned col[BP_PER];
+    const long long s0 = base + tid;
+    const int v0 = (int)(s0 / a.Ws), u0 = (int)(s0 - (long long)v0 * a.Ws);
+    {
+        int v = v0, u = u0;
+#pragma unroll
+        for (int j = 0; j < BP_PER; ++j) {
+            const long long sj = base + (long long)j * 256 + tid;
+            const bool in = sj < ns;
+            const size_t pix = in ? (size_t)(v * a.sub) * cam.W + (size_t)(u * a.sub) : 0;
+            dval[j] = depth[pix];
+            col[j] = 0u;
+            if (WRITE && bgr) {
+                const uint8_t *px = bgr + 3 * pix;
+                col[j] = (unsigned)px[2] | ((unsigned)px[1] << 8) | ((unsigned)px[0] << 16);           // r | g << 8 | b << 16
             }
-            rgb[3 * o + 0] = r;
-            rgb[3 * o + 1] = g;
-            rgb[3 * o + 2] = b;
+            u += 256;
+            while (u >= a.Ws) { u -= a.Ws; ++v; }
+        }
+#pragma unroll
+        for (int j = 0; j < BP_PER; ++j) {
+            const long long sj = base + (long long)j * 256 + tid;
+            ball[j] = __ballot(sj < ns && bp_valid_value(a, dval[j]));
+            if (lane == 0) s_wave[j * 4 + wid] = (unsigned)__popcll(ball[j]);
         }
     }
+    __syncthreads();
+    if (wid == 0) {                            // exclusive scan of the 32 per-(iteration, wave) counts, in sample order
+        const unsigned c = lane < BP_PER * 4 ? s_wave[lane] : 0u;
+        unsigned inc = c;
+#pragma unroll
+        for (int d = 1; d < 32; d <<= 1) {
+            const unsigned t = __shfl_up(inc, d);
+            if (lane >= d) inc += t;
+        }
+        if (lane < BP_PER * 4) s_wave[lane] = inc - c;
+        if (lane == BP_PER * 4 - 1) {
+            s_cnt = inc;
+            s_excl = 0ull;
+            __hip_atomic_store(gran + tile, (tile == 0 ? BP_PFX : BP_AGG) | (unsigned long long)inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();                           // s_cnt and the scanned s_wave are visible to every wave
+    const unsigned cnt_tile = s_cnt;
+    // ---- look-back, by the whole workgroup: thread t inspects the predecessors at distance t, t + 256, t + 512, t + 768
+    // (distance 0 = the tile just in front); counts are summed up to and including the nearest published prefix.  With
+    // every tile of a frame resident at once nobody holds a prefix early, so a round has to be wide: 1024 predecessors
+    // per round cost one load latency, where a 64-wide window would walk 16 rounds for the last tile of a 1080p frame.
+    if (tile != 0) {
+        unsigned long long excl = 0ull;
+        long long j = (long long)tile - 1;
+        for (;;) {
+            unsigned long long g[4];
+            unsigned near_pfx = 0xffffffffu;                                     // smallest distance with a prefix, this thread
+            bool failed = false;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const long long mine = j - (long long)(k * 256 + tid);
+                g[k] = BP_PFX;                                                   // in front of tile 0: prefix 0
+                if (mine >= 0) {
+                    unsigned spins = 0;
+                    for (;;) {
+                        g[k] = __hip_atomic_load(gran + mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((g[k] >> 62) != 0ull) break;
+                        // every spin ends: a bound, and one tile's time-out ends every other tile's wait at once
+                        if (++spins > BP_SPIN_LIMIT) { failed = true; break; }
+                        if ((spins & 255u) == 0u && __hip_atomic_load(state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) { failed = true; break; }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                if ((g[k] >> 62) == 2ull && near_pfx == 0xffffffffu) near_pfx = (unsigned)(k * 256 + tid);
+            }
+            if (failed) {
+                __hip_atomic_store(state + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_flag = 1u;
+            }
+            // nearest prefix over the workgroup
+            unsigned m = near_pfx;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) m = min(m, (unsigned)__shfl_xor((int)m, d));
+            if (lane == 0) s_red[wid] = m;
+            __syncthreads();
+            const unsigned stop = (unsigned)min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
+            __syncthreads();
+            unsigned long long v = 0ull;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if ((unsigned)(k * 256 + tid) <= stop) v += g[k] & BP_VAL;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+            if (lane == 0) s_red[wid] = v;
+            __syncthreads();
+            excl += (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+            const bool give_up = s_flag != 0u;
+            __syncthreads();
+            if (stop != 0xffffffffu || give_up) break;                           // uniform over the workgroup
+            j -= BP_WIN;
+        }
+        if (tid == 0) {
+            // the inclusive prefix goes out at once (also after a time-out, so that every successor ends too)
+            __hip_atomic_store(gran + tile, BP_PFX | ((excl + cnt_tile) & BP_VAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_excl = excl;
+        }
+        __syncthreads();
+    }
+    const unsigned long long excl = s_excl;
+    if (tile == gridDim.x - 1u && tid == 0) *total_out = excl + cnt_tile;       // the last tile in sample order knows the total
+    // ---- done polling.  The tile that gets here last re-arms the scratch for the next launch (nobody polls any more; the
+    // others may still be staging and writing, which touches none of it).  "Last" through a two-level count: 8 shard
+    // counters on lines of their own (tile % 8), then one counter of finished shards -- a single word would serialise
+    // 1000 returning atomics (6.5 us of a 1080p frame).  Placed here, the count's round trip runs under phase 2.
+    const unsigned shard = tile & 7u, in_shard = (gridDim.x - shard + 7u) >> 3;
+    unsigned long long arrived = 0ull;         // tid 0: issued here, looked at after phase 2
+    if (tid == 0) arrived = __hip_atomic_fetch_add(state + 8 + 8 * shard, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // points this tile may write: [excl, min(excl + cnt, cap))
+    const unsigned long long room = cap > excl ? cap - excl : 0ull;
+    const unsigned nw = (unsigned)(room < (unsigned long long)cnt_tile ? room : (unsigned long long)cnt_tile);
+    if (WRITE && nw != 0) {
+        // ---- phase 2: compute the survivors and stage them in output order.  LDS element i <-> global element
+        // (g0 - phase + i): a 16-byte chunk of an LDS array is 16-byte aligned in global memory too, whatever the offset
+        // and the caller's base alignment
+        const unsigned long long g0 = 3ull * excl;                               // first dword of xyz / first byte of rgb
+        const unsigned xphase = (unsigned)((g0 + ((reinterpret_cast<uintptr_t>(xyz) >> 2) & 3u)) & 3ull);
+        const unsigned bphase = (unsigned)((g0 + (reinterpret_cast<uintptr_t>(rgb) & 15u)) & 15ull);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        int v = v0, u = u0;
+#pragma unroll
+        for (int j = 0; j < BP_PER; ++j) {
+            if ((ball[j] >> lane) & 1ull) {
+                const unsigned r = s_wave[j * 4 + wid] + (unsigned)__popcll(ball[j] & below);
+                float pt[3] = {0.0f, 0.0f, 0.0f};
+                // xf[u] = (u - cx) / fx and yf[v] = (v - cy) / fy come from tables (the reference caches the same two maps,
+                // D2R:287-295): the same IEEE quotients, without two fp64 divisions per pixel
+                (void)bp_point_f(a, p, dval[j], xf[u * a.sub], yf[v * a.sub], pt);
+                s_xyz[xphase + 3 * r + 0] = pt[0];
+                s_xyz[xphase + 3 * r + 1] = pt[1];
+                s_xyz[xphase + 3 * r + 2] = pt[2];
+                s_rgb[bphase + 3 * r + 0] = (uint8_t)(col[j] & 0xffu);
+                s_rgb[bphase + 3 * r + 1] = (uint8_t)((col[j] >> 8) & 0xffu);
+                s_rgb[bphase + 3 * r + 2] = (uint8_t)((col[j] >> 16) & 0xffu);
+            }
+            u += 256;
+            while (u >= a.Ws) { u -= a.Ws; ++v; }
+        }
+        __syncthreads();
+        {   // xyz: dwords [xphase, xphase + 3 nw) of s_xyz; gx + i is the home of s_xyz[i]
+            float *__restrict__ gx = xyz + g0 - xphase;
+            const unsigned lo = xphase, hi = xphase + 3u * nw;
+            const unsigned body_lo = (lo + 3u) & ~3u, body_hi = hi & ~3u;
+            if (body_lo < body_hi) {
+                for (unsigned i = lo + tid; i < body_lo; i += 256) gx[i] = s_xyz[i];
+                for (unsigned c = body_lo / 4u + tid; c < body_hi / 4u; c += 256)
+                    *reinterpret_cast<float4 *>(gx + 4u * c) = *reinterpret_cast<const float4 *>(s_xyz + 4u * c);
+                for (unsigned i = body_hi + tid; i < hi; i += 256) gx[i] = s_xyz[i];
+            } else {
+                for (unsigned i = lo + tid; i < hi; i += 256) gx[i] = s_xyz[i];
+            }
+        }
+        {   // rgb: bytes [bphase, bphase + 3 nw) of s_rgb; gb + i is the home of s_rgb[i]
+            uint8_t *__restrict__ gb = rgb + g0 - bphase;
+            const unsigned lo = bphase, hi = bphase + 3u * nw;
+            const unsigned body_lo = (lo + 15u) & ~15u, body_hi = hi & ~15u;
+            if (body_lo < body_hi) {
+                for (unsigned i = lo + tid; i < body_lo; i += 256) gb[i] = s_rgb[i];
+                for (unsigned c = body_lo / 16u + tid; c < body_hi / 16u; c += 256)
+                    *reinterpret_cast<uint4 *>(gb + 16u * c) = *reinterpret_cast<const uint4 *>(s_rgb + 16u * c);
+                for (unsigned i = body_hi + tid; i < hi; i += 256) gb[i] = s_rgb[i];
+            } else {
+                for (unsigned i = lo + tid; i < hi; i += 256) gb[i] = s_rgb[i];
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned last = 0u;
+        if (arrived == (unsigned long long)in_shard - 1ull) {
+            const unsigned shards = gridDim.x < 8u ? gridDim.x : 8u;
+            if (__hip_atomic_fetch_add(state + 72, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)shards - 1ull) last = 2u;
+        }
+        s_flag = last;
+    }
+    __syncthreads();
+    if (s_flag == 2u) {
+        for (unsigned i = tid; i < gridDim.x; i += 256) __hip_atomic_store(gran + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < 8) __hip_atomic_store(state + 8 + 8 * tid, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) {
+            __hip_atomic_store(state, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(state + 72, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+int bp_fused_tiles(const BpArgs &a) {
+    const long long ns = (long long)a.Ws * a.Hs;
+    const long long nt = (ns + BP_TILE - 1) / BP_TILE;
+    return (int)(nt < 1 ? 1 : nt);
+}
+
+int bp_state_words(const BpArgs &a) { return BP_HDR + bp_fused_tiles(a); }
+
+// state: device buffer of at least bp_state_words(a) 64-bit words, ALL ZERO (zeroed once by the owner; the kernel leaves it
+// zero again, except the error word [1]); total_out: device word that receives the count
+int launch_bp_fused(hipStream_t s, const Cam &cam, const BpArgs &a, const PoseD &p, const float *depth, const uint8_t *bgr,
+                    const double *xf, const double *yf, unsigned long long *state, float *xyz, uint8_t *rgb, unsigned long long cap,
+                    unsigned long long *total_out, bool force_dynamic) {
+    const int nt = bp_fused_tiles(a);
+    // Static tile order while every tile of the launch can be resident at once (>= 4 workgroups of this kernel fit a CU by
+    // registers and LDS; 256 CUs): no tile can then be kept off the chip by tiles that wait for it.  If other work holds
+    // slots AND workgroups were dispatched out of order, a wait could starve: it is bounded, ends in the error word, and
+    // the blocking entry point then repeats the call in dynamic order (force_dynamic).  TL3D_BP_ORDER=dynamic|static pins it.
+    static const int pin = getenv("TL3D_BP_ORDER") ? (getenv("TL3D_BP_ORDER")[0] == 'd' ? 1 : 2) : 0;
+    BpArgs ad = a;
+    const bool stat = pin == 2 || (pin == 0 && !force_dynamic && nt <= 1024);
+    if (stat) ad.flags |= BP_F_STATIC_ORDER;
+    if (xyz && rgb)
+        hipLaunchKernelGGL(bp_fused_kernel<true>, dim3(nt), dim3(256), 0, s, cam, ad, p, depth, bgr, xf, yf, state, xyz, rgb, cap, total_out);
+    else
+        hipLaunchKernelGGL(bp_fused_kernel<false>, dim3(nt), dim3(256), 0, s, cam, ad, p, depth, bgr, xf, yf, state, nullptr, nullptr, 0ull, total_out);
+    TL3D_HIP(hipGetLastError());
+    return TL3D_OK;
 }
 
 int launch_u16_to_f32(hipStream_t s, const uint16_t *in, float *out, size_t n) {
@@ -102,21 +335,8 @@ int launch_u16_to_f32(hipStream_t s, const uint16_t *in, float *out, size_t n) {
     return TL3D_OK;
 }
 
-int launch_bp_count(hipStream_t s, const Cam &cam, const BpArgs &a, const float *depth, unsigned *block_counts, int nblocks) {
-    hipLaunchKernelGGL(bp_count_kernel, dim3(nblocks), dim3(256), 0, s, cam, a, depth, block_counts);
-    TL3D_HIP(hipGetLastError());
-    return TL3D_OK;
-}
-
 int launch_scan(hipStream_t s, const unsigned *counts, unsigned long long *offsets, int n, unsigned long long *total) {
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, counts, offsets, n, total);
-    TL3D_HIP(hipGetLastError());
-    return TL3D_OK;
-}
-
-int launch_bp_write(hipStream_t s, const Cam &cam, const BpArgs &a, const PoseD &p, const float *depth, const uint8_t *bgr,
-                    const unsigned long long *offsets, int nblocks, float *xyz, uint8_t *rgb, unsigned long long cap) {
-    hipLaunchKernelGGL(bp_write_kernel, dim3(nblocks), dim3(256), 0, s, cam, a, p, depth, bgr, offsets, xyz, rgb, cap);
     TL3D_HIP(hipGetLastError());
     return TL3D_OK;
 }

@@ -3,11 +3,14 @@
 // this replaces that pose source and returns the relative pose in the reference's chaining convention
 // (D2R:618-620).  Convention and f32 sequence = oracle/tl3d_oracle.c (orc_normals, icp_pass, solve6, se3_apply).
 //
-// Device-resident iteration: icp_reduce_kernel accumulates the 6x6 normal equations (21 + 6 + 3 sums, fp64)
-// per lane, reduces them with 64-lane wave shuffles, then across the 4 waves through LDS, and writes one
-// 32-double partial per workgroup; icp_solve_kernel sums the partials in block order (deterministic), solves
-// the damped system by a 6x6 Jacobi eigen-decomposition (unobservable directions dropped) and updates T in device memory.  No host round trip inside the loop: the host
-// replays one captured hipGraph per run (2 x (iters+1) kernels + the state copies) and reads the state once.  Bytes per iteration and sampled pixel: 4 (source
+// Device-resident iteration, ONE launch per iteration (icp_iter_kernel): every workgroup accumulates the 6x6 normal
+// equations (21 + 6 + 3 sums, fp64) per lane, reduces them with 64-lane wave shuffles, then across its 4 waves through
+// LDS, and publishes one 32-double partial (write-through stores, drained, then an agent-scope ticket).  The workgroup whose
+// ticket is the last one sums the partials in block order (deterministic), solves the damped system by a 6x6 Jacobi
+// eigen-decomposition (unobservable directions dropped), updates T in device memory and re-arms the ticket.  A dependent
+// two-kernel chain (reduce, then a one-workgroup solve) cost a second launch boundary and a second ramp per iteration:
+// 38 us -> see DESIGN.md section 7.  No host round trip inside the loop: the host replays one captured hipGraph per run
+// ((iters+1) kernels + the state copies) and reads the state once.  Bytes per iteration and sampled pixel: 4 (source
 // depth) + 16 (target normal+depth gather) = 20 B.
 #include "tl3d_internal.h"
 
@@ -58,15 +61,14 @@ __global__ __launch_bounds__(256) void normals_kernel(Cam cam, const float *__re
     nmap[(size_t)v * cam.W + u] = o;
 }
 
-__global__ __launch_bounds__(256) void icp_reduce_kernel(Cam cam, const IcpRun *__restrict__ run,
-                                                         const IcpState *__restrict__ state, int final_pass,
-                                                         double *__restrict__ slab) {
-    if (!final_pass && state->done) return;
+// accumulate this workgroup's share of the sums and leave the workgroup total in sm_out[0..31] (valid for threads < 32
+// after the function's last barrier)
+__device__ __forceinline__ void icp_accumulate(const Cam &cam, const IcpRun *__restrict__ run, const IcpState *state,
+                                               double (*sm)[ICP_SLAB], double *__restrict__ sm_out) {
     const float *__restrict__ depth_s = run->depth_src;
     const float4 *__restrict__ nmap_t = run->nmap_tgt;
     const float sc = run->scale, mind = run->mind, maxd = run->maxd, md2 = run->md2;
     const int stride = run->stride, Ws = run->Ws, Hs = run->Hs;
-    __shared__ double sm[4][ICP_SLAB];
     float r[9], t[3];
     r[0] = (float)state->T[0]; r[1] = (float)state->T[1]; r[2] = (float)state->T[2];  t[0] = (float)state->T[3];
     r[3] = (float)state->T[4]; r[4] = (float)state->T[5]; r[5] = (float)state->T[6];  t[1] = (float)state->T[7];
@@ -76,31 +78,44 @@ __global__ __launch_bounds__(256) void icp_reduce_kernel(Cam cam, const IcpRun *
 #pragma unroll
     for (int i = 0; i < 30; ++i) acc[i] = 0.0;
     const long long ns = (long long)Ws * Hs;
-    for (long long s = (long long)blockIdx.x * 256 + threadIdx.x; s < ns; s += (long long)gridDim.x * 256) {
-        const int vs = (int)(s / Ws), us = (int)(s - (long long)vs * Ws);
-        const int u = us * stride, v = vs * stride;
-        float ps[3];
-        if (!load_vertex(cam, depth_s, u, v, sc, mind, maxd, ps)) continue;
-        acc[29] += 1.0;
-        const float px = fmaf(r[0], ps[0], fmaf(r[1], ps[1], fmaf(r[2], ps[2], t[0])));
-        const float py = fmaf(r[3], ps[0], fmaf(r[4], ps[1], fmaf(r[5], ps[2], t[1])));
-        const float pz = fmaf(r[6], ps[0], fmaf(r[7], ps[1], fmaf(r[8], ps[2], t[2])));
-        if (!(pz > 0.0f)) continue;
-        const float inv = 1.0f / pz;
-        const float uf = fmaf(cam.fx * px, inv, cam.cx);
-        const float vf = fmaf(cam.fy * py, inv, cam.cy);
-        if (!(uf >= -0.5f && uf < wlim && vf >= -0.5f && vf < hlim)) continue;
+    // Two samples per trip, every load of the pair issued before its first use (source depths, then the two normal-map
+    // gathers): a thread's trip costs one depth latency + one gather latency instead of two of each.  Addresses of
+    // rejected samples are clamped to element 0 so that the loads need no branch; the per-thread order of the sums is the
+    // sample order, as before.
+    const long long step = (long long)gridDim.x * 256;
+    struct Samp { float px, py, pz; int ut, vt; bool src_ok, ok; };
+    auto prep = [&](float draw, int u, int v, bool in_range) {
+        Samp q;
+        const float d = draw * sc;
+        q.src_ok = in_range && (d > mind && d < maxd);
+        const float p0 = (((float)u - cam.cx) / cam.fx) * d;
+        const float p1 = (((float)v - cam.cy) / cam.fy) * d;
+        q.px = fmaf(r[0], p0, fmaf(r[1], p1, fmaf(r[2], d, t[0])));
+        q.py = fmaf(r[3], p0, fmaf(r[4], p1, fmaf(r[5], d, t[1])));
+        q.pz = fmaf(r[6], p0, fmaf(r[7], p1, fmaf(r[8], d, t[2])));
+        bool ok = q.src_ok && (q.pz > 0.0f);
+        const float inv = 1.0f / q.pz;
+        const float uf = fmaf(cam.fx * q.px, inv, cam.cx);
+        const float vf = fmaf(cam.fy * q.py, inv, cam.cy);
+        ok = ok && (uf >= -0.5f && uf < wlim && vf >= -0.5f && vf < hlim);
         int ut = (int)floorf(uf + 0.5f), vt = (int)floorf(vf + 0.5f);
         ut = min(ut, cam.W - 1);
         vt = min(vt, cam.H - 1);
-        const float4 nd = nmap_t[(size_t)vt * cam.W + ut];
+        q.ut = ok ? ut : 0;
+        q.vt = ok ? vt : 0;
+        q.ok = ok;
+        return q;
+    };
+    auto accum = [&](const Samp &q, const float4 nd) {
+        if (q.src_ok) acc[29] += 1.0;
         const float dt = nd.w;
-        if (!(dt > 0.0f)) continue;
-        const float qx = (((float)ut - cam.cx) / cam.fx) * dt;
-        const float qy = (((float)vt - cam.cy) / cam.fy) * dt;
+        if (!(q.ok && dt > 0.0f)) return;
+        const float px = q.px, py = q.py, pz = q.pz;
+        const float qx = (((float)q.ut - cam.cx) / cam.fx) * dt;
+        const float qy = (((float)q.vt - cam.cy) / cam.fy) * dt;
         const float dx = px - qx, dy = py - qy, dz = pz - dt;
         const float dist2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
-        if (!(dist2 <= md2)) continue;
+        if (!(dist2 <= md2)) return;
         const float res = fmaf(dx, nd.x, fmaf(dy, nd.y, dz * nd.z));
         const double J[6] = {(double)fmaf(py, nd.z, -(pz * nd.y)), (double)fmaf(pz, nd.x, -(px * nd.z)),
                              (double)fmaf(px, nd.y, -(py * nd.x)), (double)nd.x, (double)nd.y, (double)nd.z};
@@ -114,6 +129,21 @@ __global__ __launch_bounds__(256) void icp_reduce_kernel(Cam cam, const IcpRun *
         }
         acc[27] += rr * rr;
         acc[28] += 1.0;
+    };
+    for (long long s0 = (long long)blockIdx.x * 256 + threadIdx.x; s0 < ns; s0 += 2 * step) {
+        const long long s1 = s0 + step;
+        const bool in1 = s1 < ns;
+        const long long s1c = in1 ? s1 : s0;
+        const int vs0 = (int)(s0 / Ws), us0 = (int)(s0 - (long long)vs0 * Ws);
+        const int vs1 = (int)(s1c / Ws), us1 = (int)(s1c - (long long)vs1 * Ws);
+        const int u0 = us0 * stride, v0 = vs0 * stride, u1 = us1 * stride, v1 = vs1 * stride;
+        const float d0 = depth_s[(size_t)v0 * cam.W + u0];
+        const float d1 = depth_s[(size_t)v1 * cam.W + u1];
+        const Samp q0 = prep(d0, u0, v0, true), q1 = prep(d1, u1, v1, in1);
+        const float4 n0 = nmap_t[(size_t)q0.vt * cam.W + q0.ut];
+        const float4 n1 = nmap_t[(size_t)q1.vt * cam.W + q1.ut];
+        accum(q0, n0);
+        accum(q1, n1);
     }
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
@@ -126,8 +156,95 @@ __global__ __launch_bounds__(256) void icp_reduce_kernel(Cam cam, const IcpRun *
     __syncthreads();
     if (threadIdx.x < ICP_SLAB) {
         const int i = threadIdx.x;
-        slab[(size_t)blockIdx.x * ICP_SLAB + i] = (i < 30) ? ((sm[0][i] + sm[1][i]) + sm[2][i]) + sm[3][i] : 0.0;
+        sm_out[i] = (i < 30) ? ((sm[0][i] + sm[1][i]) + sm[2][i]) + sm[3][i] : 0.0;
     }
+}
+
+// 1/x and 1/sqrt(x) to ~1e-16 relative: hardware seed + two Newton steps (no IEEE division / square-root sequence)
+__device__ __forceinline__ double fast_rcp(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-x, y, 1.0);
+    return fma(y, e, y);
+}
+__device__ __forceinline__ double fast_rsq(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    double e = fma(-x * y, y, 1.0);
+    y = fma(0.5 * y, e, y);
+    e = fma(-x * y, y, 1.0);
+    return fma(0.5 * y, e, y);
+}
+
+// Direct path of oracle/tl3d_oracle.c: solve6_direct, same sequence.  Every lane runs it redundantly (no shuffles, all
+// indices static): ~250 dependent-ish fp64 operations instead of the eigen-decomposition's ~30 rounds of cross-lane
+// exchanges (18 of the 34 us of an iteration).  Returns 1 and x when it applies; 0 -> the caller runs solve6_wave.
+__device__ __forceinline__ int solve6_direct(const double *__restrict__ a21, const double *__restrict__ b, double lam,
+                                             double eig_rel, double x[6]) {
+    double A[6][6], L[6][6], M[6][6], d[6];
+    {
+        int m = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = i; j < 6; ++j) { const double e = a21[m++]; A[i][j] = e; A[j][i] = e; }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) A[i][i] += lam;
+    }
+    double tr = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) tr += A[i][i];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double s = A[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) s -= (L[j][k] * L[j][k]) * d[k];
+        ok = ok && (s > 0.0);
+        d[j] = s;
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) {
+            double t = A[i][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) t -= (L[i][k] * L[j][k]) * d[k];
+            L[i][j] = t / s;
+        }
+    }
+    if (!ok) return 0;                                       // uniform: every lane holds the same numbers
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < i; ++j) {
+            double t = L[i][j];
+#pragma unroll
+            for (int k = j + 1; k < i; ++k) t += L[i][k] * M[k][j];
+            M[i][j] = -t;
+        }
+    double tinv = 0.0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double s = 1.0 / d[j];
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) s += (M[i][j] * M[i][j]) / d[i];
+        tinv += s;
+    }
+    if (!(tinv > 0.0) || !(1.0 / tinv > eig_rel * tr)) return 0;
+    double y[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double t = -b[i];
+#pragma unroll
+        for (int j = 0; j < i; ++j) t += M[i][j] * -b[j];
+        y[i] = t / d[i];
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double t = y[j];
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) t += M[i][j] * y[i];
+        x[j] = t;
+    }
+    return 1;
 }
 
 // Same algorithm and the same arithmetic order as oracle/tl3d_oracle.c: solve6 (cyclic Jacobi, 12 sweeps, relative
@@ -154,6 +271,7 @@ __device__ __forceinline__ int solve6_wave(const double *__restrict__ a21, const
     tr = ((((a21[0] + a21[6]) + a21[11]) + a21[15]) + a21[18]) + a21[20];      // A00+A11+...+A55 in index order
     if (!(tr > 0.0)) return 1;
     const double lam = damping * (tr / 6.0);
+    if (solve6_direct(a21, b, lam, eig_rel, x)) return 0;                     // well conditioned: nothing would be truncated
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
         if (lane >= 6) a[j] = 0.0;
@@ -194,11 +312,17 @@ __device__ __forceinline__ int solve6_wave(const double *__restrict__ a21, const
             const double off_p = __shfl(my_off, partner);               // the lower lane's A[p][q] is the pivot for both
             const double app = isp ? my_diag : partner_diag, aqq = isp ? partner_diag : my_diag;
             const double apq = isp ? my_off : off_p;
+            // Rotation (c, s) of the pair.  A Jacobi sweep only needs c^2 + s^2 = 1 to rounding and an angle close to the
+            // annihilating one (its error is squared away by the next sweep), so the reciprocals and square roots are the
+            // hardware approximations + two Newton steps (~1e-16 relative) instead of IEEE sequences: the dependent chain of
+            // a round shrinks from ~150 to ~30 fp64 instructions (the solve was 18 of the 34 us of an iteration).  The
+            // eigenpairs the iteration converges to are the same to rounding; the oracle keeps exact divisions.
             double c = 1.0, sn = 0.0;
             if (lane < 6 && !(fabs(apq) < 1e-300)) {
-                const double theta = (aqq - app) / (2.0 * apq);
-                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                c = 1.0 / sqrt(t * t + 1.0);
+                const double theta = (aqq - app) * fast_rcp(2.0 * apq);
+                const double h2 = fma(theta, theta, 1.0);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) * fast_rcp(fabs(theta) + h2 * fast_rsq(h2));
+                c = fast_rsq(fma(t, t, 1.0));
                 sn = t * c;
             }
 #pragma unroll
@@ -274,25 +398,24 @@ __device__ void se3_apply(const double x[6], double *T) {
     for (int i = 0; i < 16; ++i) T[i] = Tn[i];
 }
 
-__global__ __launch_bounds__(256) void icp_solve_kernel(const double *__restrict__ slab, int nblocks, IcpState *state,
-                                                        const IcpRun *__restrict__ run, int final_pass) {
-    if (!final_pass && state->done) return;
+// The last workgroup's part: fixed-order sum of the published partials, solve, pose update.
+__device__ __forceinline__ void icp_finish(const double *slab, int nblocks, IcpState *state, const IcpRun *__restrict__ run,
+                                           int final_pass, double (*part)[ICP_SLAB], double *sums) {
     const double damping = run->damping, eps = run->eps, eig_rel = run->eig_rel;
-    __shared__ double part[8][ICP_SLAB];
-    __shared__ double sums[ICP_SLAB];
     const int t = threadIdx.x;
-    {   // slab reduction: 8 groups x 32 components, loads batched 8 deep, combined in a fixed order (deterministic)
+    {   // slab reduction: 8 groups x 32 components, loads batched 8 deep, combined in a fixed order (deterministic).
+        // The partials were written by other CUs in THIS launch: agent-scope (sc1) loads, never served from this CU's L1
         const int comp = t & 31, grp = t >> 5;
         double s = 0.0;
         int b = grp;
         for (; b + 56 < nblocks; b += 64) {
             double v[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = slab[(size_t)(b + 8 * k) * ICP_SLAB + comp];
+            for (int k = 0; k < 8; ++k) v[k] = __hip_atomic_load(slab + (size_t)(b + 8 * k) * ICP_SLAB + comp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
             for (int k = 0; k < 8; ++k) s += v[k];
         }
-        for (; b < nblocks; b += 8) s += slab[(size_t)b * ICP_SLAB + comp];
+        for (; b < nblocks; b += 8) s += __hip_atomic_load(slab + (size_t)b * ICP_SLAB + comp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         part[grp][comp] = s;
     }
     __syncthreads();
@@ -323,6 +446,38 @@ __global__ __launch_bounds__(256) void icp_solve_kernel(const double *__restrict
     }
 }
 
+// One ICP iteration in one launch.  Hand-off between workgroups inside the launch (MI355X guide, Guideline 16 / the
+// split-K "arrival ticket, last arriver combines" form): partial = 8-byte agent-scope (write-through) stores, the storing
+// wave drains them, the workgroup's barrier, ONE lane takes an agent-scope ticket; the workgroup whose ticket is the last
+// one acquires (one lane, then wait + barrier) and reads every partial with agent-scope loads.  Nothing depends on
+// dispatch order or placement; every workgroup takes exactly one ticket per launch, so the grid always drains.
+__global__ __launch_bounds__(256) void icp_iter_kernel(Cam cam, const IcpRun *__restrict__ run, IcpState *state, int final_pass,
+                                                       double *slab, unsigned *ticket) {
+    if (!final_pass && state->done) return;                // set by an EARLIER launch only: uniform over the grid
+    __shared__ double sm[8][ICP_SLAB];
+    __shared__ double tot[ICP_SLAB];
+    __shared__ int s_last;
+    icp_accumulate(cam, run, state, sm, tot);
+    if (threadIdx.x < ICP_SLAB) {
+        __hip_atomic_store(slab + (size_t)blockIdx.x * ICP_SLAB + threadIdx.x, tot[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the storing wave drains before anyone signals for it
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (tk == gridDim.x - 1u);
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    icp_finish(slab, (int)gridDim.x, state, run, final_pass, sm, tot);
+    if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // re-arm for the next launch
+}
+
 int launch_normals(hipStream_t s, const Cam &cam, const float *depth, float scale, float mind, float maxd, float jump,
                    float4 *nmap) {
     dim3 grid((cam.W + 63) / 64, (cam.H + 3) / 4);
@@ -331,10 +486,9 @@ int launch_normals(hipStream_t s, const Cam &cam, const float *depth, float scal
     return TL3D_OK;
 }
 
-int launch_icp_iteration(hipStream_t s, const Cam &cam, const IcpRun *run, int final_pass, double *slab, IcpState *state, int nblocks) {
-    hipLaunchKernelGGL(icp_reduce_kernel, dim3(nblocks), dim3(256), 0, s, cam, run, state, final_pass, slab);
-    TL3D_HIP(hipGetLastError());
-    hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(256), 0, s, slab, nblocks, state, run, final_pass);
+int launch_icp_iteration(hipStream_t s, const Cam &cam, const IcpRun *run, int final_pass, double *slab, IcpState *state, int nblocks,
+                         unsigned *ticket) {
+    hipLaunchKernelGGL(icp_iter_kernel, dim3(nblocks), dim3(256), 0, s, cam, run, state, final_pass, slab, ticket);
     TL3D_HIP(hipGetLastError());
     return TL3D_OK;
 }

@@ -282,7 +282,14 @@ __device__ __forceinline__ bool tsdf_finish(const Grid &g, const TsdfConst &c, b
 //   MAP 1: lanes = (x, y), lane loop over z   records k*64 + lane          (512 B contiguous per instruction)
 //   MAP 2: lanes = (x, z), lane loop over y   records z*64 + k*8 + x       (8 segments of 64 B)
 //   MAP 0: lanes = (x pair, y, z pair), 16-B pairs -- the generic layout, used when x is the vertical axis
-template <bool COUNT, int DBG, int MAP, typename DT>
+// VAR: how a MIXED brick's records reach the registers (MAP 1 / 2 only; the grid is the same bit for bit):
+//   0  predicated loads after the per-voxel decision: only records that change are read (fewest bytes, but the read-modify-
+//      write waits for projection + gather + decision, then for HBM)
+//   1  all 512 records loaded up front, before the projection: the HBM latency runs under the projection and the gathers;
+//      stores stay predicated.  Reads 4 KB per MIXED brick whatever changes (counted as read).
+//   2  as 1, and the NEXT listed brick's records are requested right behind this brick's gathers (one brick of look-ahead
+//      per wave): the record stream never waits for the gather phase.
+template <bool COUNT, int DBG, int MAP, typename DT, int VAR>
 __global__ __launch_bounds__(256) void tsdf_integrate_kernel(Cam cam, Grid g, PoseF pose, TsdfConst c,
                                                              const DT *__restrict__ depth,
                                                              const unsigned *__restrict__ list,
@@ -312,22 +319,47 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(Cam cam, Grid g, Po
     const unsigned a_beg = min(npair, grp * per_a), a_len = min(npair, a_beg + per_a) - a_beg;
     const unsigned b_beg = min(nlist, npair + grp * per_b), b_len = min(nlist, b_beg + per_b) - b_beg;
     const unsigned lstep = (gridDim.x / ngrp) * 4u;
-    for (unsigned t0 = bi * 4u; t0 < a_len + b_len; t0 += lstep) {
-        const unsigned t = t0 + wid;
-        if (t >= a_len + b_len) break;
+    const unsigned ntask = a_len + b_len;
+    // list entry of task t (wave-uniform): MIXED entries sit at the front of the list, FREE entries at the back (filled
+    // downwards).  They are consumed interleaved (even slots MIXED, odd slots FREE while both last): MIXED bricks are bound
+    // by the texture-address path, FREE bricks by HBM, so mixing them on every CU overlaps the two instead of running them
+    // back to back.
+    auto entry_of = [&](unsigned t) -> unsigned {
         const unsigned li = t < a_len ? a_beg + t : b_beg + (t - a_len);
-        // MIXED entries sit at the front of the list, FREE entries at the back (filled downwards).  They are consumed
-        // interleaved (even slots MIXED, odd slots FREE while both last): MIXED bricks are bound by the texture-address
-        // path, FREE bricks by HBM, so mixing them on every CU overlaps the two instead of running them back to back.
         unsigned src;
         if (li < npair) src = (li & 1u) ? nbricks - 1u - (li >> 1) : (li >> 1);
         else if (nmixed > nfree) src = li - nfree;                                   // remaining MIXED entries
         else src = nbricks - 1u - (li - nmixed);                                     // remaining FREE entries
-        const unsigned e = __builtin_amdgcn_readfirstlane(list[src]);
+        return __builtin_amdgcn_readfirstlane(list[src]);
+    };
+    constexpr bool PREF = (VAR >= 1) && (MAP != 0);
+    const int la = lane & 7, lb = lane >> 3;
+    auto rec_index = [&](int k) -> int { return MAP == 1 ? (k * 64 + lane) : (lb * 64 + k * 8 + la); };
+    int2 pre[8];                                            // VAR 2: records of the brick this wave handles next
+    bool pre_valid = false;
+    unsigned e_next = 0;
+    bool have_next = bi * 4u + wid < ntask;
+    if (have_next) e_next = entry_of(bi * 4u + wid);
+    for (unsigned t0 = bi * 4u; t0 < ntask; t0 += lstep) {
+        if (!have_next) break;
+        const unsigned e = e_next;
+        if (VAR == 2) {                                     // the entry after this one (wave-uniform)
+            have_next = t0 + lstep + wid < ntask;
+            e_next = have_next ? entry_of(t0 + lstep + wid) : 0u;
+        } else {
+            have_next = t0 + lstep + wid < ntask;
+            if (have_next) e_next = entry_of(t0 + lstep + wid);
+        }
         const int brick = (int)(e & ~FREE_FLAG);
         int4 *__restrict__ recs = reinterpret_cast<int4 *>(grid + ((size_t)brick << 9));
         if (e & FREE_FLAG) {
             int4 r0 = recs[lane], r1 = recs[64 + lane], r2 = recs[128 + lane], r3 = recs[192 + lane];
+            if (VAR == 2 && PREF && have_next && !(e_next & FREE_FLAG) && !pre_valid) {   // keep the look-ahead primed across a FREE brick
+                const int2 *__restrict__ nx2 = reinterpret_cast<const int2 *>(grid + ((size_t)(e_next & ~FREE_FLAG) << 9));
+#pragma unroll
+                for (int k = 0; k < 8; ++k) pre[k] = nx2[rec_index(k)];
+                pre_valid = true;
+            }
             r0.x += 32767; r0.y += 1; r0.z += 32767; r0.w += 1;
             r1.x += 32767; r1.y += 1; r1.z += 32767; r1.w += 1;
             r2.x += 32767; r2.y += 1; r2.z += 32767; r2.w += 1;
@@ -383,12 +415,22 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(Cam cam, Grid g, Po
     
         } else {
             // lane-owned column of 8 voxels along the image-vertical grid axis; records are touched 8 B at a time
-            const int la = lane & 7, lb = lane >> 3;
             const int i = bx * 8 + la;                                     // x is a lane axis in both maps
             const float px = fmaf((float)i + 0.5f, g.vs, g.ox);
             float zc[8], dv[8];
             bool ok[8];
             int2 *__restrict__ recs2 = reinterpret_cast<int2 *>(recs);
+            int2 rec[8];
+            if (PREF) {
+                if (VAR == 2 && pre_valid) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) rec[k] = pre[k];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) rec[k] = recs2[rec_index(k)];
+                }
+                pre_valid = false;
+            }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const int j = by * 8 + (MAP == 1 ? lb : k);
@@ -402,22 +444,30 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(Cam cam, Grid g, Po
                 ok[k] = tsdf_project(cam, c, xc, yc, zc[k], pix);
                 dv[k] = (DBG == 3) ? 1.0f + 1e-6f * (float)(pix & 1023) : ld_depth(depth, (size_t)pix);
             }
+            if (VAR == 2 && PREF && have_next && !(e_next & FREE_FLAG)) {     // right behind the gathers: the next brick's records
+                const int2 *__restrict__ nx2 = reinterpret_cast<const int2 *>(grid + ((size_t)(e_next & ~FREE_FLAG) << 9));
+#pragma unroll
+                for (int k = 0; k < 8; ++k) pre[k] = nx2[rec_index(k)];
+                pre_valid = true;
+            }
             int q[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) ok[k] = tsdf_finish(g, c, ok[k], dv[k], zc[k], q[k]);
-            int2 rec[8];
+            if (!PREF) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (ok[k]) rec[k] = (DBG == 4) ? make_int2(q[k], k) : recs2[MAP == 1 ? (k * 64 + lane) : (lb * 64 + k * 8 + la)];
+                for (int k = 0; k < 8; ++k)
+                    if (ok[k]) rec[k] = (DBG == 4) ? make_int2(q[k], k) : recs2[rec_index(k)];
+            }
 #pragma unroll
             for (int k = 0; k < 8; ++k)
                 if (ok[k]) {
                     rec[k].x += q[k];
                     rec[k].y += 1;
                     if (DBG == 4) { if (rec[k].x == 0x7fffffff) recs2[0] = rec[k]; }      // keep the values alive, never store
-                    else recs2[MAP == 1 ? (k * 64 + lane) : (lb * 64 + k * 8 + la)] = rec[k];
-                    if (COUNT) { nread += 1; nwritten += 1; }
+                    else recs2[rec_index(k)] = rec[k];
+                    if (COUNT) { nread += PREF ? 0 : 1; nwritten += 1; }
                 }
+            if (COUNT && PREF) nread += 8;
         }
     }
     if (COUNT) {
@@ -532,27 +582,35 @@ int launch_tsdf_update(hipStream_t s, const Cam &cam, const Grid &g, const PoseF
     const float ax = fabsf(p.r[3]), ay = fabsf(p.r[4]), az = fabsf(p.r[5]);
     int map = (ay >= ax && ay >= az) ? 2 : (az >= ax ? 1 : 0);
     if (force_map >= 0 && force_map <= 2) map = force_map;
-#define TL3D_LAUNCH_UPD(C_, D_, M_)                                                                                              \
+#define TL3D_LAUNCH_UPD(C_, D_, M_, V_)                                                                                            \
     do {                                                                                                                         \
         if (depth_u16)                                                                                                           \
-            hipLaunchKernelGGL((tsdf_integrate_kernel<C_, D_, M_, uint16_t>), dim3(nblk), dim3(256), 0, s, cam, g, p, c,         \
+            hipLaunchKernelGGL((tsdf_integrate_kernel<C_, D_, M_, uint16_t, V_>), dim3(nblk), dim3(256), 0, s, cam, g, p, c,     \
                                static_cast<const uint16_t *>(depth), t.list, t.list_counts, grid, counters);                      \
         else                                                                                                                     \
-            hipLaunchKernelGGL((tsdf_integrate_kernel<C_, D_, M_, float>), dim3(nblk), dim3(256), 0, s, cam, g, p, c,            \
+            hipLaunchKernelGGL((tsdf_integrate_kernel<C_, D_, M_, float, V_>), dim3(nblk), dim3(256), 0, s, cam, g, p, c,        \
                                static_cast<const float *>(depth), t.list, t.list_counts, grid, counters);                         \
     } while (0)
-#define TL3D_LAUNCH_MAP(C_, D_)                        \
-    do {                                               \
-        if (map == 2) TL3D_LAUNCH_UPD(C_, D_, 2);      \
-        else if (map == 1) TL3D_LAUNCH_UPD(C_, D_, 1); \
-        else TL3D_LAUNCH_UPD(C_, D_, 0);               \
+#define TL3D_LAUNCH_MAP(C_, D_, V_)                        \
+    do {                                                   \
+        if (map == 2) TL3D_LAUNCH_UPD(C_, D_, 2, V_);      \
+        else if (map == 1) TL3D_LAUNCH_UPD(C_, D_, 1, V_); \
+        else TL3D_LAUNCH_UPD(C_, D_, 0, V_);               \
     } while (0)
-    if (count) TL3D_LAUNCH_MAP(true, 0);
-    else if (dbg == 1) TL3D_LAUNCH_MAP(false, 1);
-    else if (dbg == 2) TL3D_LAUNCH_MAP(false, 2);
-    else if (dbg == 3) TL3D_LAUNCH_MAP(false, 3);
-    else if (dbg == 4) TL3D_LAUNCH_MAP(false, 4);
-    else TL3D_LAUNCH_MAP(false, 0);
+#define TL3D_LAUNCH_VAR(C_)                         \
+    do {                                            \
+        if (var == 2) TL3D_LAUNCH_MAP(C_, 0, 2);    \
+        else if (var == 1) TL3D_LAUNCH_MAP(C_, 0, 1); \
+        else TL3D_LAUNCH_MAP(C_, 0, 0);             \
+    } while (0)
+    static const int var = getenv("TL3D_TSDF_VARIANT") ? atoi(getenv("TL3D_TSDF_VARIANT")) : 0;
+    if (count) TL3D_LAUNCH_VAR(true);
+    else if (dbg == 1) TL3D_LAUNCH_MAP(false, 1, 0);
+    else if (dbg == 2) TL3D_LAUNCH_MAP(false, 2, 0);
+    else if (dbg == 3) TL3D_LAUNCH_MAP(false, 3, 0);
+    else if (dbg == 4) TL3D_LAUNCH_MAP(false, 4, 0);
+    else TL3D_LAUNCH_VAR(false);
+#undef TL3D_LAUNCH_VAR
 #undef TL3D_LAUNCH_MAP
 #undef TL3D_LAUNCH_UPD
     TL3D_HIP(hipGetLastError());

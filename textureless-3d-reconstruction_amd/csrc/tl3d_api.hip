@@ -93,6 +93,7 @@ static int check_slot(tl3d_ctx *ctx, int slot, bool need_loaded) {
 
 static int upload_impl(tl3d_ctx *ctx, int slot, const void *depth_hd, int depth_kind, const uint8_t *bgr_hd, bool wait);
 static void icp_lane_free(tl3d_ctx::IcpLane &ln);
+static int bp_check_error(tl3d_ctx *ctx, unsigned long long err);
 static int flush_updates(tl3d_ctx *ctx);
 // every call that reads or writes the TSDF grid, re-uses a frame slot, synchronises or time-stamps first issues the deferred updates
 #define FLUSH_UPDATES(ctx_)                      \
@@ -288,6 +289,14 @@ int tl3d_create(const tl3d_config *cfg, int device, tl3d_ctx **out) {
     if (hipMalloc(&ctx->d_cen_counters, 256 * 8 * sizeof(unsigned long long)) != hipSuccess) return fail(set_err(TL3D_E_NOMEM, "alloc failed"));
     if (hipMemsetAsync(ctx->d_cen_counters, 0, 256 * 8 * sizeof(unsigned long long), ctx->stream) != hipSuccess) return fail(set_err(TL3D_E_HIP, "memset failed"));
     if (hipMalloc(&ctx->bounds_slab, 1024 * 6 * sizeof(float)) != hipSuccess) return fail(set_err(TL3D_E_NOMEM, "alloc failed"));
+    {   // projection-factor tables: the two cached maps of the reference (D2R:287-295) are separable, so W + H doubles hold
+        // them; computed on the host with the same fp64 expression the kernels used per pixel
+        std::vector<double> f((size_t)c.W + c.H);
+        for (int u = 0; u < c.W; ++u) f[u] = ((double)u - c.cxd) / c.fxd;
+        for (int v = 0; v < c.H; ++v) f[(size_t)c.W + v] = ((double)v - c.cyd) / c.fyd;
+        if (hipMalloc(&ctx->bp_factors, f.size() * sizeof(double)) != hipSuccess) return fail(set_err(TL3D_E_NOMEM, "alloc failed"));
+        if (hipMemcpy(ctx->bp_factors, f.data(), f.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(set_err(TL3D_E_HIP, "copy failed"));
+    }
     for (int i = 0; i < 2; ++i)
         if (hipEventCreate(&ctx->ev[i]) != hipSuccess) return fail(set_err(TL3D_E_HIP, "event create failed"));
     (void)rc;
@@ -324,6 +333,10 @@ int tl3d_destroy(tl3d_ctx *ctx) {
         if (ctx->prep_stream[q]) (void)hipStreamDestroy(ctx->prep_stream[q]);
     if (ctx->block_counts) (void)hipFree(ctx->block_counts);
     if (ctx->block_offsets) (void)hipFree(ctx->block_offsets);
+    if (ctx->bp_state) (void)hipFree(ctx->bp_state);
+    if (ctx->bp_factors) (void)hipFree(ctx->bp_factors);
+    if (ctx->bp_stage_xyz) (void)hipFree(ctx->bp_stage_xyz);
+    if (ctx->bp_stage_rgb) (void)hipFree(ctx->bp_stage_rgb);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->d_cen_counters) (void)hipFree(ctx->d_cen_counters);
     if (ctx->d_maxw) (void)hipFree(ctx->d_maxw);
@@ -356,6 +369,13 @@ int tl3d_sync(tl3d_ctx *ctx) {
     for (int l = 0; l < TL3D_ICP_LANES; ++l)
         if (ctx->icp_lanes[l].stream) TL3D_HIP(hipStreamSynchronize(ctx->icp_lanes[l].stream));
     TL3D_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->bp_async_pending && ctx->bp_state) {
+        ctx->bp_async_pending = false;
+        unsigned long long err = 0;
+        TL3D_HIP(hipMemcpy(&err, ctx->bp_state + 1, sizeof(err), hipMemcpyDeviceToHost));
+        const int erc = bp_check_error(ctx, err);
+        if (erc) return erc;
+    }
     return TL3D_OK;
 }
 
@@ -470,6 +490,31 @@ static int make_bp_args(tl3d_ctx *ctx, double scale, uint32_t flags, int subsamp
     return TL3D_OK;
 }
 
+// scratch of the one-launch back-projection (layout: kernels_backproject.hip), + one word at the end for the total.  Zeroed
+// here once; every launch leaves it zero again (the tile that finishes last re-arms it), except the error word.
+static int bp_ensure_state(tl3d_ctx *ctx, const BpArgs &a) {
+    const size_t need = (size_t)bp_state_words(a) + 2;
+    if (need <= ctx->bp_state_words) return TL3D_OK;
+    if (ctx->bp_state) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(ctx->bp_state);
+    }
+    ctx->bp_state = nullptr;
+    ctx->bp_state_words = 0;
+    const size_t words = need * 2;                                  // headroom: a later, larger subsample-1 call re-uses it
+    if (hipMalloc(&ctx->bp_state, words * sizeof(unsigned long long)) != hipSuccess) return set_err(TL3D_E_NOMEM, "back-projection scratch alloc failed");
+    if (hipMemsetAsync(ctx->bp_state, 0, words * sizeof(unsigned long long), ctx->stream) != hipSuccess) return set_err(TL3D_E_HIP, "memset failed");
+    ctx->bp_state_words = words;
+    return TL3D_OK;
+}
+
+// a look-back time-out leaves the scratch in an unknown state: report it and start from zeroes again
+static int bp_check_error(tl3d_ctx *ctx, unsigned long long err) {
+    if (err == 0) return TL3D_OK;
+    (void)hipMemsetAsync(ctx->bp_state, 0, ctx->bp_state_words * sizeof(unsigned long long), ctx->stream);
+    return set_err(TL3D_E_HIP, "back-projection look-back timed out (a predecessor tile never published)");
+}
+
 int tl3d_backproject(tl3d_ctx *ctx, int slot, const double R[9], const double t[3], double scale, uint32_t flags,
                      int subsample, double min_depth, double max_depth, float *out_xyz, uint8_t *out_rgb, int64_t cap,
                      int64_t *out_n) {
@@ -482,41 +527,72 @@ int tl3d_backproject(tl3d_ctx *ctx, int slot, const double R[9], const double t[
     if (rc) return rc;
     TL3D_HIP(hipSetDevice(ctx->device));
     const Slot &s = ctx->slots[slot];
-    const long long ns = (long long)a.Ws * a.Hs;
-    const int nblocks = (int)((ns + 255) / 256);
-    ctx->ext_valid = false;                             // the block-count scratch is shared with tl3d_extract
-    rc = ensure_scratch_blocks(ctx, (size_t)nblocks + 1);
+    rc = bp_ensure_state(ctx, a);
     if (rc) return rc;
-    rc = launch_bp_count(ctx->stream, ctx->cam, a, s.depth, ctx->block_counts, nblocks);
-    if (rc) return rc;
-    rc = launch_scan(ctx->stream, ctx->block_counts, ctx->block_offsets, nblocks, ctx->block_offsets + nblocks);
-    if (rc) return rc;
-    unsigned long long total = 0;
-    TL3D_HIP(hipMemcpyAsync(&total, ctx->block_offsets + nblocks, sizeof(total), hipMemcpyDeviceToHost, ctx->stream));
-    TL3D_HIP(hipStreamSynchronize(ctx->stream));
-    *out_n = (int64_t)total;
-    if (!out_xyz || !out_rgb) return TL3D_OK;                       // size query
-    if ((int64_t)total > cap) return set_err(TL3D_E_CAPACITY, "need %llu points, capacity %lld", total, (long long)cap);
-    if (total == 0) return TL3D_OK;
+    unsigned long long *d_total = ctx->bp_state + (ctx->bp_state_words - 1);
     const PoseD p = make_pose_d(R, t, (flags & TL3D_F_NO_POSE) != 0);
-    const bool direct = is_device_ptr(out_xyz) && is_device_ptr(out_rgb);
+    const bool want = out_xyz && out_rgb;
+    const bool direct = want && is_device_ptr(out_xyz) && is_device_ptr(out_rgb);
+    const unsigned long long ns = (unsigned long long)a.Ws * (unsigned long long)a.Hs;
+    unsigned long long cap_eff = cap < 0 ? 0ull : (unsigned long long)cap;
     float *dxyz = out_xyz;
     uint8_t *drgb = out_rgb;
-    if (!direct) {
-        if (hipMalloc(&dxyz, total * 3 * sizeof(float)) != hipSuccess) return set_err(TL3D_E_NOMEM, "output staging alloc failed");
-        if (hipMalloc(&drgb, total * 3) != hipSuccess) { (void)hipFree(dxyz); return set_err(TL3D_E_NOMEM, "output staging alloc failed"); }
+    if (want && !direct) {
+        // host outputs: stage on the device (buffers kept for the life of the context, sized for a full frame)
+        const size_t npx = (size_t)ctx->cam.W * ctx->cam.H;
+        if (!ctx->bp_stage_xyz && hipMalloc(&ctx->bp_stage_xyz, npx * 3 * sizeof(float)) != hipSuccess) return set_err(TL3D_E_NOMEM, "output staging alloc failed");
+        if (!ctx->bp_stage_rgb && hipMalloc(&ctx->bp_stage_rgb, npx * 3) != hipSuccess) return set_err(TL3D_E_NOMEM, "output staging alloc failed");
+        dxyz = ctx->bp_stage_xyz;
+        drgb = ctx->bp_stage_rgb;
+        if (cap_eff > ns) cap_eff = ns;
     }
-    rc = launch_bp_write(ctx->stream, ctx->cam, a, p, s.depth, s.has_color ? s.bgr : nullptr, ctx->block_offsets, nblocks, dxyz, drgb, total);
-    hipError_t e = hipSuccess;
-    if (rc == TL3D_OK && !direct) {
-        e = hipMemcpyAsync(out_xyz, dxyz, total * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(out_rgb, drgb, total * 3, hipMemcpyDeviceToHost, ctx->stream);
+    // ONE launch: count, ordered offsets (decoupled look-back) and LDS-staged writes; without buffers: the count only.
+    // A look-back time-out (static tile order and a predecessor that never got a slot: see launch_bp_fused) is repeated
+    // once in dynamic order, which cannot starve.
+    unsigned long long h[2] = {0, 0};
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        rc = launch_bp_fused(ctx->stream, ctx->cam, a, p, s.depth, s.has_color ? s.bgr : nullptr, ctx->bp_factors, ctx->bp_factors + ctx->cam.W,
+                             ctx->bp_state, want ? dxyz : nullptr, want ? drgb : nullptr, cap_eff, d_total, attempt == 1);
+        if (rc) return rc;
+        TL3D_HIP(hipMemcpyAsync(&h[0], d_total, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+        TL3D_HIP(hipMemcpyAsync(&h[1], ctx->bp_state + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+        TL3D_HIP(hipStreamSynchronize(ctx->stream));
+        rc = bp_check_error(ctx, h[1]);
+        if (rc == TL3D_OK) break;
+        if (attempt == 1) return rc;
     }
-    hipError_t e2 = hipStreamSynchronize(ctx->stream);
-    if (!direct) { (void)hipFree(dxyz); (void)hipFree(drgb); }
-    if (rc) return rc;
-    if (e != hipSuccess || e2 != hipSuccess) return set_err(TL3D_E_HIP, "back-projection copy/sync failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+    const unsigned long long total = h[0];
+    *out_n = (int64_t)total;
+    if (!want) return TL3D_OK;                                      // size query
+    if ((int64_t)total > cap) return set_err(TL3D_E_CAPACITY, "need %llu points, capacity %lld", total, (long long)cap);
+    if (total == 0 || direct) return TL3D_OK;
+    TL3D_HIP(hipMemcpyAsync(out_xyz, dxyz, total * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    TL3D_HIP(hipMemcpyAsync(out_rgb, drgb, total * 3, hipMemcpyDeviceToHost, ctx->stream));
+    TL3D_HIP(hipStreamSynchronize(ctx->stream));
     return TL3D_OK;
+}
+
+int tl3d_backproject_device(tl3d_ctx *ctx, int slot, const double R[9], const double t[3], double scale, uint32_t flags,
+                            int subsample, double min_depth, double max_depth, float *out_xyz_dev, uint8_t *out_rgb_dev,
+                            int64_t cap, int64_t *out_n_dev) {
+    int rc = check_slot(ctx, slot, true);
+    if (rc) return rc;
+    REQUIRE(out_xyz_dev && out_rgb_dev && out_n_dev, TL3D_E_INVALID, "null output pointer");
+    REQUIRE(is_device_ptr(out_xyz_dev) && is_device_ptr(out_rgb_dev) && is_device_ptr(out_n_dev), TL3D_E_INVALID,
+            "tl3d_backproject_device writes device memory only");
+    REQUIRE(cap >= 0, TL3D_E_INVALID, "negative capacity");
+    REQUIRE((flags & TL3D_F_NO_POSE) || (R && t), TL3D_E_INVALID, "pose required unless TL3D_F_NO_POSE");
+    BpArgs a;
+    rc = make_bp_args(ctx, scale, flags, subsample, min_depth, max_depth, &a);
+    if (rc) return rc;
+    TL3D_HIP(hipSetDevice(ctx->device));
+    const Slot &s = ctx->slots[slot];
+    rc = bp_ensure_state(ctx, a);
+    if (rc) return rc;
+    const PoseD p = make_pose_d(R, t, (flags & TL3D_F_NO_POSE) != 0);
+    ctx->bp_async_pending = true;                       // tl3d_sync reports a look-back time-out of these launches
+    return launch_bp_fused(ctx->stream, ctx->cam, a, p, s.depth, s.has_color ? s.bgr : nullptr, ctx->bp_factors, ctx->bp_factors + ctx->cam.W,
+                           ctx->bp_state, out_xyz_dev, out_rgb_dev, (unsigned long long)cap, reinterpret_cast<unsigned long long *>(out_n_dev));
 }
 
 // ------------------------------------------------------------------------------------------- centroid accumulation
@@ -755,6 +831,7 @@ int tl3d_download_normals(tl3d_ctx *ctx, int slot, float *out) {
 
 static void icp_lane_free(tl3d_ctx::IcpLane &ln) {
     if (ln.slab) (void)hipFree(ln.slab);
+    if (ln.ticket) (void)hipFree(ln.ticket);
     if (ln.state) (void)hipFree(ln.state);
     if (ln.graph) (void)hipGraphExecDestroy(ln.graph);
     if (ln.host) (void)hipHostFree(ln.host);
@@ -771,6 +848,7 @@ static int icp_lane_init(tl3d_ctx *ctx, int lane) {
     if (ln.stream) return TL3D_OK;
     bool ok = hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipMalloc(&ln.slab, (size_t)ICP_MAX_BLOCKS * ICP_SLAB * sizeof(double)) == hipSuccess;
+    ok = ok && hipMalloc(&ln.ticket, 64) == hipSuccess;
     ok = ok && hipMalloc(&ln.state, sizeof(IcpState)) == hipSuccess;
     ok = ok && hipHostMalloc(&ln.host, sizeof(IcpState), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipMalloc(&ln.run, sizeof(IcpRun)) == hipSuccess;
@@ -839,9 +917,10 @@ int tl3d_icp_enqueue(tl3d_ctx *ctx, int lane, int slot_src, double scale_src, in
         TL3D_HIP(hipStreamBeginCapture(ln.stream, hipStreamCaptureModeThreadLocal));
         hipError_t ce = hipMemcpyAsync(ln.run, ln.run_host, sizeof(IcpRun), hipMemcpyHostToDevice, ln.stream);
         if (ce == hipSuccess) ce = hipMemcpyAsync(ln.state, ln.host, sizeof(IcpState), hipMemcpyHostToDevice, ln.stream);
+        if (ce == hipSuccess) ce = hipMemsetAsync(ln.ticket, 0, 64, ln.stream);      // polled words are re-armed by every replay
         int lrc = TL3D_OK;
         for (int it = 0; ce == hipSuccess && lrc == TL3D_OK && it <= prm->iters; ++it)
-            lrc = launch_icp_iteration(ln.stream, ctx->cam, ln.run, it == prm->iters, ln.slab, ln.state, ICP_MAX_BLOCKS);
+            lrc = launch_icp_iteration(ln.stream, ctx->cam, ln.run, it == prm->iters, ln.slab, ln.state, ICP_MAX_BLOCKS, ln.ticket);
         if (ce == hipSuccess && lrc == TL3D_OK) ce = hipMemcpyAsync(ln.host, ln.state, sizeof(IcpState), hipMemcpyDeviceToHost, ln.stream);
         hipError_t ee = hipStreamEndCapture(ln.stream, &g);
         if (ce != hipSuccess || ee != hipSuccess || lrc != TL3D_OK || !g) {

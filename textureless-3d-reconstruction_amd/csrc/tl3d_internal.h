@@ -117,6 +117,12 @@ struct tl3d_ctx {
     int ext_mode, ext_min_count, ext_min_weight;
     double ext_max_abs;
     bool ext_valid;
+    unsigned long long *bp_state;        // one-launch back-projection: ticket, error word, per-tile granules, [bp_state_words - 1] = total
+    size_t bp_state_words;
+    float *bp_stage_xyz;                 // staging for host-side outputs, sized for a full frame at subsample 1
+    uint8_t *bp_stage_rgb;
+    bool bp_async_pending;
+    double *bp_factors;                  // projection factors (D2R:287-295): [0, W) xf[u] = (u - cx) / fx, [W, W + H) yf[v] = (v - cy) / fy
     unsigned *block_counts;      // compaction counts
     unsigned long long *block_offsets;
     size_t scratch_blocks;
@@ -131,11 +137,12 @@ struct tl3d_ctx {
     struct IcpLane {             // one in-flight ICP run: own stream, device state, partial-sum slab, pinned read-back
         hipStream_t stream;
         double *slab;            // [ICP_MAX_BLOCKS][ICP_SLAB]
+        unsigned *ticket;        // arrival counter of the iteration kernel (64-B block of its own; 0 between launches)
         tl3d::IcpState *state;
         tl3d::IcpState *host;    // pinned: initial state in, final state out
         tl3d::IcpRun *run;       // device descriptor of the current run
         tl3d::IcpRun *run_host;  // pinned
-        hipGraphExec_t graph;    // captured chain: descriptor + state upload, (iters+1) x (reduce, solve), state download
+        hipGraphExec_t graph;    // captured chain: descriptor + state upload, ticket re-arm, (iters+1) iteration kernels, state download
         int graph_iters;
         bool busy;               // a run was enqueued and not collected yet
         hipEvent_t ev_done;      // recorded on the lane's stream behind the run: writers of the slots it reads wait on it
@@ -176,10 +183,12 @@ __device__ __forceinline__ size_t vox_index(int i, int j, int k, int nbx, int nb
 // frames
 int launch_u16_to_f32(hipStream_t s, const uint16_t *in, float *out, size_t n);
 // back-projection
-int launch_bp_count(hipStream_t s, const Cam &cam, const BpArgs &a, const float *depth, unsigned *block_counts, int nblocks);
 int launch_scan(hipStream_t s, const unsigned *counts, unsigned long long *offsets, int n, unsigned long long *total);
-int launch_bp_write(hipStream_t s, const Cam &cam, const BpArgs &a, const PoseD &p, const float *depth, const uint8_t *bgr,
-                    const unsigned long long *offsets, int nblocks, float *xyz, uint8_t *rgb, unsigned long long cap);
+int bp_fused_tiles(const BpArgs &a);
+int bp_state_words(const BpArgs &a);
+int launch_bp_fused(hipStream_t s, const Cam &cam, const BpArgs &a, const PoseD &p, const float *depth, const uint8_t *bgr,
+                    const double *xf, const double *yf, unsigned long long *state, float *xyz, uint8_t *rgb, unsigned long long cap,
+                    unsigned long long *total_out, bool force_dynamic = false);
 // centroid
 int launch_centroid_frame(hipStream_t s, const Cam &cam, const Grid &g, const BpArgs &a, const PoseD &p, const float *depth,
                           const uint8_t *bgr, unsigned long long *grid, unsigned long long *counters);
@@ -194,7 +203,8 @@ int launch_tsdf_update(hipStream_t s, const Cam &cam, const Grid &g, const PoseF
                        float maxd, int2 *grid, void *scratch, unsigned long long *counters, bool count);
 // normals + icp
 int launch_normals(hipStream_t s, const Cam &cam, const float *depth, float scale, float mind, float maxd, float jump, float4 *nmap);
-int launch_icp_iteration(hipStream_t s, const Cam &cam, const IcpRun *run, int final_pass, double *slab, IcpState *state, int nblocks);
+int launch_icp_iteration(hipStream_t s, const Cam &cam, const IcpRun *run, int final_pass, double *slab, IcpState *state, int nblocks,
+                         unsigned *ticket);
 // extraction
 int launch_extract_count(hipStream_t s, const Grid &g, int mode, int min_count, int min_weight, double max_abs,
                          const int2 *tsdf, const unsigned long long *cen, unsigned *block_counts, int nblocks);

@@ -92,3 +92,120 @@ def allreduce_context_grids(ctx, dist) -> None:
     if ctx.grid.channels & abi.CH_CENTROID:
         dist.all_reduce(ctx.grid_tensor(abi.CH_CENTROID))
     torch.cuda.synchronize()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# product path: DepthToReconstructionPipeline.reconstruct_sharded (pipeline.py) is built from these
+# ---------------------------------------------------------------------------------------------------------------------
+_COLS = 24          # 16 T | against | ok | fitness | rmse | n_corr | iters_run | status | present
+
+
+def _world(dist):
+    return 1 if dist is None or not dist.is_initialized() else dist.get_world_size()
+
+
+def _reduce(t, dist, op=None):
+    """all_reduce of a CPU tensor through whatever backend the group has (RCCL wants it on the GPU)."""
+    import torch
+    if _world(dist) == 1:
+        return t
+    if dist.get_backend() == "nccl":
+        d = t.to(torch.device("cuda", torch.cuda.current_device()))
+        dist.all_reduce(d, op=op if op is not None else dist.ReduceOp.SUM)
+        return d.cpu()
+    dist.all_reduce(t, op=op if op is not None else dist.ReduceOp.SUM)
+    return t
+
+
+def exchange_registrations(local: dict, n_frames: int, dist=None, into: dict = None):
+    """local: {curr: result dict of FusionContext.icp_collect + 'against'} for the pairs THIS rank registered.  Every rank
+    gets the union (disjoint rows of one small tensor, sum = gather).  Returns the table {curr: entry}; with `into`, the
+    received rows replace the table's and the return value tells whether anything arrived."""
+    import torch
+    buf = torch.zeros((n_frames, _COLS), dtype=torch.float64)
+    for cur, r in local.items():
+        row = buf[cur]
+        row[:16] = torch.from_numpy(np.ascontiguousarray(np.asarray(r["T"], np.float64).reshape(16)))
+        ok = not (r["status"] == 2 or r["n_corr"] < 8)
+        row[16:24] = torch.tensor([float(r["against"]), float(ok), float(r["fitness"]), float(r["rmse"]), float(r["n_corr"]),
+                                   float(r["iters_run"]), float(r["status"]), 1.0], dtype=torch.float64)
+    buf = _reduce(buf, dist).numpy()
+    table = {} if into is None else into
+    got = False
+    for cur in range(n_frames):
+        if buf[cur, 23] > 0.5:
+            got = True
+            table[cur] = dict(T=buf[cur, :16].reshape(4, 4).copy(), against=int(buf[cur, 16]), ok=bool(buf[cur, 17] > 0.5), fitness=float(buf[cur, 18]),
+                              rmse=float(buf[cur, 19]), n_corr=int(buf[cur, 20]), iters_run=int(buf[cur, 21]), status=int(buf[cur, 22]))
+    return got if into is not None else table
+
+
+def resolve_chain(table: dict, n_frames: int):
+    """The reference's skip rule (D2R:598-615) applied to a table of pair registrations: frames are visited in order; a
+    frame must have been registered against the LAST KEPT frame; a failed registration drops the frame.  Returns (kept frame
+    indices, (want, curr) of the first frame that still has to be re-registered or None).  Pure function of the table, so
+    every rank takes the same decisions."""
+    kept = [0]
+    for cur in range(1, n_frames):
+        e = table.get(cur)
+        if e is None or e["against"] != kept[-1]:
+            return kept, (kept[-1], cur)
+        if e["ok"]:
+            kept.append(cur)
+    return kept, None
+
+
+def chain_from_table(table: dict, n_frames: int):
+    """(poses, frame_index, log) of the kept frames: cam0 = (I, 0), then R = R_rel R_prev, t = R_rel t_prev + t_rel (D2R:618-620)."""
+    kept, redo = resolve_chain(table, n_frames)
+    assert redo is None, "chain_from_table needs a resolved table"
+    pose = {0: (np.eye(3), np.zeros((3, 1)))}
+    log = []
+    for cur in range(1, n_frames):
+        e = table[cur]
+        log.append(dict(frame=cur, against=e["against"], fitness=e["fitness"], rmse=e["rmse"], n_corr=e["n_corr"], iters_run=e["iters_run"],
+                        status=e["status"], dropped=not e["ok"]))
+        if e["ok"]:
+            r_prev, t_prev = pose[e["against"]]
+            T = e["T"]
+            pose[cur] = (T[:3, :3] @ r_prev, T[:3, :3] @ t_prev + T[:3, 3:4])
+    return [pose[k] for k in kept], kept, log
+
+
+def allreduce_bounds(mn, mx, dist=None):
+    """Scene bounds over all ranks (exact: MIN / MAX), so that every rank plans the same grid."""
+    import torch
+    if _world(dist) == 1:
+        return np.asarray(mn, np.float64), np.asarray(mx, np.float64)
+    lo = _reduce(torch.from_numpy(np.asarray(mn, np.float64).copy()), dist, dist.ReduceOp.MIN).numpy()
+    hi = _reduce(torch.from_numpy(np.asarray(mx, np.float64).copy()), dist, dist.ReduceOp.MAX).numpy()
+    return lo, hi
+
+
+def allreduce_counts(values, dist=None):
+    import torch
+    t = _reduce(torch.tensor([int(v) for v in values], dtype=torch.int64), dist)
+    return [int(v) for v in t.tolist()]
+
+
+def merge_context_grids(ctx, dist=None) -> None:
+    """Sum the per-rank grids into every rank's grid.  nccl backend: RCCL all-reduce on the library's own grid memory
+    (zero-copy views, xGMI); any other backend (gloo: tests, two processes on one GPU): download -> host all-reduce ->
+    upload.  Integer sums: the result does not depend on the backend, the rank count or the order."""
+    if _world(dist) == 1:
+        return
+    if dist.get_backend() == "nccl":
+        allreduce_context_grids(ctx, dist)
+        return
+    import torch
+    if ctx.grid.channels & abi.CH_TSDF:
+        w = _reduce(torch.tensor([ctx.max_weight()], dtype=torch.int64), dist)
+        if int(w.item()) > abi.TSDF_MAX_WEIGHT:
+            raise OverflowError(f"merged TSDF grid could hold {int(w.item())} observations per voxel (limit {abi.TSDF_MAX_WEIGHT})")
+        g = ctx.download_grid(abi.CH_TSDF)
+        allreduce_grid_arrays(tsdf=g, dist=dist)
+        ctx.upload_grid(abi.CH_TSDF, g)
+    if ctx.grid.channels & abi.CH_CENTROID:
+        g = ctx.download_grid(abi.CH_CENTROID)
+        allreduce_grid_arrays(centroid=g, dist=dist)
+        ctx.upload_grid(abi.CH_CENTROID, g)

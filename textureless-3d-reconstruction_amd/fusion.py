@@ -185,6 +185,17 @@ class FusionContext:
                                              int(subsample), mn, mx, abi.ptr(xyz), abi.ptr(rgb), cap, C.byref(n)))
         return xyz[:n.value], rgb[:n.value]
 
+    def backproject_device(self, slot: int, out_xyz, out_rgb, out_n, pose=None, scale=1.0, subsample: int = 1,
+                           min_depth=None, max_depth=None, scale_f64: bool = False, cap=None):
+        """Asynchronous, device-only form: out_xyz (float32 [cap,3]), out_rgb (uint8 [cap,3]) and out_n (int64 [1]) are
+        device tensors (anything with data_ptr()); nothing is read back, the call returns once its kernel is enqueued."""
+        r, t, flags = self._pose_args(pose, abi.F_SCALE_F64 if scale_f64 else 0)
+        mn = self.min_depth if min_depth is None else float(min_depth)
+        mx = self.max_depth if max_depth is None else float(max_depth)
+        cap = int(out_xyz.shape[0]) if cap is None else int(cap)
+        abi.check(self._lib.tl3d_backproject_device(self._h, int(slot), abi.ptr(r), abi.ptr(t), float(scale), flags, int(subsample),
+                                                    mn, mx, abi.ptr(out_xyz), abi.ptr(out_rgb), cap, abi.ptr(out_n)))
+
     # ---- fusion ----------------------------------------------------------------------------
     def accumulate_centroid(self, slot: int, pose=None, scale=1.0, subsample: int = 1, min_depth=None, max_depth=None,
                             scale_f64: bool = False):

@@ -342,5 +342,163 @@ class DepthToReconstructionPipeline:
         print(f"\nFinal reconstruction: {len(xyz)} points, {len(self.camera_poses)} cameras")
         return xyz.astype(np.float64), rgb, self.camera_poses
 
+    # ---- multi-GPU: frames shard across ranks, one exchange step at merge time -------------
+    def _register_pairs(self, ctx: FusionContext, pairs, slot_of, scales, init_poses=None, T_guess=None):
+        """Independent registrations (src, cur) -> result dict, `lanes` at a time, every pair through the coarse-to-fine
+        levels.  slot_of maps a global frame index to its resident slot."""
+        cfg = self.config
+        levels = [tuple(l) for l in cfg.icp_coarse] + [(cfg.icp_iters, cfg.icp_stride, cfg.icp_max_dist)]
+        common = dict(damping=cfg.icp_damping, eig_rel=cfg.icp_eig_rel, eps=cfg.icp_eps)
+        out = {}
+        lanes = abi.ICP_LANES
+
+        def prior(a, b_):
+            if init_poses is None:
+                return np.eye(4) if T_guess is None else T_guess
+            r0, t0 = init_poses[a]
+            r1, t1 = init_poses[b_]
+            rr = np.asarray(r1) @ np.asarray(r0).T
+            T = np.eye(4)
+            T[:3, :3], T[:3, 3] = rr, (np.asarray(t1).reshape(3) - rr @ np.asarray(t0).reshape(3))
+            return T
+
+        for i0 in range(0, len(pairs), lanes):
+            batch = pairs[i0:i0 + lanes]
+            T0s = [prior(a, b_) for a, b_ in batch]
+            results = [None] * len(batch)
+            for li, lv in enumerate(levels):
+                live = [k for k in range(len(batch)) if li == 0 or not (results[k]["status"] == 2 or results[k]["n_corr"] < 8)]
+                for k in live:
+                    a, b_ = batch[k]
+                    ctx.icp_enqueue(k, slot_of[a], slot_of[b_], T_init=T0s[k], scale_src=scales[a], iters=int(lv[0]), stride=int(lv[1]),
+                                    max_dist=float(lv[2]), **common)
+                for k in live:
+                    results[k] = ctx.icp_collect(k)
+                    T0s[k] = results[k]["T"]
+            for (a, b_), res in zip(batch, results):
+                out[b_] = dict(res, against=a)
+        return out
+
+    def reconstruct_sharded(self, dist, grid: Optional[GridSpec] = None, init_poses=None, poses=None, anchors=None):
+        """reconstruct() over the ranks of an initialised torch.distributed group, one process per GPU:
+
+          1. rank r uploads its contiguous frame range [lo, hi) plus the one-frame halo lo - 1 and registers every pair whose
+             later frame it owns (the pair that crosses a shard boundary belongs to the later rank), on its ICP lanes;
+          2. the relative transforms are exchanged (a few hundred bytes) and every rank chains the same global poses with
+             the same fp64 products as D2R:618-620; a frame whose registration failed is dropped and its successor is
+             re-registered against the last kept frame by the successor's owner (the reference's skip rule, D2R:598-615);
+          3. scene bounds: per-rank min / max, MIN / MAX all-reduce -> every rank plans the same grid;
+          4. rank r fuses its own frames into its private grid;
+          5. ONE sum all-reduce of the integer grids (RCCL over xGMI with the nccl backend) -> every rank holds the merged
+             grid, bit-identical to a single-GPU run; rank 0 extracts, filters and returns the cloud (other ranks return
+             (None, None, poses)).
+        Every frame must be loaded on every rank's host (load_data); only the rank's own range goes to its GPU."""
+        from . import distributed as dd
+        world, rank = dist.get_world_size(), dist.get_rank()
+        if len(self.images) < 2:
+            print("Need at least 2 images")
+            return None, None, None
+        if getattr(self, "_files", None) is not None:
+            raise ValueError("reconstruct_sharded needs load_data(): frames decoded on the host of every rank")
+        cfg = self.config
+        n = len(self.depths)
+        h, w = self.depths[0].shape
+        lo, hi = dd.shard_range(n, world, rank)
+        first = max(0, lo - 1) if hi > lo else lo                  # halo frame in front of the range
+        resident = list(range(first, hi))
+        slot_of = {g: k for k, g in enumerate(resident)}
+        say = print if rank == 0 else (lambda *a, **k: None)
+        say("\n" + "=" * 70)
+        say(f"DEPTH-ENHANCED RECONSTRUCTION PIPELINE (MI355X x{world}: ICP + voxel fusion, frames sharded by rank)")
+        say("=" * 70)
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO() if rank else None) if rank else contextlib.nullcontext():
+            self.scales = per_frame_scales(self.depths, anchors, default=float(cfg.depth_scale))
+        spare = len(resident)                                       # one more slot for out-of-range sources of repairs
+        ctx = FusionContext(w, h, cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.min_depth, cfg.max_depth, n_slots=len(resident) + 1, grid=None,
+                            device=cfg.device)
+        try:
+            for g in resident:
+                ctx.upload(slot_of[g], self.depths[g], self.images[g])
+            if poses is not None:
+                self.camera_poses, self.frame_index = list(poses), list(range(len(poses)))
+            else:
+                say("\n--- Step 1: Register frames (point-to-plane ICP, frame to frame, pairs sharded by rank) ---")
+                for g in resident:
+                    ctx.build_normals(slot_of[g], scale=self.scales[g])
+                own = [(a, b_) for a, b_ in dd.pairs_for_rank(n, world, rank)]
+                local = self._register_pairs(ctx, own, slot_of, self.scales, init_poses)
+                table = dd.exchange_registrations(local, n, dist)             # every rank: {cur: T, against, ok, statistics}
+                # the reference's skip rule: a failed frame is dropped and its successor is re-registered against the last
+                # kept frame -- by the successor's owner, one exchange per repair (failures are rare); every rank takes the
+                # same decisions from the same table
+                for _ in range(n):
+                    kept, redo = dd.resolve_chain(table, n)
+                    if redo is None:
+                        break
+                    want, cur = redo
+                    fixed = {}
+                    if lo <= cur < hi:
+                        src_slot = slot_of
+                        if want not in slot_of:                               # the source frame lives on another rank's GPU: bring it here
+                            ctx.upload(spare, self.depths[want], self.images[want])
+                            src_slot = dict(slot_of, **{want: spare})
+                        fixed = self._register_pairs(ctx, [(want, cur)], src_slot, self.scales, init_poses)
+                    dd.exchange_registrations(fixed, n, dist, into=table)
+                self.camera_poses, self.frame_index, self.icp_log = dd.chain_from_table(table, n)
+                for e in self.icp_log:
+                    say(f"\nProcessing image {e['frame']}...")
+                    if e["dropped"]:
+                        say(f"  Skipping - registration failed (correspondences: {e['n_corr']})")
+                    else:
+                        say(f"  ICP: fitness {e['fitness']:.3f}, rmse {e['rmse'] * 1e3:.2f} mm, {e['iters_run']} iterations")
+            if len(self.camera_poses) < 2:
+                say("Pose estimation failed")
+                return None, None, None
+            pose_of = dict(zip(self.frame_index, self.camera_poses))
+            mine = [g for g in range(lo, hi) if g in pose_of]
+            if grid is None:
+                say("\n--- Step 2: Bound the scene ---")
+                mn, mx = np.full(3, np.inf), np.full(3, -np.inf)
+                for g in mine:
+                    pts, _ = ctx.backproject(slot_of[g], pose=pose_of[g], scale=self.scales[g], subsample=cfg.subsample_factor)
+                    if len(pts):
+                        mn, mx = np.minimum(mn, pts.min(0)), np.maximum(mx, pts.max(0))
+                mn, mx = dd.allreduce_bounds(mn, mx, dist)
+                if not np.all(np.isfinite(mn)):
+                    say("Reconstruction failed")
+                    return None, None, None
+                grid, clipped = plan_grid(mn, mx, cfg.voxel_size, cfg.grid_dim, trunc_voxels=cfg.sdf_trunc_voxels)
+                if clipped:
+                    say(f"  Warning: scene extent {np.round(mx - mn, 3)} m at {cfg.voxel_size} m voxels exceeds the budget of "
+                        f"{cfg.grid_dim}^3 voxels; the grid {grid.dims} is centred on the scene and points outside it are dropped "
+                        "(raise --grid or --voxel-size)")
+            say(f"  Grid {grid.dims} @ {grid.voxel_size * 1e3:g} mm, origin {np.round(grid.origin, 4)}")
+            self.grid = grid
+            ctx.attach_grid(grid)
+            say(f"\n--- Step 3: Fuse depth frames (TSDF + voxel centroids), {len(mine)} of {len(pose_of)} on this rank ---")
+            for g in mine:
+                if grid.channels & abi.CH_TSDF:
+                    ctx.integrate(slot_of[g], pose_of[g], scale=self.scales[g])
+                ctx.accumulate_centroid(slot_of[g], pose_of[g], scale=self.scales[g], subsample=cfg.subsample_factor)
+            say("\n--- Step 4: Merge the per-GPU grids (integer sum all-reduce) ---")
+            dd.merge_context_grids(ctx, dist)
+            st = ctx.stats()
+            tot = dd.allreduce_counts([st["centroid_points"], st["centroid_dropped"]], dist)
+            xyz = rgb = None
+            if rank == 0:
+                say("\n--- Step 5: Extract and clean point cloud ---")
+                xyz, rgb = ctx.extract(abi.EXTRACT_CENTROID, min_count=1, min_weight=cfg.tsdf_min_weight, max_abs_tsdf=cfg.tsdf_max_abs)
+                n_vox = len(xyz)
+                if len(xyz) > 0 and cfg.outlier_filter:
+                    keep = ctx.statistical_outlier(xyz, cfg.outlier_nb_neighbors, cfg.outlier_std_ratio, cell_size=2.0 * grid.voxel_size)
+                    xyz, rgb = xyz[keep], rgb[keep]
+                self.stats = dict(points_accumulated=tot[0], points_dropped=tot[1], voxels=n_vox, after_outlier_filter=len(xyz))
+                say(f"\nFinal reconstruction: {len(xyz)} points, {len(self.camera_poses)} cameras")
+                xyz = xyz.astype(np.float64)
+        finally:
+            ctx.close()
+        return xyz, rgb, self.camera_poses
+
     def save_reconstruction(self, points, colors, output_path: str, ascii: bool = False):
         fileio.save_reconstruction(points, colors, output_path, ascii=ascii)

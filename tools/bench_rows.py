@@ -96,8 +96,12 @@ def bp(k, sub):
                                         abi.ptr(xyz_d), abi.ptr(rgb_d), cap, C.byref(n_out)))
 
 
-timeit("backproject s=1 -> device point list", lambda k: bp(k, 1), 32, px * (7 + 15))
-timeit("backproject s=2 -> device point list", lambda k: bp(k, 2), 32, px * (7 + 15) / 4)
+timeit("backproject s=1 -> device point list (blocking: count read back)", lambda k: bp(k, 1), 32, px * (7 + 15))
+timeit("backproject s=2 -> device point list (blocking: count read back)", lambda k: bp(k, 2), 32, px * (7 + 15) / 4)
+n_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+timeit("backproject s=1, device-only (one kernel, no read-back)", lambda k: ctx.backproject_device(k % N, xyz_d, rgb_d, n_dev, pose=poses[k % N], subsample=1), 64, px * (7 + 15))
+timeit("backproject s=2, device-only (one kernel, no read-back)", lambda k: ctx.backproject_device(k % N, xyz_d, rgb_d, n_dev, pose=poses[k % N], subsample=2), 64, px * (7 + 15) / 4)
+timeit("backproject s=4, device-only (one kernel, no read-back)", lambda k: ctx.backproject_device(k % N, xyz_d, rgb_d, n_dev, pose=poses[k % N], subsample=4), 64, px * (7 + 15) / 16)
 t0 = time.perf_counter()
 xyz, rgb = ctx.extract(tl3d.EXTRACT_CENTROID)
 t_ext = time.perf_counter() - t0
