@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--icp", action="store_true", help="also run frame-to-frame ICP each frame (poses still analytic)")
     ap.add_argument("--icp-iters", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-rows", action="store_true", help="skip the per-row rates of the rest of the path (N = 1 only)")
+    ap.add_argument("--cpu-merge-frames", type=int, default=6, help="frames of the numpy back-project -> vstack -> voxel centroid -> SOR sample")
     ap.add_argument("--force-dist", action="store_true", help="init torch.distributed (RCCL) even with one rank: exercises the merge path")
     ap.add_argument("--cpu-frames", type=int, default=4, help="distinct frames the CPU baseline cycles over")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-clock budget of the CPU baseline sample")
@@ -87,7 +89,8 @@ def main():
     deg = 360.0 / max(1, world * n_res)
     scene = synth.object_scene(with_room=True)
     poses = synth.orbit_poses(n_res, 1.0, deg, start_deg=rank * n_res * deg)
-    channels = tl3d.CH_TSDF | (tl3d.CH_CENTROID if args.centroid else 0)
+    want_rows = world == 1 and not args.no_rows
+    channels = tl3d.CH_TSDF | (tl3d.CH_CENTROID if (args.centroid or want_rows) else 0)
     spec = tl3d.GridSpec.cube(n, args.voxel, centre=(0.0, -0.1, 0.0), channels=channels)
     # one explicit stream shared by torch (frame synthesis, RCCL) and the library, so every hand-over is ordered
     stream = torch.cuda.Stream(dev)
@@ -118,12 +121,12 @@ def main():
     torch.cuda.synchronize(dev)
     t_gen = time.perf_counter() - t_gen
     invalid_frac = n_invalid / float(max(1, n_res) * H * W)
-    if args.icp:
+    if args.icp or want_rows:
         for i in range(n_res):
             ctx.build_normals(i)
 
     T_rel = []
-    if args.icp:
+    if args.icp or want_rows:
         for k in range(n_res):                       # analytic inter-frame motion as the ICP prior
             r_rel, t_rel = synth.relative_pose(poses[(k - 1) % n_res], poses[k])
             T0 = np.eye(4)
@@ -131,26 +134,26 @@ def main():
             T_rel.append(T0)
     LANES = tl3d.ICP_LANES
 
-    def step(s):
+    def step(s, icp=args.icp, centroid=args.centroid, frames=F):
         # registration of group g+1 (half of the lanes) runs while group g is fused (the other half was collected before)
         G = max(1, LANES // 2)
-        groups = [[(s * F + j) % n_res for j in range(j0, min(F, j0 + G))] for j0 in range(0, F, G)]
+        groups = [[(s * frames + j) % n_res for j in range(j0, min(frames, j0 + G))] for j0 in range(0, frames, G)]
 
         def enqueue(gi):
             for i, k in enumerate(groups[gi]):
                 ctx.icp_enqueue((gi & 1) * G + i, (k - 1) % n_res, k, T_init=T_rel[k], iters=args.icp_iters, stride=4, max_dist=0.05)
 
-        if args.icp:
+        if icp:
             enqueue(0)
         for gi, ks in enumerate(groups):
-            if args.icp:
+            if icp:
                 if gi + 1 < len(groups):
                     enqueue(gi + 1)
                 for i in range(len(ks)):
                     ctx.icp_collect((gi & 1) * G + i)
             for k in ks:
                 ctx.integrate(k, poses[k])
-                if args.centroid:
+                if centroid:
                     ctx.accumulate_centroid(k, poses[k], subsample=2)
 
     def barrier():
@@ -267,6 +270,77 @@ def main():
                               pose=host_keep[0][1], subsample=2)
         cpu["reference_numpy_backproject_s2_fps"] = round(1.0 / (time.perf_counter() - tb), 2)
         del orc
+        # the reference's own CPU path for these frames, restated in numpy (oracle/ref_numpy.py, bit-checked against the
+        # reference's back-projection; Open3D's voxel_down_sample / remove_statistical_outlier restated): per frame
+        # depth_to_pointcloud at the D2R stride 2 (D2R:328-384), then ONE merge_pointclouds = vstack -> voxel centroid at 5 mm ->
+        # 20-NN / 2 sigma outlier filter (D2R:386-420).  Bounded sample: a few frames, single process.
+        nm = max(2, min(args.cpu_merge_frames, len(host_keep) * 4))
+        tm0 = time.perf_counter()
+        clouds = []
+        for i in range(nm):
+            d, p = host_keep[i % len(host_keep)]
+            clouds.append(ref_numpy.backproject(d, np.zeros((H, W, 3), np.uint8), cam["fx"], cam["fy"], cam["cx"], cam["cy"], pose=p, subsample=2))
+        tm1 = time.perf_counter()
+        mp_, _ = ref_numpy.merge_open3d(clouds, args.voxel, sor=True)
+        tm2 = time.perf_counter()
+        cpu["restated_reference_path"] = {
+            "kind": "restated reference", "value": round(nm / (tm2 - tm0), 3), "unit": "frames/s", "cores": 1,
+            "sample": f"{nm} of the same {W}x{H} frames: numpy depth_to_pointcloud (stride 2) {tm1 - tm0:.1f} s + vstack -> voxel centroid "
+                      f"@ {args.voxel * 1e3:g} mm -> 20-NN outlier filter {tm2 - tm1:.1f} s, {len(mp_)} points out (oracle/ref_numpy.py, "
+                      "scipy cKDTree)"}
+
+    # ---- the rest of the path north_star names, measured in this same run (N = 1): registration in the loop, the
+    # voxel-centroid channel, back-projection to a point list, extraction, outlier filter ---------------------------
+    rows = None
+    if want_rows:
+        def timed(fn, reps):
+            fn(0)
+            ctx.sync()
+            tq = time.perf_counter()
+            for k in range(reps):
+                fn(k + 1)
+            ctx.sync()
+            return (time.perf_counter() - tq) / reps
+
+        rows = {}
+        nf = 256
+        ctx.reset()
+        t_s = timed(lambda k: step(k, icp=False, centroid=True, frames=nf), 2)
+        rows["tsdf_plus_centroid_s2_fps"] = round(nf / t_s, 1)
+        ctx.reset()
+        t_s = timed(lambda k: step(k, icp=True, centroid=False, frames=nf), 2)
+        rows["icp_in_loop_tsdf_fps"] = round(nf / t_s, 1)
+        ctx.reset()
+        t_s = timed(lambda k: step(k, icp=True, centroid=True, frames=nf), 2)
+        rows["icp_in_loop_tsdf_plus_centroid_fps"] = round(nf / t_s, 1)
+        rows["icp"] = {"iters": args.icp_iters, "stride": 4, "lanes": LANES, "prior": "analytic inter-frame motion"}
+        one = timed(lambda k: ctx.icp((k - 1) % n_res, k % n_res, T_init=T_rel[k % n_res], iters=args.icp_iters, stride=4, max_dist=0.05, eps=0.0), 24)
+        rows["icp_single_chain_us_per_iteration"] = round(1e6 * one / (args.icp_iters + 1), 2)
+        cap_pts = H * W
+        xyz_d = torch.empty((cap_pts, 3), dtype=torch.float32, device=dev)
+        rgb_d = torch.empty((cap_pts, 3), dtype=torch.uint8, device=dev)
+        n_d = torch.zeros(1, dtype=torch.int64, device=dev)
+        for sub in (1, 2):
+            t_b = timed(lambda k: ctx.backproject_device(k % n_res, xyz_d, rgb_d, n_d, pose=poses[k % n_res], subsample=sub), 64)
+            npts = int(n_d.item())
+            rows[f"backproject_s{sub}_device_us"] = round(1e6 * t_b, 2)
+            rows[f"backproject_s{sub}_GBps"] = round(((4 + 3) * (H // sub) * (W // sub) + 15 * npts) / t_b / 1e9, 1)
+        del xyz_d, rgb_d
+        # a fused grid to extract from: one pass over the resident frames (TSDF + centroids at the D2R stride)
+        ctx.reset()
+        for k in range(n_res):
+            ctx.integrate(k, poses[k])
+            ctx.accumulate_centroid(k, poses[k], subsample=2)
+        ctx.sync()
+        tq = time.perf_counter()
+        pts, _ = ctx.extract(tl3d.EXTRACT_CENTROID)
+        rows["extract_centroid_to_host_ms"] = round(1e3 * (time.perf_counter() - tq), 2)
+        rows["extract_points"] = int(len(pts))
+        tq = time.perf_counter()
+        keep = ctx.statistical_outlier(pts, 20, 2.0, cell_size=2.0 * args.voxel)
+        rows["outlier_filter_k20_ms"] = round(1e3 * (time.perf_counter() - tq), 2)
+        rows["outlier_filter_kept"] = int(keep.sum())
+        ctx.reset()
 
     if rank == 0:
         total = world * total_frames_rank
@@ -290,7 +364,7 @@ def main():
                        "invalid_pixel_fraction": round(invalid_frac, 4),
                        "hw_queues": hwq, "hip": dict(abi.RUNTIME),
                        "setup_s": round(t_gen, 1)},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "rows": rows,
         }
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())

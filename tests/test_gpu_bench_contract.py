@@ -39,10 +39,23 @@ def test_bench_json_contract():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert d["value"] > 0 and abs(d["ms_per_step"] - 1e3 * 4 / d["value"]) / d["ms_per_step"] < 0.05
+    # the rest of the path, measured in the same run (registration in the loop, centroid channel, back-projection, extraction)
+    rows = d["rows"]
+    for k in ("tsdf_plus_centroid_s2_fps", "icp_in_loop_tsdf_fps", "icp_in_loop_tsdf_plus_centroid_fps", "icp_single_chain_us_per_iteration",
+              "backproject_s1_device_us", "backproject_s1_GBps", "extract_centroid_to_host_ms", "outlier_filter_k20_ms"):
+        assert rows[k] > 0, k
+    assert rows["extract_points"] > 100 and rows["outlier_filter_kept"] <= rows["extract_points"]
+    # the reference's own CPU path (restated), bounded sample, beside the port
+    rr = c["restated_reference_path"]
+    assert rr["kind"] == "restated reference" and rr["value"] > 0 and rr["cores"] == 1 and "voxel centroid" in rr["sample"]
+    # stream concurrency and runtime versions are recorded
+    assert d["config"]["hw_queues"]["effective_queues"] >= 1 and d["config"]["hip"]["hip_runtime"] > 0
+    assert d["config"]["invalid_pixel_fraction"] == 0.0
 
 
 def test_single_rank_rccl_merge_rehearsal():
-    d = _run(["--force-dist", "--no-cpu-baseline", "--centroid", "--depth-format", "u16"], env={"MASTER_PORT": "29541"})
+    d = _run(["--force-dist", "--no-cpu-baseline", "--no-rows", "--centroid", "--depth-format", "u16"], env={"MASTER_PORT": "29541"})
     assert d["value"] > 0 and d["config"]["centroid_channel"] is True and d["config"]["depth_format"] == "u16"
+    assert d["config"]["grid_merges_in_timed_region"] == 1 and d["rows"] is None
     r = d["roofline"]
     assert r["bytes_per_launch"] == 8 * r["records_per_launch"] + 2 * 270 * 480

@@ -293,3 +293,67 @@ def test_cli_two_ranks_on_one_gpu_equal_one_process(tmp_path):
     assert one.read_bytes() == two.read_bytes()
     pts, _ = rn.read_ply(two)
     assert len(pts) > 20000
+
+
+def _tiny_depth_checkpoint(path):
+    """A randomly initialised Depth-Anything checkpoint of a few hundred KB in save_pretrained layout (no network): the same
+    transformers classes the reference loads by name (DER:114-118).  The head bias makes it predict ~1.5 everywhere."""
+    import torch
+    from transformers import DepthAnythingConfig, DepthAnythingForDepthEstimation, Dinov2Config, DPTImageProcessorPil
+    bb = Dinov2Config(hidden_size=32, num_hidden_layers=2, num_attention_heads=2, mlp_ratio=2, image_size=70, patch_size=14,
+                      out_features=["stage1", "stage2"], reshape_hidden_states=False, apply_layernorm=True)
+    cfg = DepthAnythingConfig(backbone_config=bb, reassemble_hidden_size=32, neck_hidden_sizes=[16, 32], reassemble_factors=[2, 1],
+                              fusion_hidden_size=16, head_hidden_size=8, patch_size=14)
+    torch.manual_seed(0)
+    model = DepthAnythingForDepthEstimation(cfg)
+    with torch.no_grad():
+        model.head.conv3.bias.fill_(1.5)
+    model.save_pretrained(path)
+    DPTImageProcessorPil(do_resize=True, size={"height": 70, "width": 70}, keep_aspect_ratio=True, ensure_multiple_of=14, resample=3,
+                         do_normalize=True).save_pretrained(path)
+    return model
+
+
+def test_der_driver_with_local_depth_model_and_per_frame_clouds(tmp_path, capsys):
+    """Row f4: `--depth-model <local dir>` runs the upstream transformers depth network on the GPU from a local checkpoint
+    (never by name), hands the depth tensors to the frame slots without a host copy and writes <output>/reconstruction.ply;
+    `--per-frame-ply` adds <output>/pointclouds/<stem>.ply per frame with depth_processor.py's naming (DP:923-934)."""
+    import torch
+    from PIL import Image
+    from tl3d.depthnet import LocalDepthEstimator
+    ckpt = tmp_path / "ckpt"
+    ref_model = _tiny_depth_checkpoint(str(ckpt))
+    rng = np.random.default_rng(0)
+    inp = tmp_path / "images"
+    inp.mkdir()
+    imgs = []
+    for i in range(3):
+        img = rng.integers(0, 256, (96, 128, 3), dtype=np.uint8)
+        Image.fromarray(img[..., ::-1]).save(inp / f"view_{i:02d}.png")
+        imgs.append(img)
+    # the wrapper equals the reference's call sequence on the upstream classes (DER:139-165)
+    net = LocalDepthEstimator(str(ckpt), device=0)
+    got = net.estimate(imgs[0])
+    assert got.is_cuda and got.dtype == torch.float32 and tuple(got.shape) == (96, 128)
+    inputs = net.processor(images=Image.fromarray(imgs[0][..., ::-1]), return_tensors="pt")
+    with torch.no_grad():
+        want = torch.nn.functional.interpolate(ref_model.eval()(**inputs).predicted_depth.unsqueeze(1), size=(96, 128), mode="bicubic",
+                                               align_corners=False).squeeze()
+    assert torch.allclose(got.cpu(), want, rtol=1e-4, atol=1e-5) and abs(float(got.mean()) - 1.5) < 1e-2
+    del net
+    import depth_enhanced_reconstruction as cli
+    out_dir = tmp_path / "out"
+    rc = cli.main(["--input", str(inp), "--output", str(out_dir), "--fx", "100", "--fy", "100", "--cx", "64", "--cy", "48",
+                   "--depth-model", str(ckpt), "--per-frame-ply"])
+    text = capsys.readouterr().out
+    assert rc == 0 and "Estimating depth maps" in text and "Depth 3/3" in text
+    pts, _ = rn.read_ply(out_dir / "reconstruction.ply")
+    assert len(pts) > 500 and abs(np.median(pts[:, 2]) - 1.5) < 0.05                 # the plane the tiny network predicts
+    clouds = sorted(p.name for p in (out_dir / "pointclouds").iterdir())
+    assert clouds == ["view_00.ply", "view_01.ply", "view_02.ply"]
+    cp, cc = rn.read_ply(out_dir / "pointclouds" / "view_01.ply")                     # camera frame, DER's stride 4, BGR -> RGB
+    assert len(cp) == (96 // 4) * (128 // 4) and np.allclose(cp[:, 2], 1.5, atol=1e-2)
+    assert np.array_equal(cc[0], imgs[1][0, 0, ::-1])
+    # a missing checkpoint is an explicit error, never a download
+    assert cli.main(["--input", str(inp), "--output", str(out_dir), "--depth-model", str(tmp_path / "nope")]) == 1
+    assert "never touches the network" in capsys.readouterr().out

@@ -204,3 +204,69 @@ def test_product_scale_estimators_equal_the_reference_goldens(golden_dir, capsys
     assert "Estimated depth scale:" in out and "  Depth scale:" in out
     # four points are enough for D2R only (DER:673 wants >= 5 input points)
     assert g["scale/four_der"] == 1.0 and g["scale/four_d2r"] != 1.0 and g["scale/too_few_d2r"] == 1.0
+
+
+def _write_exr(path, planes, compression, ptype):
+    """Test-side OpenEXR writer (scan-line, single part): planes {name: [H, W]}; compression 0 NONE / 2 ZIPS / 3 ZIP."""
+    import struct
+    import zlib
+    names = sorted(planes)
+    h, w = planes[names[0]].shape
+    dt = {1: "<f2", 2: "<f4", 0: "<u4"}[ptype]
+
+    def attr(name, typ, val):
+        return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<i", len(val)) + val
+    chl = b"".join(n.encode() + b"\0" + struct.pack("<iB3xii", ptype, 0, 1, 1) for n in names) + b"\0"
+    box = struct.pack("<4i", 0, 0, w - 1, h - 1)
+    head = struct.pack("<II", 20000630, 2) + attr("channels", "chlist", chl) + attr("compression", "compression", bytes([compression])) + \
+        attr("dataWindow", "box2i", box) + attr("displayWindow", "box2i", box) + attr("lineOrder", "lineOrder", b"\0") + \
+        attr("pixelAspectRatio", "float", struct.pack("<f", 1.0)) + attr("screenWindowCenter", "v2f", struct.pack("<2f", 0, 0)) + \
+        attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + b"\0"
+    lines = {0: 1, 2: 1, 3: 16}[compression]
+    chunks = []
+    for y in range(0, h, lines):
+        raw = b"".join(planes[n][r].astype(dt).tobytes() for r in range(y, min(h, y + lines)) for n in names)
+        body = raw
+        if compression:
+            b = np.frombuffer(raw, np.uint8)
+            t = np.concatenate([b[0::2], b[1::2]]).astype(np.int64)
+            d = t.copy()
+            d[1:] = (t[1:] - t[:-1] + 128 + 256) % 256
+            z = zlib.compress(d.astype(np.uint8).tobytes())
+            body = z if len(z) < len(raw) else raw
+        chunks.append(struct.pack("<ii", y, len(body)) + body)
+    off, table = len(head) + 8 * len(chunks), []
+    for c in chunks:
+        table.append(off)
+        off += len(c)
+    with open(path, "wb") as f:
+        f.write(head + struct.pack(f"<{len(table)}Q", *table) + b"".join(chunks))
+
+
+def test_exr_depth_reader(tmp_path, capsys):
+    """Row a2, the EXR branch of load_depth (D2R:92-95; the reference goes through OpenCV, which this image lacks): scan-line
+    files, NONE / ZIPS / ZIP, float and half pixels, one channel back as float32; what the reader cannot decode is said so."""
+    rng = np.random.default_rng(3)
+    d = (0.3 + 4.0 * rng.random((37, 53))).astype(np.float32)
+    d[5, 7] = 0.0
+    for comp in (0, 2, 3):
+        _write_exr(tmp_path / f"z{comp}.exr", {"Z": d}, comp, 2)
+        out = fileio.DepthImageLoader.load_depth(tmp_path / f"z{comp}.exr")
+        assert out.dtype == np.float32 and np.array_equal(out, d), comp
+    smooth = np.tile(np.linspace(1.0, 2.0, 53, dtype=np.float32), (37, 1))          # compressible: exercises the inflate path
+    _write_exr(tmp_path / "smooth.exr", {"Y": smooth}, 3, 2)
+    assert np.array_equal(fileio.DepthImageLoader.load_depth(tmp_path / "smooth.exr"), smooth)
+    h16 = d.astype(np.float16)
+    _write_exr(tmp_path / "half.EXR", {"Y": h16}, 3, 1)
+    assert np.array_equal(fileio.DepthImageLoader.load_depth(tmp_path / "half.EXR"), h16.astype(np.float32))
+    _write_exr(tmp_path / "rgbz.exr", {"R": d, "G": d, "B": d, "Z": d * 2}, 2, 2)     # depth channel wins over colour
+    assert np.array_equal(fileio.DepthImageLoader.load_depth(tmp_path / "rgbz.exr"), d * 2)
+    _write_exr(tmp_path / "rgb.exr", {"R": d, "G": d * 0, "B": d * 0}, 0, 2)
+    assert np.allclose(fileio.DepthImageLoader.load_depth(tmp_path / "rgb.exr"), 0.299 * d, rtol=1e-6)
+    bad = bytearray((tmp_path / "z0.exr").read_bytes())
+    bad[bad.index(b"compression\0compression\0") + 28] = 4                            # PIZ
+    (tmp_path / "piz.exr").write_bytes(bytes(bad))
+    assert fileio.DepthImageLoader.load_depth(tmp_path / "piz.exr") is None
+    assert "compression 4 is not supported" in capsys.readouterr().out
+    (tmp_path / "junk.exr").write_bytes(b"not an exr")
+    assert fileio.DepthImageLoader.load_depth(tmp_path / "junk.exr") is None

@@ -46,9 +46,12 @@ class DepthImageLoader:
                 return arr
             return arr.astype(np.float32) / 1000.0
         if filepath.suffix in (".exr", ".EXR"):
-            # the reference reads EXR through OpenCV (D2R:92-95); no EXR decoder exists in this image
-            print(f"  Warning: EXR depth is not supported without OpenCV: {filepath.name}")
-            return None
+            # the reference reads EXR through OpenCV (cv2.imread(..., IMREAD_ANYDEPTH) -> one float32 channel, D2R:92-95)
+            try:
+                return read_exr_depth(filepath)
+            except (OSError, ValueError) as e:
+                print(f"  Warning: cannot read EXR depth {filepath.name}: {e}")
+                return None
         return None
 
     @staticmethod
@@ -63,6 +66,78 @@ class DepthImageLoader:
             if cand.exists():
                 return cand
         return None
+
+
+def read_exr_depth(path) -> np.ndarray:
+    """Minimal OpenEXR reader for depth maps: single-part scan-line files, compression NONE / ZIPS / ZIP, HALF / FLOAT / UINT
+    channels.  Returns ONE float32 channel as `cv2.imread(path, cv2.IMREAD_ANYDEPTH)` does for the reference (D2R:92-95):
+    the only channel, else `Z`, else `Y`, else the grey value 0.299 R + 0.587 G + 0.114 B.  Tiled, multi-part, deep and
+    PIZ / PXR24 / B44 / DWA files raise ValueError (OpenCV is not available in this image: written from the OpenEXR file
+    layout, parity unpinned)."""
+    import struct
+    import zlib
+    with open(str(path), "rb") as f:
+        data = f.read()
+    if len(data) < 8 or struct.unpack_from("<I", data, 0)[0] != 20000630:
+        raise ValueError("not an OpenEXR file")
+    flags = struct.unpack_from("<I", data, 4)[0]
+    if flags & 0x1A00:
+        raise ValueError("tiled / deep / multi-part OpenEXR files are not supported")
+    pos, attrs = 8, {}
+    while data[pos] != 0:
+        e = data.index(b"\0", pos); name = data[pos:e].decode("latin1"); pos = e + 1
+        e = data.index(b"\0", pos); typ = data[pos:e].decode("latin1"); pos = e + 1
+        size = struct.unpack_from("<i", data, pos)[0]; pos += 4
+        attrs[name] = (typ, data[pos:pos + size]); pos += size
+    pos += 1
+    comp = attrs["compression"][1][0]
+    if comp not in (0, 2, 3):
+        raise ValueError(f"OpenEXR compression {comp} is not supported (NONE, ZIPS, ZIP are)")
+    x0, y0, x1, y1 = struct.unpack("<4i", attrs["dataWindow"][1])
+    w, h = x1 - x0 + 1, y1 - y0 + 1
+    chans, cp, cl = [], 0, attrs["channels"][1]
+    while cl[cp] != 0:
+        e = cl.index(b"\0", cp); cname = cl[cp:e].decode("latin1"); cp = e + 1
+        ptype, _pl, xs, ys = struct.unpack_from("<iB3xii", cl, cp); cp += 16
+        if xs != 1 or ys != 1:
+            raise ValueError("sub-sampled OpenEXR channels are not supported")
+        chans.append((cname, ptype))
+    psize = {0: 4, 1: 2, 2: 4}
+    row_bytes = sum(psize[t] * w for _, t in chans)
+    lines = {0: 1, 2: 1, 3: 16}[comp]
+    nchunks = (h + lines - 1) // lines
+    offsets = struct.unpack_from(f"<{nchunks}Q", data, pos)
+    planes = {c: np.zeros((h, w), np.float32) for c, _ in chans}
+    for off in offsets:
+        y, sz = struct.unpack_from("<ii", data, off)
+        raw = data[off + 8:off + 8 + sz]
+        nl = min(lines, y0 + h - y)
+        want = row_bytes * nl
+        if comp != 0 and sz < want:
+            t = np.frombuffer(zlib.decompress(raw), np.uint8).astype(np.int64)
+            if len(t) != want:
+                raise ValueError("corrupt OpenEXR chunk")
+            t = (np.cumsum(t - 128) + 128) % 256                     # undo the byte-delta predictor: t[i] += t[i-1] - 128
+            half = (want + 1) // 2
+            buf = np.empty(want, np.uint8)
+            buf[0::2], buf[1::2] = t[:half], t[half:]                  # undo the even / odd byte split
+            raw = buf.tobytes()
+        p = 0
+        for r in range(nl):
+            for cname, ptype in chans:
+                n = psize[ptype] * w
+                seg = raw[p:p + n]; p += n
+                dt = {0: "<u4", 1: "<f2", 2: "<f4"}[ptype]
+                planes[cname][y - y0 + r] = np.frombuffer(seg, dt).astype(np.float32)
+    names = [c for c, _ in chans]
+    if len(names) == 1:
+        return planes[names[0]]
+    for pick in ("Z", "Y"):
+        if pick in planes:
+            return planes[pick]
+    if all(c in planes for c in "RGB"):
+        return (np.float32(0.299) * planes["R"] + np.float32(0.587) * planes["G"] + np.float32(0.114) * planes["B"]).astype(np.float32)
+    return planes[names[0]]
 
 
 def read_image_bgr(path) -> Optional[np.ndarray]:

@@ -294,7 +294,9 @@ class DepthToReconstructionPipeline:
                     if self.depths[i].shape != (h, w):
                         raise ValueError(f"frame {i} is {self.depths[i].shape}, expected {(h, w)}")
                     ctx.upload(i, self.depths[i], self.images[i])
-            self.scales = per_frame_scales(self.depths, anchors, default=scale, fetch=ctx.download_depth)
+            # depth maps may be GPU tensors (depth estimated in this process): the scale rule then reads them back per frame
+            host_depths = [d if isinstance(d, np.ndarray) else None for d in self.depths]
+            self.scales = per_frame_scales(host_depths, anchors, default=scale, fetch=ctx.download_depth)
             if poses is not None:
                 self.camera_poses, self.frame_index = list(poses), list(range(len(poses)))
             else:
@@ -499,6 +501,28 @@ class DepthToReconstructionPipeline:
         finally:
             ctx.close()
         return xyz, rgb, self.camera_poses
+
+    def export_frame_clouds(self, out_dir, subsample: int = 1, min_depth=None, max_depth=None):
+        """Per-frame camera-space clouds like depth_processor.py writes them (DP:371-422 back-projection, DP:923-934 file):
+        `<out_dir>/pointclouds/<image stem>.ply`, one per loaded frame.  Returns the number of files written."""
+        from pathlib import Path
+        cfg = self.config
+        out = Path(out_dir) / "pointclouds"
+        out.mkdir(parents=True, exist_ok=True)
+        if not self.depths:
+            return 0
+        h, w = self.depths[0].shape
+        n_written = 0
+        with FusionContext(w, h, cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.min_depth if min_depth is None else min_depth,
+                           cfg.max_depth if max_depth is None else max_depth, n_slots=1, grid=None, device=cfg.device) as ctx:
+            for name, d, img in zip(self.image_names, self.depths, self.images):
+                ctx.upload(0, d, img)
+                pts, col = ctx.backproject(0, pose=None, scale=float(cfg.depth_scale), subsample=int(subsample))
+                if len(pts) == 0:
+                    continue                                         # DP:929-931: nothing to save
+                fileio.write_ply_binary(out / f"{Path(name).stem}.ply", pts.astype(np.float64), col)
+                n_written += 1
+        return n_written
 
     def save_reconstruction(self, points, colors, output_path: str, ascii: bool = False):
         fileio.save_reconstruction(points, colors, output_path, ascii=ascii)
