@@ -201,48 +201,85 @@ def main():
         elapsed = float(tmax.item())
 
     # ---- roofline of the dominant kernel (tsdf_integrate), rank 0 ----------------------------------------
+    depth_bpp = 2.0 if args.depth_format == "u16" else 4.0
+
+    def measure_roofline(c_, steps_):
+        """Counted algorithmic bytes per launch (a counting pass over the resident frames) and the kernel's own duration
+        (hipEvent pairs around every batch of back-to-back launches, on the launching stream) over `steps_` steps."""
+        c_.reset_stats()
+        c_.set_profile(count_records=True, time_kernels=False)
+        for j in range(n_res):
+            c_.integrate(j, poses[j])
+        st = c_.stats()
+        nl = max(1, st["tsdf_launches"])
+        rec_per_launch = (st["tsdf_records_read"] + st["tsdf_records_written"]) / nl
+        counted_free = st["tsdf_bricks_free_counted"] / nl
+        c_.reset_stats()
+        c_.reset()
+        c_.set_profile(count_records=False, time_kernels=True)
+        for s_ in range(steps_):
+            for j in range(F):
+                c_.integrate((s_ * F + j) % n_res, poses[(s_ * F + j) % n_res])
+        st2 = c_.stats()
+        c_.set_profile(False, False)
+        c_.reset()
+        k_ms = st2["tsdf_kernel_ms"] / max(1, st2["tsdf_kernel_timed"])
+        # voxel records read + written (8 B each), one 4-byte counter read + written per free-space brick that was counted
+        # instead of streamed, and the depth frame read once
+        bytes_launch = 8.0 * rec_per_launch + 8.0 * counted_free + depth_bpp * H * W
+        achieved = bytes_launch / (k_ms * 1e-3) / 1e9
+        return {"achieved": round(achieved, 1), "frac": round(achieved / 8000.0, 4), "bytes_per_launch": int(bytes_launch),
+                "records_per_launch": int(rec_per_launch), "bricks_visited_per_launch": int(st["tsdf_bricks_visited"] / nl),
+                "free_space_bricks_per_launch": int(st["tsdf_bricks_free"] / nl), "free_space_bricks_counted_per_launch": int(counted_free),
+                "ms_per_launch": round(k_ms, 4)}
+
     roof = None
     if rank == 0:
         launches = total_frames_rank
-        ctx.reset_stats()
-        ctx.set_profile(count_records=True, time_kernels=False)
-        for j in range(n_res):
-            ctx.integrate(j, poses[j])
-        st = ctx.stats()
-        rec_per_launch = (st["tsdf_records_read"] + st["tsdf_records_written"]) / max(1, st["tsdf_launches"])
-        bricks_per_launch = st["tsdf_bricks_visited"] / max(1, st["tsdf_launches"])
-        free_per_launch = st["tsdf_bricks_free"] / max(1, st["tsdf_launches"])
-        ctx.reset_stats()
-        ctx.set_profile(count_records=False, time_kernels=True)
-        for s in range(args.steps):
-            for j in range(F):
-                ctx.integrate((s * F + j) % n_res, poses[(s * F + j) % n_res])
-        st2 = ctx.stats()
-        ctx.set_profile(False, False)
-        k_ms = st2["tsdf_kernel_ms"] / max(1, st2["tsdf_kernel_timed"])
-        depth_bpp = 2.0 if args.depth_format == "u16" else 4.0
-        bytes_launch = 8.0 * rec_per_launch + depth_bpp * H * W      # voxel records + the depth frame read once
+        m = measure_roofline(ctx, args.steps)
         region_ms = dev_ms / launches
-        # duration of the dominant kernel alone: hipEvent pairs recorded around every tsdf_integrate launch on the
-        # launching stream, over a re-run of the same K steps (the timed region itself carries no extra events)
-        achieved = bytes_launch / (k_ms * 1e-3) / 1e9
+        counters_on = m["free_space_bricks_counted_per_launch"] > 0
         traffic = None
         pj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pj):
             try:
                 with open(pj) as f:
                     tj = json.load(f)
-                if tj.get("grid") == n and tj.get("width") == W and tj.get("height") == H:
+                # a PMC measurement only speaks for the kernel and input it was taken on
+                if (tj.get("grid") == n and tj.get("width") == W and tj.get("height") == H and tj.get("depth_format", "f32") == args.depth_format
+                        and bool(tj.get("free_space_counters", False)) == counters_on):
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roof = {"bound": "hbm", "kernel": "tsdf_integrate_kernel", "achieved": round(achieved, 1), "peak": 8000.0,
-                "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
-                "bytes_per_launch": int(bytes_launch), "records_per_launch": int(rec_per_launch),
-                "dense_sweep_bytes": int(16.0 * n ** 3 + 4.0 * H * W), "bricks_visited_per_launch": int(bricks_per_launch),
-                "free_space_bricks_per_launch": int(free_per_launch),
-                "ms_per_launch": round(k_ms, 4), "ms_per_frame_all_kernels": round(region_ms, 4),
+        roof = {"bound": "hbm", "kernel": "tsdf_integrate_kernel", "achieved": m["achieved"], "peak": 8000.0,
+                "unit": "GB/s", "frac": m["frac"], "traffic": traffic,
+                "bytes_per_launch": m["bytes_per_launch"], "records_per_launch": m["records_per_launch"],
+                "dense_sweep_bytes": int(16.0 * n ** 3 + 4.0 * H * W), "bricks_visited_per_launch": m["bricks_visited_per_launch"],
+                "free_space_bricks_per_launch": m["free_space_bricks_per_launch"],
+                "free_space_bricks_counted_per_launch": m["free_space_bricks_counted_per_launch"],
+                "ms_per_launch": m["ms_per_launch"], "ms_per_frame_all_kernels": round(region_ms, 4),
                 "launches": launches, "frames_per_sweep": 1}
+        if counters_on and world == 1 and args.depth_format == "f32":
+            # the same frames in the round-1 formulation (free-space bricks streamed: 8 KB of records per brick and frame):
+            # more bytes, moved faster per byte, more time per frame -- both are reported
+            os.environ["TL3D_FREE_COUNTERS"] = "0"
+            try:
+                ctx_s = tl3d.FusionContext(W, H, cam["fx"], cam["fy"], cam["cx"], cam["cy"], min_depth=0.1, max_depth=50.0, n_slots=n_res,
+                                           grid=tl3d.GridSpec.cube(n, args.voxel, centre=(0.0, -0.1, 0.0), channels=tl3d.CH_TSDF),
+                                           device=local_rank, stream=stream.cuda_stream)
+            finally:
+                del os.environ["TL3D_FREE_COUNTERS"]
+            for i in range(n_res):
+                ctx_s.upload(i, ctx.download_depth(i), None)
+            ms_ = measure_roofline(ctx_s, max(1, min(args.steps, 2)))
+            ctx_s.set_profile(False, False)
+            tq = time.perf_counter()
+            for j in range(F):
+                ctx_s.integrate(j % n_res, poses[j % n_res])
+            ctx_s.sync()
+            ms_["frames_per_s"] = round(F / (time.perf_counter() - tq), 1)
+            ctx_s.close()
+            roof["free_space_streamed"] = ms_
 
     # ---- CPU baseline: the oracle on the host cores, bounded sample, rank 0 at N=1 only --------------------
     cpu = None

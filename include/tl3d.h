@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TL3D_ABI_VERSION 2
+#define TL3D_ABI_VERSION 3
 
 /* error codes */
 #define TL3D_OK 0
@@ -113,7 +113,9 @@ typedef struct tl3d_stats {
     uint64_t tsdf_records_read;      /* voxel records loaded by tl3d_integrate kernels (counting mode) */
     uint64_t tsdf_records_written;
     uint64_t tsdf_bricks_visited;    /* bricks that passed culling                                      */
-    uint64_t tsdf_bricks_free;       /* of those: free-space bricks (streaming update, no depth lookups) */
+    uint64_t tsdf_bricks_free;       /* of those: free-space bricks (no depth lookups)                   */
+    uint64_t tsdf_bricks_free_counted; /* of those: handled by ONE add to the brick's free-space counter instead of a
+                                          read-modify-write of its 512 records (8 B instead of 8 KB; counting mode)   */
     uint64_t centroid_launches;
     uint64_t centroid_points;        /* points accumulated                                              */
     uint64_t centroid_dropped;       /* valid points that fell outside the grid                         */
@@ -174,6 +176,11 @@ int tl3d_accumulate_points(tl3d_ctx *ctx, const float *xyz_hd, const uint8_t *rg
 int tl3d_points_bounds(tl3d_ctx *ctx, const float *xyz_hd, int64_t n, double out_min[3], double out_max[3]);
 
 /* a11: TSDF integration of one frame (no reference code; convention in DESIGN.md).
+ * Free space: a brick (8^3 voxels) that lies wholly in front of everything the frame sees would get (+32767, +1) on each
+ * of its 512 records; the library adds 1 to a per-brick counter instead and folds the pending counts into the records
+ * before anything can read the TSDF channel (tl3d_grid_device_ptr, tl3d_grid_download, tl3d_grid_add, tl3d_extract,
+ * tl3d_grid_max_weight, tl3d_sync), so the channel's contents are the same bit for bit.  TL3D_FREE_COUNTERS=0 in the
+ * environment streams the records every frame instead (the round-1 behaviour).
  * The frame's classification kernels are enqueued at once on side streams; its grid update is issued together with
  * those of the following calls (batches of up to 32 by default, TL3D_TSDF_BATCH) so that the main stream pays one cross-stream
  * wait per batch.  Every other call that touches the grid or the slot, tl3d_sync, tl3d_event_record and

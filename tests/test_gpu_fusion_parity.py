@@ -463,3 +463,44 @@ def test_streams_run_side_by_side_without_scheduler_stalls():
         assert info["elapsed_ms"] < 1.6, info                       # 16 streams, 16 queues: one round (+ launch overhead)
         many = abi.probe_hw_queues(0, 48, 0.25)
         assert many["elapsed_ms"] < 4.0, many                       # 3 rounds; the over-subscribed regime takes 10-20 ms
+
+
+def test_free_space_counters_fold_to_the_same_grid():
+    """Free-space bricks are counted (one add per brick and frame) and folded into the records before anything reads the
+    TSDF channel: download, merge, extraction, weight check and checkpoint see the oracle's grid bit for bit, and the counting
+    mode reports which bricks were counted instead of streamed."""
+    poses, frames = small_scene_frames(n=6, deg=9.0, scene=None)
+    ctx, orc = make_pair(dims=(96, 96, 96), voxel=0.025, centre=(0.0, -0.2, 0.0), n_slots=6)
+    with ctx:
+        ctx.set_profile(True, False)
+        for i, (d, c) in enumerate(frames):
+            ctx.upload(i, d, c)
+        for i in range(3):
+            ctx.integrate(i, poses[i])
+            orc.tsdf_integrate(frames[i][0], poses[i][0], poses[i][1])
+        st = ctx.stats()
+        assert st["tsdf_bricks_free"] >= 5 and st["tsdf_bricks_free_counted"] == st["tsdf_bricks_free"]      # default: counted
+        assert np.array_equal(ctx.download_grid(tl3d.CH_TSDF), orc.tsdf)                    # folded by the download
+        for i in range(3, 6):                                                               # more frames on top of folded + new counts
+            ctx.integrate(i, poses[i])
+            orc.tsdf_integrate(frames[i][0], poses[i][0], poses[i][1])
+        assert ctx.max_weight() == int(orc.tsdf[:, 1].max())                                # folded by the weight check
+        xyz, _ = ctx.extract(tl3d.EXTRACT_TSDF, min_weight=2)                               # and by the extraction
+        oxyz, _ = orc.extract(1, min_weight=2, use_centroid=False)
+        assert len(xyz) > 100 and np.array_equal(xyz, oxyz)
+        g = ctx.download_grid(tl3d.CH_TSDF)
+        assert np.array_equal(g, orc.tsdf)
+        ctx.add_grid(tl3d.CH_TSDF, g)                                                       # merge of two folded grids
+        assert np.array_equal(ctx.download_grid(tl3d.CH_TSDF), 2 * orc.tsdf)
+        ctx.reset()
+        ctx.integrate(0, poses[0])
+        o2 = c_oracle_like(orc)
+        o2.tsdf_integrate(frames[0][0], poses[0][0], poses[0][1])
+        assert np.array_equal(ctx.download_grid(tl3d.CH_TSDF), o2.tsdf)                     # counters were cleared by the reset
+
+
+def c_oracle_like(orc):
+    from oracle import c_oracle
+    c = orc.cfg
+    return c_oracle.Oracle(c.width, c.height, c.fx, c.fy, c.cx, c.cy, c.min_depth, c.max_depth, dims=(c.nx, c.ny, c.nz),
+                           origin=tuple(c.origin), voxel_size=c.voxel_size, sdf_trunc=c.sdf_trunc)

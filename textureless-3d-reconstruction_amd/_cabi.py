@@ -10,7 +10,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TL3D_LIB") or os.path.join(_HERE, "libtl3d.so")     # TL3D_LIB: a diagnostic build
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 OK, E_INVALID, E_HIP, E_NOMEM, E_CAPACITY, E_STATE, E_NODEVICE = 0, -1, -2, -3, -4, -5, -6
 CH_TSDF, CH_CENTROID = 1, 2
 DEPTH_F32_M, DEPTH_U16_MM = 0, 1
@@ -59,7 +59,7 @@ class IcpParams(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("tsdf_launches", C.c_uint64), ("tsdf_records_read", C.c_uint64), ("tsdf_records_written", C.c_uint64),
-                ("tsdf_bricks_visited", C.c_uint64), ("tsdf_bricks_free", C.c_uint64), ("centroid_launches", C.c_uint64), ("centroid_points", C.c_uint64),
+                ("tsdf_bricks_visited", C.c_uint64), ("tsdf_bricks_free", C.c_uint64), ("tsdf_bricks_free_counted", C.c_uint64), ("centroid_launches", C.c_uint64), ("centroid_points", C.c_uint64),
                 ("centroid_dropped", C.c_uint64), ("tsdf_kernel_ms", C.c_double), ("tsdf_kernel_timed", C.c_uint64)]
 
 

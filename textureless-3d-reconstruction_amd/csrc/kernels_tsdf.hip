@@ -32,6 +32,7 @@ namespace tl3d {
 struct TsdfConst {
     float mind, maxd, sc, wlim, hlim;
     int xcd_group;
+    int free_counted;            // FREE bricks were counted in the per-brick free-space counters by the classification: not listed
 };
 
 constexpr int TILE = 32;
@@ -151,7 +152,7 @@ __device__ __forceinline__ bool sphere_in_view(const Frustum &fr, float x, float
 
 __global__ __launch_bounds__(256) void brick_cull_kernel(Cam cam, Grid g, PoseF pose, Frustum fr, Pyramid py,
                                                          const float4 *__restrict__ tiles, unsigned *__restrict__ list,
-                                                         unsigned *__restrict__ list_counts) {
+                                                         unsigned *__restrict__ list_counts, unsigned *__restrict__ free_cnt) {
     __shared__ unsigned s_cnt[4][2];
     __shared__ unsigned s_base[2];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -245,7 +246,33 @@ __global__ __launch_bounds__(256) void brick_cull_kernel(Cam cam, Grid g, PoseF 
     for (int w = 0; w < wid; ++w) { bm += s_cnt[w][0]; bf += s_cnt[w][1]; }
     const unsigned long long below = (1ull << lane) - 1ull;
     if (cls == 1) list[bm + __popcll(mm & below)] = (unsigned)brick;
-    if (cls == 2) list[nbricks - 1u - (bf + __popcll(mf & below))] = (unsigned)brick | FREE_FLAG;
+    if (cls == 2) {
+        // Free space: every voxel of the brick gets exactly (+32767, +1).  With per-brick counters that is ONE integer add
+        // here instead of a 4 KB read + 4 KB write by the update kernel; the counters are folded into the records before
+        // anything reads them (fold_free_kernel).  Without counters the brick goes on the list (from the back).
+        if (free_cnt) atomicAdd(free_cnt + brick, 1u);
+        else list[nbricks - 1u - (bf + __popcll(mf & below))] = (unsigned)brick | FREE_FLAG;
+    }
+}
+
+// records += count x (32767, 1) for every brick with a pending free-space count; the count returns to zero.  One wave per
+// brick, 16 B per lane.  Runs on the main stream before anything reads the TSDF channel (download, merge, extraction,
+// weight check), i.e. once per scan, not per frame.
+__global__ __launch_bounds__(256) void fold_free_kernel(int2 *__restrict__ grid, unsigned *__restrict__ free_cnt, unsigned nbricks) {
+    const int lane = threadIdx.x & 63;
+    for (unsigned b = blockIdx.x * 4u + (threadIdx.x >> 6); b < nbricks; b += gridDim.x * 4u) {
+        const unsigned c = __builtin_amdgcn_readfirstlane(free_cnt[b]);
+        if (c == 0u) continue;
+        int4 *__restrict__ recs = reinterpret_cast<int4 *>(grid + ((size_t)b << 9));
+        const int dq = (int)(c * 32767u), dw = (int)c;
+        int4 r0 = recs[lane], r1 = recs[64 + lane], r2 = recs[128 + lane], r3 = recs[192 + lane];
+        r0.x += dq; r0.y += dw; r0.z += dq; r0.w += dw;
+        r1.x += dq; r1.y += dw; r1.z += dq; r1.w += dw;
+        r2.x += dq; r2.y += dw; r2.z += dq; r2.w += dw;
+        r3.x += dq; r3.y += dw; r3.z += dq; r3.w += dw;
+        recs[lane] = r0; recs[64 + lane] = r1; recs[128 + lane] = r2; recs[192 + lane] = r3;
+        if (lane == 0) free_cnt[b] = 0u;
+    }
 }
 
 // ---- 4. integration --------------------------------------------------------------------------------------
@@ -301,6 +328,8 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(Cam cam, Grid g, Po
     // the trip count below comes from device memory: clamp it to what the list can hold, so that no ordering mistake
     // upstream can ever turn into an unbounded loop or an out-of-range list read
     unsigned nmixed = min(list_counts[0], nbricks), nfree = min(list_counts[1], nbricks - nmixed);
+    const unsigned nfree_classified = nfree;
+    if (c.free_counted) nfree = 0;                          // counted by the classification, not listed
     if (DBG == 1 || DBG == 3 || DBG == 4) nfree = 0;
     if (DBG == 2) nmixed = 0;        // (list offsets below stay valid: FREE entries are addressed from the back)
     const unsigned nlist = nmixed + nfree;
@@ -481,8 +510,9 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(Cam cam, Grid g, Po
             atomicAdd(counters + 3, (unsigned long long)nwritten);
         }
         if (blockIdx.x == 0 && threadIdx.x == 0) {
-            atomicAdd(counters + 4, (unsigned long long)nlist);
-            atomicAdd(counters + 5, (unsigned long long)nfree);
+            atomicAdd(counters + 4, (unsigned long long)(nmixed + nfree_classified));
+            atomicAdd(counters + 5, (unsigned long long)nfree_classified);
+            if (c.free_counted) atomicAdd(counters + 6, (unsigned long long)nfree_classified);
         }
     }
 }
@@ -528,8 +558,9 @@ static TsdfScratch carve(const Cam &cam, void *scratch) {
     return t;
 }
 
-static TsdfConst make_const(const Cam &cam, float scale, float mind, float maxd) {
+static TsdfConst make_const(const Cam &cam, float scale, float mind, float maxd, bool free_counted = false) {
     TsdfConst c;
+    c.free_counted = free_counted ? 1 : 0;
     c.mind = mind;
     c.maxd = maxd;
     c.sc = scale;
@@ -542,7 +573,7 @@ static TsdfConst make_const(const Cam &cam, float scale, float mind, float maxd)
 
 // depth tiles + pyramid + brick classification -> compact brick list in scratch
 int launch_tsdf_prepare(hipStream_t s, const Cam &cam, const Grid &g, const PoseF &p, const Frustum &fr, const void *depth, bool depth_u16,
-                        float scale, float mind, float maxd, void *scratch) {
+                        float scale, float mind, float maxd, void *scratch, unsigned *free_cnt) {
     const TsdfConst c = make_const(cam, scale, mind, maxd);
     const TsdfScratch t = carve(cam, scratch);
     const int ntiles = t.py.ntx[0] * t.py.nty[0];
@@ -559,15 +590,23 @@ int launch_tsdf_prepare(hipStream_t s, const Cam &cam, const Grid &g, const Pose
     }
     const int ncells = ((g.nbx + 3) / 4) * ((g.nby + 3) / 4) * ((g.nbz + 3) / 4);
     hipLaunchKernelGGL(brick_cull_kernel, dim3((ncells + 3) / 4), dim3(256), 0, s, cam, g, p, fr, t.py, t.tiles, t.list,
-                       t.list_counts);
+                       t.list_counts, free_cnt);
     TL3D_HIP(hipGetLastError());
     return TL3D_OK;
 }
 
 // the dominant kernel: read-modify-write of the listed bricks
+int launch_fold_free(hipStream_t s, const Grid &g, int2 *grid, unsigned *free_cnt) {
+    const unsigned nbricks = (unsigned)(g.nbx * g.nby * g.nbz);
+    const unsigned nb = (nbricks + 3u) / 4u < 2048u ? (nbricks + 3u) / 4u : 2048u;
+    hipLaunchKernelGGL(fold_free_kernel, dim3(nb ? nb : 1), dim3(256), 0, s, grid, free_cnt, nbricks);
+    TL3D_HIP(hipGetLastError());
+    return TL3D_OK;
+}
+
 int launch_tsdf_update(hipStream_t s, const Cam &cam, const Grid &g, const PoseF &p, const void *depth, bool depth_u16, float scale, float mind,
-                       float maxd, int2 *grid, void *scratch, unsigned long long *counters, bool count) {
-    const TsdfConst c = make_const(cam, scale, mind, maxd);
+                       float maxd, int2 *grid, void *scratch, unsigned long long *counters, bool count, bool free_counted) {
+    const TsdfConst c = make_const(cam, scale, mind, maxd, free_counted);
     const TsdfScratch t = carve(cam, scratch);
     const int nbricks = g.nbx * g.nby * g.nbz;
     // 6 workgroups per CU.  The update saturates from 4 per CU upwards; with the update launches batched

@@ -126,6 +126,20 @@ static int measure_max_weight(tl3d_ctx *ctx, const int2 *grid, long long *out) {
     return TL3D_OK;
 }
 
+// pending free-space counts -> records (main stream; the deferred updates must have been issued: their classification
+// kernels, which increment the counters on the side streams, are ordered before the main stream by flush_updates)
+static int fold_free(tl3d_ctx *ctx) {
+    if (!ctx->free_cnt || !ctx->free_dirty) return TL3D_OK;
+    ctx->free_dirty = false;
+    return launch_fold_free(ctx->stream, ctx->grid, ctx->tsdf, ctx->free_cnt);
+}
+#define FLUSH_AND_FOLD(ctx_)                     \
+    do {                                         \
+        FLUSH_UPDATES(ctx_);                     \
+        const int frc_ = fold_free(ctx_);        \
+        if (frc_) return frc_;                   \
+    } while (0)
+
 static int validate_grid(const tl3d_config *cfg) {
     REQUIRE((cfg->channels & ~(TL3D_CH_TSDF | TL3D_CH_CENTROID)) == 0 && cfg->channels != 0, TL3D_E_INVALID, "bad channel bits 0x%x", cfg->channels);
     REQUIRE(cfg->nx > 0 && cfg->ny > 0 && cfg->nz > 0 && cfg->nx % TL3D_BRICK == 0 && cfg->ny % TL3D_BRICK == 0 &&
@@ -169,6 +183,13 @@ static int alloc_grid(tl3d_ctx *ctx, const tl3d_config *cfg) {
             for (int q = 0; q < ctx->n_prep_streams; ++q)
                 if (!ctx->prep_stream[q] && hipStreamCreateWithFlags(&ctx->prep_stream[q], hipStreamNonBlocking) != hipSuccess)
                     return set_err(TL3D_E_HIP, "stream create failed");
+        }
+        ctx->free_cnt = nullptr;
+        ctx->free_dirty = false;
+        if (!(getenv("TL3D_FREE_COUNTERS") && atoi(getenv("TL3D_FREE_COUNTERS")) == 0)) {
+            const size_t nbr = (size_t)g.nbx * g.nby * g.nbz;
+            if (hipMalloc(&ctx->free_cnt, nbr * sizeof(unsigned)) != hipSuccess) return set_err(TL3D_E_NOMEM, "free-space counter alloc failed");
+            if (hipMemsetAsync(ctx->free_cnt, 0, nbr * sizeof(unsigned), ctx->stream) != hipSuccess) return set_err(TL3D_E_HIP, "memset failed");
         }
         ctx->tsdf_use_u16 = !(getenv("TL3D_U16_GATHER") && atoi(getenv("TL3D_U16_GATHER")) == 0);
         const char *nb = getenv("TL3D_TSDF_BATCH");
@@ -340,6 +361,7 @@ int tl3d_destroy(tl3d_ctx *ctx) {
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->d_cen_counters) (void)hipFree(ctx->d_cen_counters);
     if (ctx->d_maxw) (void)hipFree(ctx->d_maxw);
+    if (ctx->free_cnt) (void)hipFree(ctx->free_cnt);
     for (int l = 0; l < TL3D_ICP_LANES; ++l) {
         tl3d_ctx::IcpLane &ln = ctx->icp_lanes[l];
         if (ln.stream) (void)hipStreamSynchronize(ln.stream);
@@ -362,7 +384,7 @@ int tl3d_destroy(tl3d_ctx *ctx) {
 
 int tl3d_sync(tl3d_ctx *ctx) {
     REQUIRE(ctx != nullptr, TL3D_E_INVALID, "null ctx");
-    FLUSH_UPDATES(ctx);
+    FLUSH_AND_FOLD(ctx);
     TL3D_HIP(hipSetDevice(ctx->device));
     for (int q = 0; q < 2; ++q)
         if (ctx->prep_stream[q]) TL3D_HIP(hipStreamSynchronize(ctx->prep_stream[q]));
@@ -730,7 +752,7 @@ static int flush_updates(tl3d_ctx *ctx) {
         const Slot &us = ctx->slots[u.slot];
         const bool u16 = us.has_u16 && ctx->tsdf_use_u16;
         rc = launch_tsdf_update(ctx->stream, ctx->cam, ctx->grid, u.pose, u16 ? (const void *)us.depth_u16 : (const void *)us.depth, u16, u.scale, mind, maxd, ctx->tsdf,
-                                ctx->tsdf_scratch[u.buf], ctx->d_counters, ctx->count_records);
+                                ctx->tsdf_scratch[u.buf], ctx->d_counters, ctx->count_records, ctx->free_cnt != nullptr);
         if (rc == TL3D_OK) { ctx->stats.tsdf_launches++; ++launched; }
     }
     if (kt >= 0) {
@@ -754,7 +776,7 @@ int tl3d_integrate(tl3d_ctx *ctx, int slot, const double R[9], const double t[3]
     const float mind = (float)ctx->cfg.min_depth, maxd = (float)ctx->cfg.max_depth;
     // int32 headroom: one more observation must keep every |sum_q| <= weight * 32767 below 2^31
     if (ctx->tsdf_w_unknown || ctx->tsdf_w_upper + 1 > TL3D_TSDF_MAX_WEIGHT) {
-        FLUSH_UPDATES(ctx);
+        FLUSH_AND_FOLD(ctx);
         long long w = 0;
         rc = measure_max_weight(ctx, ctx->tsdf, &w);
         if (rc) return rc;
@@ -765,16 +787,17 @@ int tl3d_integrate(tl3d_ctx *ctx, int slot, const double R[9], const double t[3]
                 w, TL3D_TSDF_MAX_WEIGHT);
     }
     ctx->tsdf_w_upper++;
+    ctx->free_dirty = true;
     Slot &sl = ctx->slots[slot];
     const bool u16 = sl.has_u16 && ctx->tsdf_use_u16;
     const void *dptr = u16 ? (const void *)sl.depth_u16 : (const void *)sl.depth;
     static const bool single = getenv("TL3D_SINGLE_STREAM") && atoi(getenv("TL3D_SINGLE_STREAM")) != 0;
     if (single) {                                       // everything in order on the caller's stream
-        rc = launch_tsdf_prepare(ctx->stream, ctx->cam, ctx->grid, p, fr, dptr, u16, (float)scale, mind, maxd, ctx->tsdf_scratch[0]);
+        rc = launch_tsdf_prepare(ctx->stream, ctx->cam, ctx->grid, p, fr, dptr, u16, (float)scale, mind, maxd, ctx->tsdf_scratch[0], ctx->free_cnt);
         if (rc) return rc;
         const int kt = ktimer_begin(ctx);
         rc = launch_tsdf_update(ctx->stream, ctx->cam, ctx->grid, p, dptr, u16, (float)scale, mind, maxd, ctx->tsdf,
-                                ctx->tsdf_scratch[0], ctx->d_counters, ctx->count_records);
+                                ctx->tsdf_scratch[0], ctx->d_counters, ctx->count_records, ctx->free_cnt != nullptr);
         if (kt >= 0) {
             ctx->ktimers[kt].launches = 1;
             (void)hipEventRecord(ctx->ktimers[kt].b, ctx->stream);
@@ -790,7 +813,7 @@ int tl3d_integrate(tl3d_ctx *ctx, int slot, const double R[9], const double t[3]
     hipStream_t ps = ctx->prep_stream[ctx->tsdf_seq++ % (unsigned)ctx->n_prep_streams];
     if (sl.ev_upload) TL3D_HIP(hipStreamWaitEvent(ps, sl.ev_upload, 0));
     if (ctx->upd_recorded[half]) TL3D_HIP(hipStreamWaitEvent(ps, ctx->ev_upd[half], 0));
-    rc = launch_tsdf_prepare(ps, ctx->cam, ctx->grid, p, fr, dptr, u16, (float)scale, mind, maxd, ctx->tsdf_scratch[b]);
+    rc = launch_tsdf_prepare(ps, ctx->cam, ctx->grid, p, fr, dptr, u16, (float)scale, mind, maxd, ctx->tsdf_scratch[b], ctx->free_cnt);
     if (rc) return rc;
     TL3D_HIP(hipEventRecord(ctx->ev_prep[b], ps));
     tl3d_ctx::PendingUpdate &u = ctx->pend[ctx->n_pend++];
@@ -991,6 +1014,8 @@ int tl3d_grid_reset(tl3d_ctx *ctx) {
     TL3D_HIP(hipSetDevice(ctx->device));
     if (ctx->tsdf) TL3D_HIP(hipMemsetAsync(ctx->tsdf, 0, ctx->nvox * sizeof(int2), ctx->stream));
     if (ctx->centroid) TL3D_HIP(hipMemsetAsync(ctx->centroid, 0, ctx->nvox * 32, ctx->stream));
+    if (ctx->free_cnt) TL3D_HIP(hipMemsetAsync(ctx->free_cnt, 0, (ctx->nvox >> 9) * sizeof(unsigned), ctx->stream));
+    ctx->free_dirty = false;
     ctx->tsdf_w_upper = 0;
     ctx->tsdf_w_unknown = false;
     return TL3D_OK;
@@ -999,7 +1024,7 @@ int tl3d_grid_reset(tl3d_ctx *ctx) {
 int tl3d_grid_device_ptr(tl3d_ctx *ctx, uint32_t channel, void **ptr, size_t *bytes) {
     REQUIRE(ptr && bytes, TL3D_E_INVALID, "null out pointer");
     if (ctx) {
-        FLUSH_UPDATES(ctx);
+        FLUSH_AND_FOLD(ctx);
         ctx->grid_epoch++;                  // the caller may write through the pointer (all-reduce)
         if (channel == TL3D_CH_TSDF) ctx->tsdf_w_unknown = true;
     }
@@ -1011,7 +1036,7 @@ int tl3d_grid_download(tl3d_ctx *ctx, uint32_t channel, void *out, size_t bytes)
     size_t nb;
     int rc = grid_sel(ctx, channel, &p, &nb);
     if (rc) return rc;
-    FLUSH_UPDATES(ctx);
+    FLUSH_AND_FOLD(ctx);
     REQUIRE(out && bytes == nb, TL3D_E_INVALID, "buffer is %zu B, grid channel is %zu B", bytes, nb);
     TL3D_HIP(hipSetDevice(ctx->device));
     TL3D_HIP(hipMemcpyAsync(out, p, nb, hipMemcpyDefault, ctx->stream));
@@ -1028,7 +1053,11 @@ int tl3d_grid_upload(tl3d_ctx *ctx, uint32_t channel, const void *in, size_t byt
     ctx->grid_epoch++;
     REQUIRE(in && bytes == nb, TL3D_E_INVALID, "buffer is %zu B, grid channel is %zu B", bytes, nb);
     TL3D_HIP(hipSetDevice(ctx->device));
-    if (channel == TL3D_CH_TSDF) ctx->tsdf_w_unknown = true;
+    if (channel == TL3D_CH_TSDF) {
+        ctx->tsdf_w_unknown = true;
+        if (ctx->free_cnt) TL3D_HIP(hipMemsetAsync(ctx->free_cnt, 0, (ctx->nvox >> 9) * sizeof(unsigned), ctx->stream));   // the upload replaces the channel
+        ctx->free_dirty = false;
+    }
     TL3D_HIP(hipMemcpyAsync(p, in, nb, hipMemcpyDefault, ctx->stream));
     TL3D_HIP(hipStreamSynchronize(ctx->stream));
     return TL3D_OK;
@@ -1039,7 +1068,7 @@ int tl3d_grid_add(tl3d_ctx *ctx, uint32_t channel, const void *other, size_t byt
     size_t nb;
     int rc = grid_sel(ctx, channel, &p, &nb);
     if (rc) return rc;
-    FLUSH_UPDATES(ctx);
+    FLUSH_AND_FOLD(ctx);
     ctx->grid_epoch++;
     REQUIRE(other && bytes == nb, TL3D_E_INVALID, "buffer is %zu B, grid channel is %zu B", bytes, nb);
     TL3D_HIP(hipSetDevice(ctx->device));
@@ -1076,7 +1105,7 @@ int tl3d_grid_add(tl3d_ctx *ctx, uint32_t channel, const void *other, size_t byt
 int tl3d_grid_max_weight(tl3d_ctx *ctx, int64_t *out) {
     REQUIRE(ctx && out, TL3D_E_INVALID, "null argument");
     REQUIRE(ctx->tsdf != nullptr, TL3D_E_STATE, "TSDF channel not enabled");
-    FLUSH_UPDATES(ctx);
+    FLUSH_AND_FOLD(ctx);
     TL3D_HIP(hipSetDevice(ctx->device));
     long long w = 0;
     const int rc = measure_max_weight(ctx, ctx->tsdf, &w);
@@ -1094,7 +1123,7 @@ int tl3d_extract(tl3d_ctx *ctx, int mode, int min_count, int min_weight, double 
     REQUIRE(mode == TL3D_EXTRACT_CENTROID || mode == TL3D_EXTRACT_TSDF, TL3D_E_INVALID, "bad mode %d", mode);
     if (mode == TL3D_EXTRACT_CENTROID) REQUIRE(ctx->centroid != nullptr, TL3D_E_STATE, "centroid channel not enabled");
     if (mode == TL3D_EXTRACT_TSDF) REQUIRE(ctx->tsdf != nullptr, TL3D_E_STATE, "TSDF channel not enabled");
-    FLUSH_UPDATES(ctx);
+    FLUSH_AND_FOLD(ctx);
     TL3D_HIP(hipSetDevice(ctx->device));
     const int nblocks = (int)((ctx->nvox + EXTRACT_CHUNK - 1) / EXTRACT_CHUNK);
     int rc = ensure_scratch_blocks(ctx, (size_t)nblocks + 1);
@@ -1211,6 +1240,7 @@ int tl3d_get_stats(tl3d_ctx *ctx, tl3d_stats *out) {
     ctx->stats.tsdf_records_written = h[3];
     ctx->stats.tsdf_bricks_visited = h[4];
     ctx->stats.tsdf_bricks_free = h[5];
+    ctx->stats.tsdf_bricks_free_counted = h[6];
     *out = ctx->stats;
     return TL3D_OK;
 }

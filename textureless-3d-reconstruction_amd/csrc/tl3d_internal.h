@@ -129,6 +129,11 @@ struct tl3d_ctx {
     // int32 headroom of the TSDF sums: |sum_q| <= weight * 32767 stays below 2^31 while weight <= TL3D_TSDF_MAX_WEIGHT.
     // tsdf_w_upper bounds the largest voxel weight from above (+1 per integrated frame); when it reaches the limit, or after
     // a merge the library could not see (grid upload, grid pointer handed out), it is re-measured by a reduction over the grid
+    // Free-space counters: a brick that is wholly free space in a frame gets +1 here (one integer add by the classification
+    // kernel) instead of (+32767, +1) on each of its 512 records; the pending counts are folded into the records before
+    // anything reads the TSDF channel.  TL3D_FREE_COUNTERS=0 keeps the round-1 behaviour (records streamed every frame).
+    unsigned *free_cnt;
+    bool free_dirty;
     long long tsdf_w_upper;
     bool tsdf_w_unknown;
     int *d_maxw;
@@ -198,9 +203,10 @@ int launch_bounds(hipStream_t s, const float *xyz, long long n, float *slab, int
 // tsdf
 size_t tsdf_scratch_bytes(const Cam &cam, const Grid &g);
 int launch_tsdf_prepare(hipStream_t s, const Cam &cam, const Grid &g, const PoseF &p, const Frustum &fr, const void *depth, bool depth_u16,
-                        float scale, float mind, float maxd, void *scratch);
+                        float scale, float mind, float maxd, void *scratch, unsigned *free_cnt);
 int launch_tsdf_update(hipStream_t s, const Cam &cam, const Grid &g, const PoseF &p, const void *depth, bool depth_u16, float scale, float mind,
-                       float maxd, int2 *grid, void *scratch, unsigned long long *counters, bool count);
+                       float maxd, int2 *grid, void *scratch, unsigned long long *counters, bool count, bool free_counted);
+int launch_fold_free(hipStream_t s, const Grid &g, int2 *grid, unsigned *free_cnt);
 // normals + icp
 int launch_normals(hipStream_t s, const Cam &cam, const float *depth, float scale, float mind, float maxd, float jump, float4 *nmap);
 int launch_icp_iteration(hipStream_t s, const Cam &cam, const IcpRun *run, int final_pass, double *slab, IcpState *state, int nblocks,
