@@ -5,7 +5,10 @@
 // depth map into integer accumulators (exact, order-free => bit-reproducible, and the multi-GPU merge is a sum).
 //
 // record (32 B, one 32-B sector): u64[4] = { sx | sy<<32, sz | n<<32, sr | sg<<32, sb }, s* in units of voxel/4096.
-// One thread per sampled pixel; runs of adjacent lanes that share a voxel are combined in the wave before the atomics.
+// One thread per sampled pixel.  Points that share a voxel are combined on chip before anything reaches the grid: first
+// runs of adjacent lanes in the wave (segmented shuffle scan), then -- per-frame kernel -- across the workgroup's 32 x 8
+// tile of samples in an LDS table keyed by the record index (LDS-staged voxel-block accumulation); only one set of four
+// 64-bit atomics per distinct voxel and tile goes to HBM.
 #include "bp_device.h"
 #include "tl3d_internal.h"
 
@@ -54,7 +57,7 @@ __device__ __forceinline__ unsigned long long shfl_down_u64(unsigned long long v
 // first sums each run of adjacent lanes with equal record index (segmented inclusive scan: 6 shuffle steps) and only the
 // last lane of a run issues the four 64-bit atomics.  Integer sums: the grid is the same bit for bit, with ~4-8x fewer
 // atomics.  Every lane of the wave must call this (the shuffles need a full EXEC mask).
-__device__ __forceinline__ void centroid_commit_runs(CenAdd k, unsigned long long *__restrict__ grid) {
+__device__ __forceinline__ bool centroid_reduce_runs(CenAdd &k) {
     const int lane = threadIdx.x & 63;
     const unsigned long long prev_rec = shfl_up_u64(k.rec, 1), next_rec = shfl_down_u64(k.rec, 1);   // all lanes, no short-circuit
     const bool head = (lane == 0) | (prev_rec != k.rec);
@@ -70,7 +73,11 @@ __device__ __forceinline__ void centroid_commit_runs(CenAdd k, unsigned long lon
         if (lane - d >= start) { k.a += oa; k.b += ob; k.c += oc; k.d += od; }
     }
     const bool tail = (lane == 63) | (next_rec != k.rec);
-    if (tail && k.rec != ~0ull) {
+    return tail && k.rec != ~0ull;                                // this lane now carries its run's sums
+}
+
+__device__ __forceinline__ void centroid_commit_runs(CenAdd k, unsigned long long *__restrict__ grid) {
+    if (centroid_reduce_runs(k)) {
         unsigned long long *rec = grid + 4 * k.rec;
         atomicAdd(rec + 0, k.a);
         atomicAdd(rec + 1, k.b);
@@ -79,17 +86,19 @@ __device__ __forceinline__ void centroid_commit_runs(CenAdd k, unsigned long lon
     }
 }
 
-__global__ __launch_bounds__(256) void centroid_frame_kernel(Cam cam, Grid g, BpArgs a, PoseD p, const float *__restrict__ depth,
-                                                             const uint8_t *__restrict__ bgr, unsigned long long *__restrict__ grid,
-                                                             unsigned long long *__restrict__ counters) {
-    const long long s = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long ns = (long long)a.Ws * a.Hs;
+// LDS table of the per-frame kernel: open addressing, 1024 slots for the at most 1024 samples of a 32 x 32 tile (never more
+// distinct keys than slots, so every probe sequence ends); key = record index + 1 (0 = empty), four 64-bit sums per slot.
+// Dense sampling only (stride 1 and 2: 74 / 18 pixels per 5 mm voxel at 1 m); from stride 3 on neighbouring samples
+// rarely share a voxel and the points go straight to the grid (centroid_direct_kernel).
+constexpr int CEN_TW = 32, CEN_TH = 32, CEN_SLOTS = 1024;
+
+__device__ __forceinline__ CenAdd centroid_sample(const Cam &cam, const Grid &g, const BpArgs &a, const PoseD &p, const float *__restrict__ depth,
+                                                  const uint8_t *__restrict__ bgr, int us, int vs, bool &valid) {
     CenAdd k;
     k.rec = ~0ull;
     k.a = k.b = k.c = k.d = 0;
-    bool valid = false;
-    if (s < ns) {
-        const int vs = (int)(s / a.Ws), us = (int)(s - (long long)vs * a.Ws);
+    valid = false;
+    if (us < a.Ws && vs < a.Hs) {
         const int u = us * a.sub, v = vs * a.sub;
         float pt[3];
         if (bp_pixel(cam, a, p, depth, u, v, pt)) {
@@ -102,14 +111,86 @@ __global__ __launch_bounds__(256) void centroid_frame_kernel(Cam cam, Grid g, Bp
             k = centroid_key(g, pt, r8, g8, b8);
         }
     }
-    // statistics: one pair of adds per workgroup into one of 256 counter lines (a single hot word would serialise the
-    // whole launch: same-address atomics retire at ~90 per microsecond)
-    const int nvalid = __syncthreads_count(valid), nkept = __syncthreads_count(k.rec != ~0ull);
-    if (threadIdx.x == 0 && nvalid) {
+    return k;
+}
+
+// statistics: one pair of adds per workgroup into one of 256 counter lines (a single hot word would serialise the whole
+// launch: same-address atomics retire at ~90 per microsecond)
+__device__ __forceinline__ void centroid_stats(int nvalid_thread, int nkept_thread, unsigned long long *__restrict__ counters) {
+    __shared__ int s_n[2];
+    if (threadIdx.x == 0) { s_n[0] = 0; s_n[1] = 0; }
+    __syncthreads();
+    int v = nvalid_thread, k = nkept_thread;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { v += __shfl_down(v, d); k += __shfl_down(k, d); }
+    if ((threadIdx.x & 63) == 0 && v) { atomicAdd(&s_n[0], v); atomicAdd(&s_n[1], k); }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_n[0]) {
         unsigned long long *line = counters + (size_t)(blockIdx.x & 255) * 8;
-        atomicAdd(line + 0, (unsigned long long)nkept);
-        atomicAdd(line + 1, (unsigned long long)(nvalid - nkept));
+        atomicAdd(line + 0, (unsigned long long)s_n[1]);
+        atomicAdd(line + 1, (unsigned long long)(s_n[0] - s_n[1]));
     }
+}
+
+__global__ __launch_bounds__(256) void centroid_frame_kernel(Cam cam, Grid g, BpArgs a, PoseD p, const float *__restrict__ depth,
+                                                             const uint8_t *__restrict__ bgr, unsigned long long *__restrict__ grid,
+                                                             unsigned long long *__restrict__ counters, int tiles_x) {
+    __shared__ unsigned long long s_key[CEN_SLOTS];
+    __shared__ unsigned long long s_val[CEN_SLOTS][4];
+    for (int h = threadIdx.x; h < CEN_SLOTS; h += 256) {
+        s_key[h] = 0ull;
+        s_val[h][0] = 0ull; s_val[h][1] = 0ull; s_val[h][2] = 0ull; s_val[h][3] = 0ull;
+    }
+    __syncthreads();
+    // the workgroup's samples: a 32 x 32 tile of the (sub-sampled) image, 8 rows at a time, so that voxels are shared
+    // across rows too (a 5 mm voxel spans ~8 x 8 pixels at 1 m)
+    const int tx = (int)(blockIdx.x % (unsigned)tiles_x), ty = (int)(blockIdx.x / (unsigned)tiles_x);
+    const int us = tx * CEN_TW + (threadIdx.x & (CEN_TW - 1));
+    int nvalid = 0, nkept = 0;
+#pragma unroll
+    for (int r = 0; r < CEN_TH / 8; ++r) {
+        const int vs = ty * CEN_TH + r * 8 + (threadIdx.x >> 5);
+        bool valid;
+        CenAdd k = centroid_sample(cam, g, a, p, depth, bgr, us, vs, valid);
+        nvalid += valid ? 1 : 0;
+        nkept += (k.rec != ~0ull) ? 1 : 0;
+        if (centroid_reduce_runs(k)) {                            // one lane per run of equal voxels: into the LDS table
+            const unsigned long long key = k.rec + 1ull;
+            unsigned h = (unsigned)((k.rec * 0x9E3779B97F4A7C15ull) >> 54) & (CEN_SLOTS - 1);
+            for (;;) {
+                const unsigned long long old = atomicCAS(&s_key[h], 0ull, key);
+                if (old == 0ull || old == key) break;
+                h = (h + 1u) & (CEN_SLOTS - 1);
+            }
+            atomicAdd(&s_val[h][0], k.a);
+            atomicAdd(&s_val[h][1], k.b);
+            atomicAdd(&s_val[h][2], k.c);
+            atomicAdd(&s_val[h][3], k.d);
+        }
+    }
+    centroid_stats(nvalid, nkept, counters);                      // (its barriers also complete the table)
+    for (int h = threadIdx.x; h < CEN_SLOTS; h += 256) {          // one set of grid atomics per distinct voxel of the tile
+        const unsigned long long key = s_key[h];
+        if (key != 0ull) {
+            unsigned long long *rec = grid + 4 * (key - 1ull);
+            atomicAdd(rec + 0, s_val[h][0]);
+            atomicAdd(rec + 1, s_val[h][1]);
+            atomicAdd(rec + 2, s_val[h][2]);
+            atomicAdd(rec + 3, s_val[h][3]);
+        }
+    }
+}
+
+// sparse sampling (stride >= 3): one thread per sample in row-major order, runs combined in the wave, straight to the grid
+__global__ __launch_bounds__(256) void centroid_direct_kernel(Cam cam, Grid g, BpArgs a, PoseD p, const float *__restrict__ depth,
+                                                              const uint8_t *__restrict__ bgr, unsigned long long *__restrict__ grid,
+                                                              unsigned long long *__restrict__ counters) {
+    const long long s = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long ns = (long long)a.Ws * a.Hs;
+    const int vs = (int)(s / a.Ws), us = (int)(s - (long long)vs * a.Ws);
+    bool valid;
+    CenAdd k = centroid_sample(cam, g, a, p, depth, bgr, s < ns ? us : a.Ws, vs, valid);
+    centroid_stats(valid ? 1 : 0, (k.rec != ~0ull) ? 1 : 0, counters);
     centroid_commit_runs(k, grid);
 }
 
@@ -126,14 +207,7 @@ __global__ __launch_bounds__(256) void centroid_points_kernel(Grid g, const floa
         const float pt[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
         k = centroid_key(g, pt, rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]);
     }
-    // statistics: one pair of adds per workgroup into one of 256 counter lines (a single hot word would serialise the
-    // whole launch: same-address atomics retire at ~90 per microsecond)
-    const int nvalid = __syncthreads_count(valid), nkept = __syncthreads_count(k.rec != ~0ull);
-    if (threadIdx.x == 0 && nvalid) {
-        unsigned long long *line = counters + (size_t)(blockIdx.x & 255) * 8;
-        atomicAdd(line + 0, (unsigned long long)nkept);
-        atomicAdd(line + 1, (unsigned long long)(nvalid - nkept));
-    }
+    centroid_stats(valid ? 1 : 0, (k.rec != ~0ull) ? 1 : 0, counters);
     centroid_commit_runs(k, grid);
 }
 
@@ -186,9 +260,14 @@ __global__ __launch_bounds__(256) void add_u64_kernel(ulonglong2 *__restrict__ d
 
 int launch_centroid_frame(hipStream_t s, const Cam &cam, const Grid &g, const BpArgs &a, const PoseD &p, const float *depth,
                           const uint8_t *bgr, unsigned long long *grid, unsigned long long *counters) {
-    const long long ns = (long long)a.Ws * a.Hs;
-    const unsigned nb = (unsigned)((ns + 255) / 256);
-    hipLaunchKernelGGL(centroid_frame_kernel, dim3(nb), dim3(256), 0, s, cam, g, a, p, depth, bgr, grid, counters);
+    if (a.sub >= 3) {
+        const long long ns = (long long)a.Ws * a.Hs;
+        hipLaunchKernelGGL(centroid_direct_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, s, cam, g, a, p, depth, bgr, grid, counters);
+    } else {
+        const int tiles_x = (a.Ws + CEN_TW - 1) / CEN_TW, tiles_y = (a.Hs + CEN_TH - 1) / CEN_TH;
+        hipLaunchKernelGGL(centroid_frame_kernel, dim3((unsigned)tiles_x * (unsigned)tiles_y), dim3(256), 0, s, cam, g, a, p, depth, bgr, grid,
+                           counters, tiles_x);
+    }
     TL3D_HIP(hipGetLastError());
     return TL3D_OK;
 }
