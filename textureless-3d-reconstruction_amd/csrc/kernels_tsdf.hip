@@ -316,7 +316,9 @@ __device__ __forceinline__ bool tsdf_finish(const Grid &g, const TsdfConst &c, b
 //      stores stay predicated.  Reads 4 KB per MIXED brick whatever changes (counted as read).
 //   2  as 1, and the NEXT listed brick's records are requested right behind this brick's gathers (one brick of look-ahead
 //      per wave): the record stream never waits for the gather phase.
-template <bool COUNT, int DBG, int MAP, typename DT, int VAR>
+// FREEB: the list may hold free-space bricks (TL3D_FREE_COUNTERS=0, the round-1 formulation); false = they were counted by
+// the classification, the kernel only sees MIXED bricks (a separate instantiation, so that profiles tell the two apart).
+template <bool COUNT, int DBG, int MAP, typename DT, int VAR, bool FREEB>
 __global__ __launch_bounds__(256) void tsdf_integrate_kernel(Cam cam, Grid g, PoseF pose, TsdfConst c,
                                                              const DT *__restrict__ depth,
                                                              const unsigned *__restrict__ list,
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(Cam cam, Grid g, Po
     // upstream can ever turn into an unbounded loop or an out-of-range list read
     unsigned nmixed = min(list_counts[0], nbricks), nfree = min(list_counts[1], nbricks - nmixed);
     const unsigned nfree_classified = nfree;
-    if (c.free_counted) nfree = 0;                          // counted by the classification, not listed
+    if (!FREEB || c.free_counted) nfree = 0;                // counted by the classification, not listed
     if (DBG == 1 || DBG == 3 || DBG == 4) nfree = 0;
     if (DBG == 2) nmixed = 0;        // (list offsets below stay valid: FREE entries are addressed from the back)
     const unsigned nlist = nmixed + nfree;
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(Cam cam, Grid g, Po
         }
         const int brick = (int)(e & ~FREE_FLAG);
         int4 *__restrict__ recs = reinterpret_cast<int4 *>(grid + ((size_t)brick << 9));
-        if (e & FREE_FLAG) {
+        if (FREEB && (e & FREE_FLAG)) {
             int4 r0 = recs[lane], r1 = recs[64 + lane], r2 = recs[128 + lane], r3 = recs[192 + lane];
             if (VAR == 2 && PREF && have_next && !(e_next & FREE_FLAG) && !pre_valid) {   // keep the look-ahead primed across a FREE brick
                 const int2 *__restrict__ nx2 = reinterpret_cast<const int2 *>(grid + ((size_t)(e_next & ~FREE_FLAG) << 9));
@@ -621,20 +623,25 @@ int launch_tsdf_update(hipStream_t s, const Cam &cam, const Grid &g, const PoseF
     const float ax = fabsf(p.r[3]), ay = fabsf(p.r[4]), az = fabsf(p.r[5]);
     int map = (ay >= ax && ay >= az) ? 2 : (az >= ax ? 1 : 0);
     if (force_map >= 0 && force_map <= 2) map = force_map;
-#define TL3D_LAUNCH_UPD(C_, D_, M_, V_)                                                                                            \
+#define TL3D_LAUNCH_UPD(C_, D_, M_, V_, F_)                                                                                            \
     do {                                                                                                                         \
         if (depth_u16)                                                                                                           \
-            hipLaunchKernelGGL((tsdf_integrate_kernel<C_, D_, M_, uint16_t, V_>), dim3(nblk), dim3(256), 0, s, cam, g, p, c,     \
+            hipLaunchKernelGGL((tsdf_integrate_kernel<C_, D_, M_, uint16_t, V_, F_>), dim3(nblk), dim3(256), 0, s, cam, g, p, c, \
                                static_cast<const uint16_t *>(depth), t.list, t.list_counts, grid, counters);                      \
         else                                                                                                                     \
-            hipLaunchKernelGGL((tsdf_integrate_kernel<C_, D_, M_, float, V_>), dim3(nblk), dim3(256), 0, s, cam, g, p, c,        \
+            hipLaunchKernelGGL((tsdf_integrate_kernel<C_, D_, M_, float, V_, F_>), dim3(nblk), dim3(256), 0, s, cam, g, p, c,    \
                                static_cast<const float *>(depth), t.list, t.list_counts, grid, counters);                         \
     } while (0)
-#define TL3D_LAUNCH_MAP(C_, D_, V_)                        \
-    do {                                                   \
-        if (map == 2) TL3D_LAUNCH_UPD(C_, D_, 2, V_);      \
-        else if (map == 1) TL3D_LAUNCH_UPD(C_, D_, 1, V_); \
-        else TL3D_LAUNCH_UPD(C_, D_, 0, V_);               \
+#define TL3D_LAUNCH_MAPF(C_, D_, V_, F_)                       \
+    do {                                                       \
+        if (map == 2) TL3D_LAUNCH_UPD(C_, D_, 2, V_, F_);      \
+        else if (map == 1) TL3D_LAUNCH_UPD(C_, D_, 1, V_, F_); \
+        else TL3D_LAUNCH_UPD(C_, D_, 0, V_, F_);               \
+    } while (0)
+#define TL3D_LAUNCH_MAP(C_, D_, V_)                             \
+    do {                                                        \
+        if (free_counted) TL3D_LAUNCH_MAPF(C_, D_, V_, false);  \
+        else TL3D_LAUNCH_MAPF(C_, D_, V_, true);                \
     } while (0)
 #define TL3D_LAUNCH_VAR(C_)                         \
     do {                                            \
@@ -650,6 +657,7 @@ int launch_tsdf_update(hipStream_t s, const Cam &cam, const Grid &g, const PoseF
     else if (dbg == 4) TL3D_LAUNCH_MAP(false, 4, 0);
     else TL3D_LAUNCH_VAR(false);
 #undef TL3D_LAUNCH_VAR
+#undef TL3D_LAUNCH_MAPF
 #undef TL3D_LAUNCH_MAP
 #undef TL3D_LAUNCH_UPD
     TL3D_HIP(hipGetLastError());

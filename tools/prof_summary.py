@@ -48,30 +48,62 @@ for k in sorted(agg):
     for c in sorted(agg[k]):
         print(f"    {c:36s} {agg[k][c] / max(1, cnt[k][c]):18.1f}  (n={cnt[k][c]})")
 
-key = [k for k in agg if "tsdf_integrate_kernel<false, 0" in k]      # production variant (any lane map)
+def mean_of(pattern, counter, kernel_tag):
+    tot, n = 0.0, 0
+    for r in rows(pattern):
+        if kernel_tag in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter:
+            tot += float(r.get("Counter_Value", 0))
+            n += 1
+    return tot / n if n else None
+
+
+def bench_json(name):
+    for f in glob.glob(os.path.join(out, name)):
+        for line in open(f):
+            if line.startswith("{"):
+                return json.loads(line)
+    return None
+
+
+key = [k for k in agg if "tsdf_integrate_kernel<false, 0" in k and k.rstrip(">").endswith("false")]      # production variant: free space counted (any lane map)
 if key and "FETCH_SIZE" in agg[key[0]] and "WRITE_SIZE" in agg[key[0]]:
     k = key[0]
     fetch_kb = agg[k]["FETCH_SIZE"] / cnt[k]["FETCH_SIZE"]
     write_kb = agg[k]["WRITE_SIZE"] / cnt[k]["WRITE_SIZE"]
-    # FETCH_SIZE tallies 16-B-per-lane streaming reads (the free-space bricks) at half their bytes and this kernel's 8-B
-    # predicated loads and 4-B gathers at face value (calibrated: TL3D_DEBUG_ONLY=2 / =1 runs, see profiles/pmc_traffic.json);
-    # so the correction is one more copy of what the free-space bricks alone fetch (calibration pass pmc_free)
-    kfree = [q for q in agg if "tsdf_integrate_kernel<false, 2" in q and "FETCH_SIZE" in agg[q]]
-    fetch_free_kb = agg[kfree[0]]["FETCH_SIZE"] / cnt[kfree[0]]["FETCH_SIZE"] if kfree else None
-    traffic = ((fetch_kb + fetch_free_kb + write_kb) if fetch_free_kb is not None else (2.0 * fetch_kb + write_kb)) * 1024.0
-    alg = None
-    for f in glob.glob(os.path.join(out, "bench_pmc1.log")):
-        for line in open(f):
-            if line.startswith("{"):
-                alg = json.loads(line)["roofline"]["bytes_per_launch"]
-    j = {"grid": 512, "width": 1080, "height": 1920, "kernel": "tsdf_integrate_kernel",
-         "fetch_size_kb": round(fetch_kb, 1), "fetch_size_free_bricks_only_kb": None if fetch_free_kb is None else round(fetch_free_kb, 1),
-         "write_size_kb": round(write_kb, 1),
-         "hbm_bytes_per_launch": int(traffic), "algorithmic_bytes_per_launch": alg,
-         "note": "traffic = (FETCH_SIZE + FETCH_SIZE of the free-space bricks alone + WRITE_SIZE) * 1024: FETCH_SIZE on gfx950 "
-                 "reports half the bytes of 16-B-per-lane streaming reads (MI355X_MICROARCH.md, HBM) -- the free-space bricks, "
-                 "calibrated x2.04 -- and this kernel's predicated 8-B loads and 4-B gathers at face value (calibrated x1.0); "
-                 "without the calibration pass the fallback is the upper bound 2*FETCH_SIZE + WRITE_SIZE"}
+    b1 = bench_json("bench_pmc1.log")
+    alg = b1["roofline"]["bytes_per_launch"] if b1 else None
+    counted = bool(b1 and b1["roofline"].get("free_space_bricks_counted_per_launch", 0) > 0)
+    # Calibration of FETCH_SIZE on THIS kernel's access patterns (the guide: FETCH_SIZE reports exactly half the bytes of
+    # 16-B-per-lane streaming reads on gfx950; other widths must be calibrated on a known byte count):
+    #   variant 2 reads all 512 records of every listed brick with 8-B-per-lane loads -> known bytes = 4096 x listed bricks
+    cal = None
+    f_v2 = mean_of("cal_v2/**/*counter_collection.csv", "FETCH_SIZE", "tsdf_integrate_kernel<false, 0")
+    b_v2 = bench_json("bench_cal_v2.log")
+    if f_v2 and b_v2:
+        r2 = b_v2["roofline"]
+        listed = r2["bricks_visited_per_launch"] - r2["free_space_bricks_counted_per_launch"]
+        known = 4096.0 * listed                                  # record bytes read; the depth image (mostly cache hits) comes on top
+        cal = {"variant2_fetch_size_kb": round(f_v2, 1), "variant2_known_record_bytes_read": int(known),
+               "factor_8B_per_lane_reads": round(f_v2 * 1024.0 / known, 3)}
+    traffic = (fetch_kb + write_kb) * 1024.0                      # 8-B-per-lane loads, 4-B gathers and stores at face value (factor above ~1.0)
+    j = {"grid": 512, "width": 1080, "height": 1920, "depth_format": "f32", "free_space_counters": counted,
+         "kernel": "tsdf_integrate_kernel", "fetch_size_kb": round(fetch_kb, 1), "write_size_kb": round(write_kb, 1),
+         "hbm_bytes_per_launch": int(traffic), "algorithmic_bytes_per_launch": alg, "calibration": cal,
+         "note": "traffic = (FETCH_SIZE + WRITE_SIZE) * 1024 from separate --pmc passes.  The guide's gfx950 correction (FETCH_SIZE "
+                 "reports half the bytes of 16-B-per-lane streaming reads) does not apply to this kernel since free-space bricks are "
+                 "counted instead of streamed: its reads are 8-B-per-lane predicated loads and 4-B gathers, calibrated at face value "
+                 "on a known byte count (calibration.factor_8B_per_lane_reads)."}
+    # the round-1 formulation (free-space bricks streamed), for the second roofline object of bench.py
+    f_s = mean_of("str_1/**/*counter_collection.csv", "FETCH_SIZE", "tsdf_integrate_kernel<false, 0")
+    w_s = mean_of("str_2/**/*counter_collection.csv", "WRITE_SIZE", "tsdf_integrate_kernel<false, 0")
+    f_free = mean_of("str_free/**/*counter_collection.csv", "FETCH_SIZE", "tsdf_integrate_kernel<false, 2")
+    b_s = bench_json("bench_str1.log")
+    if f_s and w_s and f_free and b_s:
+        j["free_space_streamed"] = {"fetch_size_kb": round(f_s, 1), "fetch_size_free_bricks_only_kb": round(f_free, 1), "write_size_kb": round(w_s, 1),
+                                    "hbm_bytes_per_launch": int((f_s + f_free + w_s) * 1024.0),
+                                    "algorithmic_bytes_per_launch": b_s["roofline"]["bytes_per_launch"],
+                                    "note": "FETCH_SIZE + one more copy of what the free-space bricks alone fetch (16 B per lane: reported at "
+                                            "half their bytes) + WRITE_SIZE"}
     with open(os.path.join(out, "pmc_traffic.json"), "w") as f:
         json.dump(j, f, indent=1)
     print("== traffic ==")
