@@ -216,6 +216,19 @@ int tl3d_grid_add(tl3d_ctx *ctx, uint32_t channel, const void *other_hd, size_t 
 /* largest number of observations any voxel of the TSDF channel holds (one reduction over the grid, blocks) */
 int tl3d_grid_max_weight(tl3d_ctx *ctx, int64_t *out);
 
+/* e: the merge step of the multi-GPU path for hosts WITHOUT torch.distributed (frames shard across
+ * ranks, one sum all-reduce of the per-GPU grids at merge time).  One process per GPU; rank 0 obtains an id and hands it
+ * to the others by any means (file, socket, MPI); every rank then joins and merges.  RCCL is loaded at run time
+ * (librccl.so, the copy already in the process if there is one), so libtl3d.so itself does not depend on it.  The
+ * all-reduce runs on the context's stream, in place on the grid memory (int32 / uint64 sums: the merged grid is
+ * bit-identical to a single-GPU run); the TSDF channel's int32 headroom (TL3D_TSDF_MAX_WEIGHT) is checked over all ranks
+ * first and the merge refused with TL3D_E_STATE if it could wrap.  Python hosts use tl3d.distributed (same operations
+ * through torch.distributed on tl3d_grid_device_ptr memory). */
+#define TL3D_RCCL_ID_BYTES 128
+int tl3d_rccl_unique_id(uint8_t id_out[TL3D_RCCL_ID_BYTES]);
+int tl3d_rccl_init(tl3d_ctx *ctx, int world, int rank, const uint8_t id[TL3D_RCCL_ID_BYTES]);
+int tl3d_allreduce_grid(tl3d_ctx *ctx, uint32_t channels /* TL3D_CH_* mask; 0 = every channel the grid has */);
+
 /* a7 (read-back half) + N4: fused grid -> point list. min_count: centroid occupancy threshold;
  * tsdf gate (centroid mode, only if the TSDF channel exists and min_weight > 0): keep voxels with
  * weight >= min_weight and |mean tsdf| <= max_abs_tsdf. */

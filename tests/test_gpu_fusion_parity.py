@@ -504,3 +504,30 @@ def c_oracle_like(orc):
     c = orc.cfg
     return c_oracle.Oracle(c.width, c.height, c.fx, c.fy, c.cx, c.cy, c.min_depth, c.max_depth, dims=(c.nx, c.ny, c.nz),
                            origin=tuple(c.origin), voxel_size=c.voxel_size, sdf_trunc=c.sdf_trunc)
+
+
+def test_c_abi_rccl_merge_single_rank():
+    """tl3d_rccl_unique_id / tl3d_rccl_init / tl3d_allreduce_grid: the merge step for hosts without torch.distributed, RCCL
+    resolved at run time.  One rank on the one GPU of this box: the all-reduce is the identity, the int32 headroom check
+    runs over 'all' ranks, the grid stays the oracle's; a second join is refused."""
+    poses, frames = small_scene_frames(n=3, deg=6.0)
+    ctx, orc = make_pair(dims=(64, 64, 64), voxel=0.04)
+    with ctx:
+        for i, (d, c) in enumerate(frames):
+            ctx.upload(i, d, c)
+            ctx.integrate(i, poses[i])
+            ctx.accumulate_centroid(i, poses[i], subsample=2)
+            orc.tsdf_integrate(d, poses[i][0], poses[i][1])
+            orc.centroid_accumulate(d, c, poses[i][0], poses[i][1], subsample=2)
+        with pytest.raises(tl3d.Tl3dError):
+            ctx.allreduce_grid()                                   # no communicator yet
+        uid = tl3d.FusionContext.rccl_unique_id()
+        assert len(uid) == 128 and any(uid)
+        ctx.rccl_init(1, 0, uid)
+        ctx.allreduce_grid()                                       # both channels; folds the free-space counts first
+        assert np.array_equal(ctx.download_grid(tl3d.CH_TSDF), orc.tsdf)
+        assert np.array_equal(ctx.download_grid(tl3d.CH_CENTROID), orc.centroid)
+        ctx.allreduce_grid(tl3d.CH_TSDF)
+        assert np.array_equal(ctx.download_grid(tl3d.CH_TSDF), orc.tsdf)
+        with pytest.raises(tl3d.Tl3dError):
+            ctx.rccl_init(1, 0, uid)

@@ -1,4 +1,5 @@
 // tl3d_api.hip -- the extern "C" surface declared in include/tl3d.h: context, frame slots, launch glue.
+#include <dlfcn.h>
 #include <stdarg.h>
 #include <stdlib.h>
 #include <math.h>
@@ -26,6 +27,42 @@ int set_err(int code, const char *fmt, ...) {
     do {                                                   \
         if (!(cond)) return set_err((code), __VA_ARGS__);  \
     } while (0)
+
+// The five RCCL entry points the merge needs, resolved at run time; enum values from rccl.h (ncclInt32 = 2, ncclInt64 = 4,
+// ncclUint64 = 5, ncclSum = 0).
+namespace {
+struct Rccl {
+    void *lib = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, const void *, int) = nullptr;      // ncclUniqueId is passed BY VALUE in C: see rccl_init_rank
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+struct RcclId { char bytes[TL3D_RCCL_ID_BYTES]; };
+Rccl g_rccl;
+
+int rccl_load() {
+    if (g_rccl.lib) return TL3D_OK;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+        g_rccl.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (g_rccl.lib) break;
+    }
+    if (!g_rccl.lib) return set_err(TL3D_E_STATE, "RCCL (librccl.so) could not be loaded: %s", dlerror());
+    g_rccl.GetUniqueId = (int (*)(void *))dlsym(g_rccl.lib, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (int (*)(void **, int, const void *, int))dlsym(g_rccl.lib, "ncclCommInitRank");
+    g_rccl.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(g_rccl.lib, "ncclAllReduce");
+    g_rccl.CommDestroy = (int (*)(void *))dlsym(g_rccl.lib, "ncclCommDestroy");
+    g_rccl.GetErrorString = (const char *(*)(int))dlsym(g_rccl.lib, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy) {
+        g_rccl.lib = nullptr;
+        return set_err(TL3D_E_STATE, "librccl.so lacks the expected entry points");
+    }
+    return TL3D_OK;
+}
+const char *rccl_msg(int rc) { return g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "RCCL error"; }
+}  // namespace
+
 
 static bool is_device_ptr(const void *p) {
     if (!p) return false;
@@ -360,6 +397,7 @@ int tl3d_destroy(tl3d_ctx *ctx) {
     if (ctx->bp_stage_rgb) (void)hipFree(ctx->bp_stage_rgb);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->d_cen_counters) (void)hipFree(ctx->d_cen_counters);
+    if (ctx->rccl_comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(ctx->rccl_comm);
     if (ctx->d_maxw) (void)hipFree(ctx->d_maxw);
     if (ctx->free_cnt) (void)hipFree(ctx->free_cnt);
     for (int l = 0; l < TL3D_ICP_LANES; ++l) {
@@ -1113,6 +1151,78 @@ int tl3d_grid_max_weight(tl3d_ctx *ctx, int64_t *out) {
     ctx->tsdf_w_upper = w;
     ctx->tsdf_w_unknown = false;
     *out = (int64_t)w;
+    return TL3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------- RCCL merge (no torch)
+int tl3d_rccl_unique_id(uint8_t id_out[TL3D_RCCL_ID_BYTES]) {
+    REQUIRE(id_out != nullptr, TL3D_E_INVALID, "null out pointer");
+    int rc = rccl_load();
+    if (rc) return rc;
+    RcclId id;
+    memset(&id, 0, sizeof(id));
+    const int nrc = g_rccl.GetUniqueId(&id);
+    REQUIRE(nrc == 0, TL3D_E_HIP, "ncclGetUniqueId failed: %s", rccl_msg(nrc));
+    memcpy(id_out, id.bytes, TL3D_RCCL_ID_BYTES);
+    return TL3D_OK;
+}
+
+int tl3d_rccl_init(tl3d_ctx *ctx, int world, int rank, const uint8_t id_in[TL3D_RCCL_ID_BYTES]) {
+    REQUIRE(ctx && id_in, TL3D_E_INVALID, "null argument");
+    REQUIRE(world >= 1 && rank >= 0 && rank < world, TL3D_E_INVALID, "bad rank %d of %d", rank, world);
+    REQUIRE(ctx->rccl_comm == nullptr, TL3D_E_STATE, "context already joined a communicator");
+    int rc = rccl_load();
+    if (rc) return rc;
+    TL3D_HIP(hipSetDevice(ctx->device));
+    RcclId id;
+    memcpy(id.bytes, id_in, TL3D_RCCL_ID_BYTES);
+    // ncclResult_t ncclCommInitRank(ncclComm_t*, int nranks, ncclUniqueId commId /* 128-byte struct BY VALUE */, int rank)
+    typedef int (*init_fn)(void **, int, RcclId, int);
+    void *comm = nullptr;
+    const int nrc = ((init_fn)(void *)g_rccl.CommInitRank)(&comm, world, id, rank);
+    REQUIRE(nrc == 0 && comm, TL3D_E_HIP, "ncclCommInitRank failed: %s", rccl_msg(nrc));
+    ctx->rccl_comm = comm;
+    ctx->rccl_world = world;
+    return TL3D_OK;
+}
+
+int tl3d_allreduce_grid(tl3d_ctx *ctx, uint32_t channels) {
+    REQUIRE(ctx != nullptr, TL3D_E_INVALID, "null ctx");
+    REQUIRE(ctx->rccl_comm != nullptr, TL3D_E_STATE, "call tl3d_rccl_init first");
+    if (channels == 0) channels = (ctx->tsdf ? TL3D_CH_TSDF : 0u) | (ctx->centroid ? TL3D_CH_CENTROID : 0u);
+    REQUIRE((channels & ~(TL3D_CH_TSDF | TL3D_CH_CENTROID)) == 0, TL3D_E_INVALID, "bad channel mask 0x%x", channels);
+    if (channels & TL3D_CH_TSDF) REQUIRE(ctx->tsdf != nullptr, TL3D_E_STATE, "TSDF channel not enabled");
+    if (channels & TL3D_CH_CENTROID) REQUIRE(ctx->centroid != nullptr, TL3D_E_STATE, "centroid channel not enabled");
+    FLUSH_AND_FOLD(ctx);
+    TL3D_HIP(hipSetDevice(ctx->device));
+    ctx->grid_epoch++;
+    if (channels & TL3D_CH_TSDF) {
+        // int32 headroom over all ranks: the sum of the ranks' largest voxel weights bounds the merged grid's
+        long long w = 0;
+        int rc = measure_max_weight(ctx, ctx->tsdf, &w);
+        if (rc) return rc;
+        long long *d_w = nullptr;
+        TL3D_HIP(hipMalloc(&d_w, sizeof(long long)));
+        hipError_t e = hipMemcpyAsync(d_w, &w, sizeof(w), hipMemcpyHostToDevice, ctx->stream);
+        int nrc = e == hipSuccess ? g_rccl.AllReduce(d_w, d_w, 1, 4 /* ncclInt64 */, 0 /* ncclSum */, ctx->rccl_comm, ctx->stream) : -1;
+        long long total = 0;
+        if (nrc == 0) e = hipMemcpyAsync(&total, d_w, sizeof(total), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(d_w);
+        REQUIRE(nrc == 0 && e == hipSuccess, TL3D_E_HIP, "weight all-reduce failed: %s", nrc ? rccl_msg(nrc) : hipGetErrorString(e));
+        REQUIRE(total <= TL3D_TSDF_MAX_WEIGHT, TL3D_E_STATE,
+                "the merged TSDF grid could hold %lld observations per voxel (limit %d): merge more often or extract between scans", total,
+                TL3D_TSDF_MAX_WEIGHT);
+        nrc = g_rccl.AllReduce(ctx->tsdf, ctx->tsdf, ctx->nvox * 2, 2 /* ncclInt32 */, 0, ctx->rccl_comm, ctx->stream);
+        REQUIRE(nrc == 0, TL3D_E_HIP, "ncclAllReduce (TSDF) failed: %s", rccl_msg(nrc));
+        ctx->tsdf_w_upper = total;
+        ctx->tsdf_w_unknown = false;
+    }
+    if (channels & TL3D_CH_CENTROID) {
+        const int nrc = g_rccl.AllReduce(ctx->centroid, ctx->centroid, ctx->nvox * 4, 5 /* ncclUint64 */, 0, ctx->rccl_comm, ctx->stream);
+        REQUIRE(nrc == 0, TL3D_E_HIP, "ncclAllReduce (centroid) failed: %s", rccl_msg(nrc));
+    }
+    TL3D_HIP(hipStreamSynchronize(ctx->stream));
     return TL3D_OK;
 }
 

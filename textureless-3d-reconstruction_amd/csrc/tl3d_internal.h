@@ -134,6 +134,8 @@ struct tl3d_ctx {
     // anything reads the TSDF channel.  TL3D_FREE_COUNTERS=0 keeps the round-1 behaviour (records streamed every frame).
     unsigned *free_cnt;
     bool free_dirty;
+    void *rccl_comm;             // ncclComm_t of tl3d_rccl_init (RCCL is dlopen'ed: tl3d_api.hip)
+    int rccl_world;
     long long tsdf_w_upper;
     bool tsdf_w_unknown;
     int *d_maxw;

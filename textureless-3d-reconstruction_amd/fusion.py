@@ -296,6 +296,21 @@ class FusionContext:
         abi.check(self._lib.tl3d_grid_max_weight(self._h, C.byref(w)))
         return int(w.value)
 
+    # ---- multi-GPU merge through the library's own RCCL binding (hosts without torch.distributed) -------------------
+    @staticmethod
+    def rccl_unique_id() -> bytes:
+        buf = (C.c_uint8 * 128)()
+        abi.check(abi.load().tl3d_rccl_unique_id(buf))
+        return bytes(buf)
+
+    def rccl_init(self, world: int, rank: int, unique_id: bytes):
+        assert len(unique_id) == 128
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        abi.check(self._lib.tl3d_rccl_init(self._h, int(world), int(rank), buf))
+
+    def allreduce_grid(self, channels: int = 0):
+        abi.check(self._lib.tl3d_allreduce_grid(self._h, int(channels)))
+
     def grid_tensor(self, channel: int):
         """Zero-copy torch view of a grid channel (for torch.distributed all_reduce over RCCL)."""
         import torch
