@@ -166,6 +166,13 @@ int tl3d_backproject_device(tl3d_ctx *ctx, int slot, const double R[9], const do
                             uint32_t flags, int subsample, double min_depth, double max_depth,
                             float *out_xyz_dev, uint8_t *out_rgb_dev, int64_t cap, int64_t *out_n_dev);
 
+/* Extent of the points tl3d_backproject would emit for this frame, without emitting them: out_min / out_max = component-wise
+ * min / max of the float32 points (+inf / -inf when no pixel survives).  What `p.min(0)`, `p.max(0)` give the reference when it
+ * bounds a cloud for Open3D's voxel origin (D2R:404-410). */
+int tl3d_frame_bounds(tl3d_ctx *ctx, int slot, const double R[9], const double t[3], double scale, uint32_t flags,
+                      int subsample, double min_depth, double max_depth, double out_min[3], double out_max[3],
+                      int64_t *out_reserved /* may be NULL */);
+
 /* a7 (fusion half): accumulate the same points straight into the centroid channel, no point list
  * (replaces np.vstack + Open3D voxel_down_sample's hash-map insert, D2R:401-410). */
 int tl3d_accumulate_centroid(tl3d_ctx *ctx, int slot, const double R[9], const double t[3], double scale,
@@ -203,6 +210,21 @@ int tl3d_icp_p2plane(tl3d_ctx *ctx, int slot_src, double scale_src, int slot_tgt
 int tl3d_icp_enqueue(tl3d_ctx *ctx, int lane, int slot_src, double scale_src, int slot_tgt, const double T_init[16],
                      const tl3d_icp_params *prm);
 int tl3d_icp_collect(tl3d_ctx *ctx, int lane, tl3d_icp_result *out);
+
+/* a10, batched: n_pairs independent registrations, each through ALL of `levels` (coarse to fine: a level starts from the
+ * pose the previous one ended with; a pair stops early when a level fails or ends with fewer than 8 correspondences, as
+ * the per-level calls above are used by a host) in ONE kernel launch: no host round trip and no launch per iteration.
+ * The result of a pair is that of its last level run; it does not depend on which batch the pair is in.  One batch may be
+ * in flight per context (own stream); uploads and normal maps issued before the enqueue precede it, slot rewrites issued
+ * after it wait for it.  What replaces the reference's per-pair detect_and_match + compute_pose calls (D2R:573-596). */
+#define TL3D_ICP_MAX_LEVELS 4
+typedef struct tl3d_icp_pair {
+    int32_t slot_src, slot_tgt;
+    double scale_src;           /* metric scale of the source depth                                */
+    double T_init[16];          /* initial src-camera -> tgt-camera pose, row-major 4x4            */
+} tl3d_icp_pair;
+int tl3d_icp_batch_enqueue(tl3d_ctx *ctx, const tl3d_icp_pair *pairs, int n_pairs, const tl3d_icp_params *levels, int n_levels);
+int tl3d_icp_batch_collect(tl3d_ctx *ctx, tl3d_icp_result *out /* [n_pairs] */, int n_pairs);
 
 /* grids */
 /* Give a context created with channels = 0 its grid later (geometry fields of cfg: channels, nx, ny, nz, origin,

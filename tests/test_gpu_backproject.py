@@ -196,3 +196,24 @@ def test_device_only_backprojection_offsets_alignment_and_capacity():
         ctx.backproject_device(1, bx[:63].view(21, 3), bc[:63].view(21, 3), nn, pose=pose)
         ctx.sync()
         assert int(nn.item()) == 0 and (bx == -7.0).all() and (bc == 201).all()
+
+
+def test_frame_bounds_equal_the_extent_of_the_point_list():
+    """tl3d_frame_bounds (the scene-bounding pass of the pipeline): min / max of the float32 points, without the points."""
+    rng = np.random.default_rng(5)
+    h, w = 97, 131
+    depth = (0.4 + 2.0 * rng.random((h, w))).astype(np.float32)
+    depth[rng.random((h, w)) < 0.3] = 0.0
+    q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+    q *= np.sign(np.linalg.det(q))
+    pose = (q, rng.normal(size=3))
+    with tl3d.FusionContext(w, h, 120.0, 118.0, 64.5, 47.0, n_slots=2) as ctx:
+        ctx.upload(0, depth, None)
+        ctx.upload(1, np.zeros((h, w), np.float32), None)
+        for sub in (1, 2, 3):
+            for p, sc in ((pose, 1.0), (None, 0.7)):
+                pts, _ = ctx.backproject(0, pose=p, scale=sc, subsample=sub)
+                lo, hi = ctx.frame_bounds(0, pose=p, scale=sc, subsample=sub)
+                assert np.array_equal(lo, pts.min(0).astype(np.float64)) and np.array_equal(hi, pts.max(0).astype(np.float64))
+        lo, hi = ctx.frame_bounds(1, pose=pose)
+        assert np.all(np.isinf(lo)) and np.all(lo > 0) and np.all(np.isinf(hi)) and np.all(hi < 0)

@@ -531,3 +531,42 @@ def test_c_abi_rccl_merge_single_rank():
         assert np.array_equal(ctx.download_grid(tl3d.CH_TSDF), orc.tsdf)
         with pytest.raises(tl3d.Tl3dError):
             ctx.rccl_init(1, 0, uid)
+
+
+def test_icp_batch_matches_oracle_and_the_per_level_calls():
+    """tl3d_icp_batch_*: every pair through all levels in one launch = the per-level blocking calls a host would chain
+    (same stop rule between levels) = the oracle; a pair's result does not depend on the batch it is in."""
+    poses, frames = small_scene_frames(n=6, deg=1.5)
+    ctx, orc = make_pair(channels=0, dims=(8, 8, 8), n_slots=7)
+    levels = [dict(iters=6, stride=4, max_dist=0.2, eps=1e-7), dict(iters=10, stride=2, max_dist=0.1, eps=1e-7)]
+    with ctx:
+        for i, f in enumerate(frames):
+            ctx.upload(i, *f)
+            ctx.build_normals(i)
+        ctx.upload(6, np.zeros_like(frames[0][0]), None)             # an empty frame: its pair must fail, not hang
+        pairs = [(i, i + 1) for i in range(5)] + [(6, 0)]
+        T0 = [None, np.eye(4), None, None, None, None]
+        chained = []
+        for k, (a, b) in enumerate(pairs):
+            T, res = np.eye(4), None
+            for lv in levels:
+                res = ctx.icp(a, b, T_init=T, **lv)
+                if res["status"] == 2 or res["n_corr"] < 8:
+                    break
+                T = res["T"]
+            chained.append(res)
+        got = ctx.icp_batch(pairs, levels, T_init=T0)
+        alone = ctx.icp_batch([pairs[2]], levels)[0]
+        with pytest.raises(tl3d.Tl3dError):
+            ctx.icp_batch_collect()                                  # nothing in flight
+        onm = orc.normals(frames[1][0])
+        T, ores = np.eye(4), None
+        for lv in levels:
+            ores = orc.icp(frames[0][0], onm, T_init=T, iters=lv["iters"], stride=lv["stride"], max_dist=lv["max_dist"], eps=lv["eps"])
+            T = ores["T"]
+    for a, b in zip(chained[:5], got[:5]):
+        assert np.linalg.norm(a["T"] - b["T"]) <= 1e-9 and abs(a["n_corr"] - b["n_corr"]) <= 2 and a["n_src"] == b["n_src"]
+        assert a["iters_run"] == b["iters_run"] and a["status"] == b["status"] and abs(a["rmse"] - b["rmse"]) < 1e-9
+    assert got[5]["status"] == 2 and got[5]["n_corr"] == 0 and chained[5]["status"] == 2
+    assert np.array_equal(alone["T"], got[2]["T"]) and alone["n_corr"] == got[2]["n_corr"]
+    assert np.linalg.norm(got[0]["T"] - ores["T"]) <= 1e-9 and got[0]["iters_run"] == ores["iters_run"] and got[0]["n_src"] == ores["n_src"]

@@ -23,9 +23,9 @@ TSDF_MAX_WEIGHT = 65536
 SYMBOLS = [
     "tl3d_last_error", "tl3d_version", "tl3d_device_count", "tl3d_runtime_info", "tl3d_probe_hw_queues", "tl3d_grid_max_weight", "tl3d_create", "tl3d_destroy", "tl3d_sync",
     "tl3d_upload_frame", "tl3d_download_depth", "tl3d_pinned_alloc", "tl3d_pinned_free", "tl3d_upload_frame_async",
-    "tl3d_slot_wait", "tl3d_attach_grid", "tl3d_backproject", "tl3d_backproject_device", "tl3d_accumulate_centroid",
+    "tl3d_slot_wait", "tl3d_attach_grid", "tl3d_backproject", "tl3d_backproject_device", "tl3d_frame_bounds", "tl3d_accumulate_centroid",
     "tl3d_accumulate_points", "tl3d_points_bounds", "tl3d_integrate", "tl3d_build_normals",
-    "tl3d_download_normals", "tl3d_icp_p2plane", "tl3d_icp_enqueue", "tl3d_icp_collect", "tl3d_grid_reset", "tl3d_grid_device_ptr",
+    "tl3d_download_normals", "tl3d_icp_p2plane", "tl3d_icp_enqueue", "tl3d_icp_collect", "tl3d_icp_batch_enqueue", "tl3d_icp_batch_collect", "tl3d_grid_reset", "tl3d_grid_device_ptr",
     "tl3d_grid_download", "tl3d_grid_upload", "tl3d_grid_add", "tl3d_rccl_unique_id", "tl3d_rccl_init", "tl3d_allreduce_grid", "tl3d_extract", "tl3d_statistical_outlier",
     "tl3d_set_profile", "tl3d_get_stats", "tl3d_reset_stats", "tl3d_event_record", "tl3d_event_elapsed_ms",
 ]
@@ -55,6 +55,13 @@ class IcpResult(C.Structure):
 class IcpParams(C.Structure):
     _fields_ = [("iters", C.c_int32), ("stride", C.c_int32),
                 ("max_dist", C.c_double), ("damping", C.c_double), ("eps", C.c_double), ("eig_rel", C.c_double)]
+
+
+class IcpPair(C.Structure):
+    _fields_ = [("slot_src", C.c_int32), ("slot_tgt", C.c_int32), ("scale_src", C.c_double), ("T_init", C.c_double * 16)]
+
+
+ICP_MAX_LEVELS = 4
 
 
 class Stats(C.Structure):
@@ -157,6 +164,7 @@ def load():
         "tl3d_attach_grid": [vp, C.POINTER(Config)],
         "tl3d_backproject": [vp, i32, vp, vp, dbl, u32, i32, dbl, dbl, vp, vp, i64, C.POINTER(i64)],
         "tl3d_backproject_device": [vp, i32, vp, vp, dbl, u32, i32, dbl, dbl, vp, vp, i64, vp],
+        "tl3d_frame_bounds": [vp, i32, vp, vp, dbl, u32, i32, dbl, dbl, vp, vp, vp],
         "tl3d_accumulate_centroid": [vp, i32, vp, vp, dbl, u32, i32, dbl, dbl],
         "tl3d_accumulate_points": [vp, vp, vp, i64],
         "tl3d_points_bounds": [vp, vp, i64, vp, vp],
@@ -166,6 +174,8 @@ def load():
         "tl3d_icp_p2plane": [vp, i32, dbl, i32, vp, C.POINTER(IcpParams), C.POINTER(IcpResult)],
         "tl3d_icp_enqueue": [vp, i32, i32, dbl, i32, vp, C.POINTER(IcpParams)],
         "tl3d_icp_collect": [vp, i32, C.POINTER(IcpResult)],
+        "tl3d_icp_batch_enqueue": [vp, C.POINTER(IcpPair), i32, C.POINTER(IcpParams), i32],
+        "tl3d_icp_batch_collect": [vp, C.POINTER(IcpResult), i32],
         "tl3d_grid_reset": [vp],
         "tl3d_grid_device_ptr": [vp, u32, C.POINTER(vp), C.POINTER(C.c_size_t)],
         "tl3d_grid_download": [vp, u32, vp, C.c_size_t],

@@ -298,6 +298,47 @@ __global__ __launch_bounds__(256) void bp_fused_kernel(Cam cam, BpArgs a, PoseD 
     }
 }
 
+// min / max of a frame's back-projected points without materialising them (the scene-bounding pass of the pipeline used
+// to read every frame's point list back to the host just to take its extent): per-workgroup partials, reduced by the host.
+__global__ __launch_bounds__(256) void bp_bounds_kernel(Cam cam, BpArgs a, PoseD p, const float *__restrict__ depth,
+                                                        const double *__restrict__ xf, const double *__restrict__ yf,
+                                                        float *__restrict__ slab) {
+    __shared__ float sm[4][6];
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    const long long ns = (long long)a.Ws * a.Hs;
+    for (long long s = (long long)blockIdx.x * 256 + threadIdx.x; s < ns; s += (long long)gridDim.x * 256) {
+        const int vs = (int)(s / a.Ws), us = (int)(s - (long long)vs * a.Ws);
+        const int u = us * a.sub, v = vs * a.sub;
+        float pt[3];
+        if (bp_point_f(a, p, depth[(size_t)v * cam.W + u], xf[u], yf[v], pt)) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { mn[k] = fminf(mn[k], pt[k]); mx[k] = fmaxf(mx[k], pt[k]); }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        for (int d = 32; d > 0; d >>= 1) {
+            mn[k] = fminf(mn[k], __shfl_down(mn[k], d));
+            mx[k] = fmaxf(mx[k], __shfl_down(mx[k], d));
+        }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0)
+        for (int k = 0; k < 3; ++k) { sm[wid][k] = mn[k]; sm[wid][3 + k] = mx[k]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = sm[0][threadIdx.x];
+        for (int w = 1; w < 4; ++w) v = threadIdx.x < 3 ? fminf(v, sm[w][threadIdx.x]) : fmaxf(v, sm[w][threadIdx.x]);
+        slab[blockIdx.x * 6 + threadIdx.x] = v;
+    }
+}
+
+int launch_bp_bounds(hipStream_t s, const Cam &cam, const BpArgs &a, const PoseD &p, const float *depth, const double *xf, const double *yf,
+                     float *slab, int nblocks) {
+    hipLaunchKernelGGL(bp_bounds_kernel, dim3(nblocks), dim3(256), 0, s, cam, a, p, depth, xf, yf, slab);
+    TL3D_HIP(hipGetLastError());
+    return TL3D_OK;
+}
+
 int bp_fused_tiles(const BpArgs &a) {
     const long long ns = (long long)a.Ws * a.Hs;
     const long long nt = (ns + BP_TILE - 1) / BP_TILE;

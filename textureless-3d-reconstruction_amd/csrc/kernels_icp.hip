@@ -63,16 +63,11 @@ __global__ __launch_bounds__(256) void normals_kernel(Cam cam, const float *__re
 
 // accumulate this workgroup's share of the sums and leave the workgroup total in sm_out[0..31] (valid for threads < 32
 // after the function's last barrier)
-__device__ __forceinline__ void icp_accumulate(const Cam &cam, const IcpRun *__restrict__ run, const IcpState *state,
-                                               double (*sm)[ICP_SLAB], double *__restrict__ sm_out) {
-    const float *__restrict__ depth_s = run->depth_src;
-    const float4 *__restrict__ nmap_t = run->nmap_tgt;
-    const float sc = run->scale, mind = run->mind, maxd = run->maxd, md2 = run->md2;
-    const int stride = run->stride, Ws = run->Ws, Hs = run->Hs;
-    float r[9], t[3];
-    r[0] = (float)state->T[0]; r[1] = (float)state->T[1]; r[2] = (float)state->T[2];  t[0] = (float)state->T[3];
-    r[3] = (float)state->T[4]; r[4] = (float)state->T[5]; r[5] = (float)state->T[6];  t[1] = (float)state->T[7];
-    r[6] = (float)state->T[8]; r[7] = (float)state->T[9]; r[8] = (float)state->T[10]; t[2] = (float)state->T[11];
+// `member` of `members` workgroups share one registration: member m takes samples m*256 + tid, + members*256, ...
+__device__ __forceinline__ void icp_accumulate_core(const Cam &cam, const float *__restrict__ depth_s, const float4 *__restrict__ nmap_t,
+                                                    float sc, float mind, float maxd, float md2, int stride, int Ws, int Hs,
+                                                    const float r[9], const float t[3], int member, int members,
+                                                    double (*sm)[ICP_SLAB], double *__restrict__ sm_out, unsigned long long *stamp = nullptr) {
     const float wlim = (float)cam.W - 0.5f, hlim = (float)cam.H - 0.5f;
     double acc[30];
 #pragma unroll
@@ -82,7 +77,7 @@ __device__ __forceinline__ void icp_accumulate(const Cam &cam, const IcpRun *__r
     // gathers): a thread's trip costs one depth latency + one gather latency instead of two of each.  Addresses of
     // rejected samples are clamped to element 0 so that the loads need no branch; the per-thread order of the sums is the
     // sample order, as before.
-    const long long step = (long long)gridDim.x * 256;
+    const long long step = (long long)members * 256;
     struct Samp { float px, py, pz; int ut, vt; bool src_ok, ok; };
     auto prep = [&](float draw, int u, int v, bool in_range) {
         Samp q;
@@ -130,7 +125,7 @@ __device__ __forceinline__ void icp_accumulate(const Cam &cam, const IcpRun *__r
         acc[27] += rr * rr;
         acc[28] += 1.0;
     };
-    for (long long s0 = (long long)blockIdx.x * 256 + threadIdx.x; s0 < ns; s0 += 2 * step) {
+    for (long long s0 = (long long)member * 256 + threadIdx.x; s0 < ns; s0 += 2 * step) {
         const long long s1 = s0 + step;
         const bool in1 = s1 < ns;
         const long long s1c = in1 ? s1 : s0;
@@ -145,19 +140,46 @@ __device__ __forceinline__ void icp_accumulate(const Cam &cam, const IcpRun *__r
         accum(q0, n0);
         accum(q1, n1);
     }
+    if (stamp) stamp[0] = wall_clock64();
+    // Wave reduction of the 30 sums.  A shuffle tree per sum is 30 x 6 dependent 64-bit shuffles (6.6 us measured, a third of
+    // an iteration); instead the lanes split the sums between them while they add: at distance 32 the lower half of the wave
+    // keeps sums 0..15 and the upper half 16..31, at distance 16 each quarter keeps 8 of those, ... -- 16 + 8 + 4 + 2 + 1 + 1
+    // shuffles.  Every sum is still added over the same tree (lane l with l + 32, then with l + 16, ...; IEEE addition commutes),
+    // so the totals are bit for bit those of the shuffle tree; the total of sum c ends in lanes 2c and 2c + 1.
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    double v[32];
 #pragma unroll
-    for (int i = 0; i < 30; ++i) {
-        double v = acc[i];
+    for (int i = 0; i < 30; ++i) v[i] = acc[i];
+    v[30] = 0.0;
+    v[31] = 0.0;
 #pragma unroll
-        for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d);
-        if (lane == 0) sm[wid][i] = v;
+    for (int half = 16, dist = 32; half >= 1; half >>= 1, dist >>= 1) {
+        const bool up = (lane & dist) != 0;
+#pragma unroll
+        for (int k = 0; k < half; ++k) {
+            const double send = up ? v[k] : v[k + half];
+            const double keep = up ? v[k + half] : v[k];
+            v[k] = keep + __shfl_xor(send, dist);
+        }
     }
+    v[0] += __shfl_xor(v[0], 1);
+    if (!(lane & 1)) sm[wid][lane >> 1] = v[0];
+    if (stamp) stamp[1] = wall_clock64();
     __syncthreads();
     if (threadIdx.x < ICP_SLAB) {
         const int i = threadIdx.x;
-        sm_out[i] = (i < 30) ? ((sm[0][i] + sm[1][i]) + sm[2][i]) + sm[3][i] : 0.0;
+        sm_out[i] = ((sm[0][i] + sm[1][i]) + sm[2][i]) + sm[3][i];            // (sums 30 and 31 are zero)
     }
+}
+
+__device__ __forceinline__ void icp_accumulate(const Cam &cam, const IcpRun *__restrict__ run, const IcpState *state,
+                                               double (*sm)[ICP_SLAB], double *__restrict__ sm_out) {
+    float r[9], t[3];
+    r[0] = (float)state->T[0]; r[1] = (float)state->T[1]; r[2] = (float)state->T[2];  t[0] = (float)state->T[3];
+    r[3] = (float)state->T[4]; r[4] = (float)state->T[5]; r[5] = (float)state->T[6];  t[1] = (float)state->T[7];
+    r[6] = (float)state->T[8]; r[7] = (float)state->T[9]; r[8] = (float)state->T[10]; t[2] = (float)state->T[11];
+    icp_accumulate_core(cam, run->depth_src, run->nmap_tgt, run->scale, run->mind, run->maxd, run->md2, run->stride, run->Ws, run->Hs,
+                        r, t, (int)blockIdx.x, (int)gridDim.x, sm, sm_out);
 }
 
 // 1/x and 1/sqrt(x) to ~1e-16 relative: hardware seed + two Newton steps (no IEEE division / square-root sequence)
@@ -399,9 +421,8 @@ __device__ void se3_apply(const double x[6], double *T) {
 }
 
 // The last workgroup's part: fixed-order sum of the published partials, solve, pose update.
-__device__ __forceinline__ void icp_finish(const double *slab, int nblocks, IcpState *state, const IcpRun *__restrict__ run,
+__device__ __forceinline__ void icp_finish(const double *slab, int nblocks, IcpState *state, double damping, double eps, double eig_rel,
                                            int final_pass, double (*part)[ICP_SLAB], double *sums) {
-    const double damping = run->damping, eps = run->eps, eig_rel = run->eig_rel;
     const int t = threadIdx.x;
     {   // slab reduction: 8 groups x 32 components, loads batched 8 deep, combined in a fixed order (deterministic).
         // The partials were written by other CUs in THIS launch: agent-scope (sc1) loads, never served from this CU's L1
@@ -474,8 +495,149 @@ __global__ __launch_bounds__(256) void icp_iter_kernel(Cam cam, const IcpRun *__
     }
     __syncthreads();
     if (!s_last) return;
-    icp_finish(slab, (int)gridDim.x, state, run, final_pass, sm, tot);
+    icp_finish(slab, (int)gridDim.x, state, run->damping, run->eps, run->eig_rel, final_pass, sm, tot);
     if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // re-arm for the next launch
+}
+
+// A batch of registrations, each through all its levels and iterations, in ONE launch.  `members` workgroups share a
+// pair; after every pass they meet at the pair's barrier in device memory: partial sums as agent-scope stores (drained),
+// one arrival ticket per workgroup, the last arriver sums the partials in member order, solves, updates the pose and
+// publishes the next generation word (pass count + the done / over flags) with a release store; the others poll that
+// word (one lane per workgroup; a long first sleep, then short ones: polls of one word from a hundred CUs at full rate
+// saturate its memory channel and starve the arrivals).  Arrival counter and generation word of a pair sit in different
+// cache lines, and consecutive pairs' lines are > 4 KB apart (different channels).
+// Waiting needs the pair's other workgroups to be running: workgroups therefore take their (pair, member) from a ticket
+// counter as they START, so the members of every pair but the newest are all resident (or done) whatever the dispatch
+// order, and the newest pair gets the slots the older ones free -- the grid always drains (members <= 128 workgroups
+// against >= 256 resident ones).  Every wait is bounded in time; a time-out raises the error word and ends the launch.
+constexpr unsigned long long ICP_WAIT_LIMIT_TICKS = 200000000ull;          // 2 s of the 100 MHz wall clock
+__device__ __forceinline__ size_t icp_sync_line(int pair, int rows) {        // 16-word line of `pair`: neighbours are rows*64 B (> 4 KB) apart
+    return ((size_t)(pair & 63) * (size_t)rows + (size_t)(pair >> 6)) * 16;
+}
+__global__ __launch_bounds__(256) void icp_batch_kernel(Cam cam, IcpBatchArgs a) {
+    __shared__ double sm[8][ICP_SLAB];
+    __shared__ double tot[ICP_SLAB];
+    __shared__ double sT[12];
+    __shared__ int s_flag[4];                              // [0] ticket, [1] last arriver, [2] generation word seen, [3] wait failed
+    const int tid = threadIdx.x;
+    if (tid == 0) s_flag[0] = (int)__hip_atomic_fetch_add(a.ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int ticket = s_flag[0];
+    const int pair = ticket / a.members, member = ticket - pair * a.members;
+    if (pair >= a.n_pairs) return;                         // (grid = n_pairs * members: never)
+    const IcpBatchPair pr = a.pairs[pair];
+    IcpState *st = a.states + pair;
+    unsigned *stage = a.stage ? a.stage + (size_t)ticket * 4 : nullptr;      // experiments: how far this workgroup got
+    if (stage && tid == 0) { stage[0] = 1u; stage[1] = (unsigned)blockIdx.x; stage[3] = __builtin_amdgcn_s_getreg((4 << 11) | (0 << 6) | 20); }
+    unsigned *arrive = a.sync + icp_sync_line(pair, a.sync_rows);
+    unsigned *genw = a.sync + (size_t)64 * a.sync_rows * 16 + icp_sync_line(pair, a.sync_rows);
+    double *slab = a.slab + (size_t)pair * a.members * ICP_SLAB;
+    unsigned gen = 0;
+    unsigned long long *dbg = (a.dbg && pair == 0 && tid == 0) ? a.dbg + (size_t)member * 16 * 8 : nullptr;
+#define ICP_STAMP(k_) do { if (dbg && gen < 16u) dbg[gen * 8 + (k_)] = wall_clock64(); } while (0)
+    for (int lv = 0; lv < a.n_levels; ++lv) {
+        const IcpLevel L = a.lv[lv];
+        int done = 0, over = 0;
+        for (int it = 0;; ++it) {
+            const int final_pass = (done || it >= L.iters);
+            ICP_STAMP(0);
+            // the pose of this pass: after the first pass it was written by another CU inside this launch
+            if (tid < 12) sT[tid] = __hip_atomic_load(st->T + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            float r[9], t[3];
+            r[0] = (float)sT[0]; r[1] = (float)sT[1]; r[2] = (float)sT[2];  t[0] = (float)sT[3];
+            r[3] = (float)sT[4]; r[4] = (float)sT[5]; r[5] = (float)sT[6];  t[1] = (float)sT[7];
+            r[6] = (float)sT[8]; r[7] = (float)sT[9]; r[8] = (float)sT[10]; t[2] = (float)sT[11];
+            ICP_STAMP(1);
+            icp_accumulate_core(cam, pr.depth_src, pr.nmap_tgt, pr.scale, a.mind, a.maxd, L.md2, L.stride, L.Ws, L.Hs, r, t, member, a.members, sm, tot,
+                                (dbg && gen < 16u) ? dbg + gen * 8 + 3 : nullptr);
+            ICP_STAMP(2);
+            if (stage && tid == 0) stage[0] = 2u + 16u * gen;
+            if (tid < ICP_SLAB) {
+                __hip_atomic_store(slab + (size_t)member * ICP_SLAB + tid, tot[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+            if (tid == 0) {
+                const unsigned arrived = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int last = (arrived == (unsigned)a.members - 1u);
+                if (stage) { stage[0] = 3u + 16u * gen; stage[2] = arrived; }
+                if (last) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                s_flag[1] = last;
+                if (dbg && gen < 16u) dbg[gen * 8 + 7] = (unsigned long long)last;
+            }
+            ICP_STAMP(5);
+            __syncthreads();
+            if (s_flag[1]) {
+                icp_finish(slab, a.members, st, L.damping, L.eps, L.eig_rel, final_pass, sm, tot);
+                if (tid == 0) {
+                    int over_ = 0;
+                    if (final_pass) {                      // what the host did between levels: stop on failure or < 8 correspondences
+                        if (lv == a.n_levels - 1 || __hip_atomic_load(&st->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2 || tot[28] < 8.0) {
+                            st->over = 1;
+                            over_ = 1;
+                        } else {
+                            st->done = 0;
+                            st->status = 0;
+                            st->iters_run = 0;
+                        }
+                    }
+                    const unsigned word = ((gen + 1u) << 2) | (over_ ? 2u : 0u) | (__hip_atomic_load(&st->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1u : 0u);
+                    if (a.poll_rmw) {
+                        (void)__hip_atomic_exchange(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);             // arrivals of the next pass
+                        (void)__hip_atomic_exchange(genw, word, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);            // state above is visible first
+                    } else {
+                        __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(genw, word, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    s_flag[2] = (int)word;
+                    s_flag[3] = 0;
+                }
+            } else if (tid == 0) {
+                const unsigned long long t0 = wall_clock64();
+                unsigned word, polls = 0;
+                bool failed = false;
+                __builtin_amdgcn_s_sleep(100);             // the last arriver needs >= 3 us (sum, solve, update)
+                while (((word = a.poll_rmw ? __hip_atomic_fetch_add(genw, (unsigned)a.zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                           : __hip_atomic_load(genw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 2) == gen) {
+                    if ((++polls & 63u) == 0u &&
+                        (wall_clock64() - t0 > ICP_WAIT_LIMIT_TICKS || __hip_atomic_load(a.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                        failed = true;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(16);
+                }
+                if (failed && __hip_atomic_exchange(a.ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                    a.ctl[4] = (unsigned)pair; a.ctl[5] = (unsigned)member; a.ctl[6] = gen; a.ctl[7] = polls;      // the first time-out, for the host's message
+                    a.ctl[8] = __hip_atomic_fetch_add(arrive, (unsigned)a.zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    a.ctl[9] = __hip_atomic_fetch_add(genw, (unsigned)a.zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    a.ctl[10] = (unsigned)lv; a.ctl[11] = (unsigned)it;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                s_flag[2] = (int)word;
+                s_flag[3] = failed;
+            }
+            ICP_STAMP(6);
+            __syncthreads();
+            ++gen;
+            const int word = s_flag[2], failed = s_flag[3];
+            done = word & 1;
+            over = (word >> 1) & 1;
+            __syncthreads();                               // s_flag is rewritten by the next pass
+            if (failed) return;                            // a wait timed out: the error word is set, the host reports it
+            if (final_pass) break;
+        }
+        if (over) return;
+    }
+}
+
+int launch_icp_batch(hipStream_t s, const Cam &cam, const IcpBatchArgs &a) {
+    hipLaunchKernelGGL(icp_batch_kernel, dim3((unsigned)a.n_pairs * (unsigned)a.members), dim3(256), 0, s, cam, a);
+    TL3D_HIP(hipGetLastError());
+    return TL3D_OK;
 }
 
 int launch_normals(hipStream_t s, const Cam &cam, const float *depth, float scale, float mind, float maxd, float jump,

@@ -130,6 +130,7 @@ static int check_slot(tl3d_ctx *ctx, int slot, bool need_loaded) {
 
 static int upload_impl(tl3d_ctx *ctx, int slot, const void *depth_hd, int depth_kind, const uint8_t *bgr_hd, bool wait);
 static void icp_lane_free(tl3d_ctx::IcpLane &ln);
+static void icp_batch_free(tl3d_ctx::IcpBatch &b);
 static int bp_check_error(tl3d_ctx *ctx, unsigned long long err);
 static int flush_updates(tl3d_ctx *ctx);
 // every call that reads or writes the TSDF grid, re-uses a frame slot, synchronises or time-stamps first issues the deferred updates
@@ -148,6 +149,8 @@ static int order_after_lanes(tl3d_ctx *ctx, int slot, bool rewrites_depth, bool 
         if ((rewrites_depth && ln.src_slot == slot) || (rewrites_nmap && ln.tgt_slot == slot))
             TL3D_HIP(hipStreamWaitEvent(ctx->stream, ln.ev_done, 0));
     }
+    if (ctx->icp_batch.busy && ctx->icp_batch.ev_done)      // (coarse: a batch may read any slot)
+        TL3D_HIP(hipStreamWaitEvent(ctx->stream, ctx->icp_batch.ev_done, 0));
     return TL3D_OK;
 }
 
@@ -321,6 +324,19 @@ int tl3d_create(const tl3d_config *cfg, int device, tl3d_ctx **out) {
     ctx->device = device;
     ctx->slots = new (std::nothrow) Slot[cfg->n_slots];
     if (!ctx->slots) { delete ctx; return set_err(TL3D_E_NOMEM, "host allocation failed"); }
+    {
+        const size_t npx = (size_t)cfg->width * cfg->height;
+        const size_t bytes[4] = {npx * sizeof(float), npx * sizeof(uint16_t), npx * 3, npx * sizeof(float4)};
+        FramePool *pools[4] = {&ctx->pool_depth, &ctx->pool_u16, &ctx->pool_bgr, &ctx->pool_nmap};
+        for (int k = 0; k < 4; ++k) {
+            FramePool &fp = *pools[k];
+            fp.block = (bytes[k] + 255) & ~(size_t)255;
+            fp.remaining = cfg->n_slots;
+            fp.max_slabs = (cfg->n_slots + FRAME_SLAB_BLOCKS - 1) / FRAME_SLAB_BLOCKS;
+            fp.slabs = (void **)calloc((size_t)fp.max_slabs, sizeof(void *));
+            if (!fp.slabs) { (void)tl3d_destroy(ctx); return set_err(TL3D_E_NOMEM, "host allocation failed"); }
+        }
+    }
 
     Cam &c = ctx->cam;
     c.W = cfg->width; c.H = cfg->height;
@@ -363,6 +379,32 @@ int tl3d_create(const tl3d_config *cfg, int device, tl3d_ctx **out) {
     return TL3D_OK;
 }
 
+// One block of a frame pool (nullptr when the device is out of memory).  A slab is sized for the slots still without a
+// buffer of this kind, at most FRAME_SLAB_BLOCKS of them, so a context never holds more than it was created for.
+static void *pool_take(FramePool &fp) {
+    if (fp.cur_left == 0) {
+        if (fp.remaining <= 0 || fp.n_slabs >= fp.max_slabs) return nullptr;
+        const int nb = fp.remaining < FRAME_SLAB_BLOCKS ? fp.remaining : FRAME_SLAB_BLOCKS;
+        void *p = nullptr;
+        if (hipMalloc(&p, fp.block * (size_t)nb) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        fp.slabs[fp.n_slabs++] = p;
+        fp.cur = (char *)p;
+        fp.cur_left = nb;
+    }
+    void *out = fp.cur;
+    fp.cur += fp.block;
+    --fp.cur_left;
+    --fp.remaining;
+    return out;
+}
+
+static void pool_release(FramePool &fp) {
+    for (int i = 0; i < fp.n_slabs; ++i) (void)hipFree(fp.slabs[i]);
+    free(fp.slabs);
+    fp.slabs = nullptr;
+    fp.n_slabs = fp.max_slabs = 0;
+}
+
 int tl3d_destroy(tl3d_ctx *ctx) {
     if (!ctx) return TL3D_OK;
     (void)hipSetDevice(ctx->device);
@@ -370,15 +412,15 @@ int tl3d_destroy(tl3d_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->slots) {
         for (int i = 0; i < ctx->cfg.n_slots; ++i) {
-            if (ctx->slots[i].depth) (void)hipFree(ctx->slots[i].depth);
-            if (ctx->slots[i].depth_u16) (void)hipFree(ctx->slots[i].depth_u16);
-            if (ctx->slots[i].bgr) (void)hipFree(ctx->slots[i].bgr);
-            if (ctx->slots[i].nmap) (void)hipFree(ctx->slots[i].nmap);
             if (ctx->slots[i].ev_upload) (void)hipEventDestroy(ctx->slots[i].ev_upload);
             if (ctx->slots[i].ev_normals) (void)hipEventDestroy(ctx->slots[i].ev_normals);
         }
         delete[] ctx->slots;
     }
+    pool_release(ctx->pool_depth);
+    pool_release(ctx->pool_u16);
+    pool_release(ctx->pool_bgr);
+    pool_release(ctx->pool_nmap);
     if (ctx->own_tsdf && ctx->tsdf) (void)hipFree(ctx->tsdf);
     if (ctx->own_centroid && ctx->centroid) (void)hipFree(ctx->centroid);
     for (int q = 0; q < 2; ++q)
@@ -405,6 +447,8 @@ int tl3d_destroy(tl3d_ctx *ctx) {
         if (ln.stream) (void)hipStreamSynchronize(ln.stream);
         icp_lane_free(ln);
     }
+    if (ctx->icp_batch.stream) (void)hipStreamSynchronize(ctx->icp_batch.stream);
+    icp_batch_free(ctx->icp_batch);
     if (ctx->bounds_slab) (void)hipFree(ctx->bounds_slab);
     for (int i = 0; i < 2; ++i)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
@@ -457,21 +501,21 @@ static int upload_impl(tl3d_ctx *ctx, int slot, const void *depth_hd, int depth_
     if (rc) return rc;
     Slot &s = ctx->slots[slot];
     const size_t npx = (size_t)ctx->cam.W * ctx->cam.H;
-    if (!s.depth && hipMalloc(&s.depth, npx * sizeof(float)) != hipSuccess) return set_err(TL3D_E_NOMEM, "frame alloc failed");
+    if (!s.depth && !(s.depth = (float *)pool_take(ctx->pool_depth))) return set_err(TL3D_E_NOMEM, "frame alloc failed");
     if (depth_kind == TL3D_DEPTH_F32_M) {
         TL3D_HIP(hipMemcpyAsync(s.depth, depth_hd, npx * sizeof(float), hipMemcpyDefault, ctx->stream));
         s.has_u16 = false;
     } else {
         // the millimetre image stays beside its f32 conversion: the TSDF kernels gather from it (half the cache lines
         // under a brick's footprint) and convert with the same IEEE division, every other kernel reads the f32 copy
-        if (!s.depth_u16 && hipMalloc(&s.depth_u16, npx * sizeof(uint16_t)) != hipSuccess) return set_err(TL3D_E_NOMEM, "frame alloc failed");
+        if (!s.depth_u16 && !(s.depth_u16 = (uint16_t *)pool_take(ctx->pool_u16))) return set_err(TL3D_E_NOMEM, "frame alloc failed");
         TL3D_HIP(hipMemcpyAsync(s.depth_u16, depth_hd, npx * sizeof(uint16_t), hipMemcpyDefault, ctx->stream));
         rc = launch_u16_to_f32(ctx->stream, s.depth_u16, s.depth, npx);
         if (rc) return rc;
         s.has_u16 = true;
     }
     if (bgr_hd) {
-        if (!s.bgr && hipMalloc(&s.bgr, npx * 3) != hipSuccess) return set_err(TL3D_E_NOMEM, "frame alloc failed");
+        if (!s.bgr && !(s.bgr = (uint8_t *)pool_take(ctx->pool_bgr))) return set_err(TL3D_E_NOMEM, "frame alloc failed");
         TL3D_HIP(hipMemcpyAsync(s.bgr, bgr_hd, npx * 3, hipMemcpyDefault, ctx->stream));
         s.has_color = true;
     } else {
@@ -653,6 +697,36 @@ int tl3d_backproject_device(tl3d_ctx *ctx, int slot, const double R[9], const do
     ctx->bp_async_pending = true;                       // tl3d_sync reports a look-back time-out of these launches
     return launch_bp_fused(ctx->stream, ctx->cam, a, p, s.depth, s.has_color ? s.bgr : nullptr, ctx->bp_factors, ctx->bp_factors + ctx->cam.W,
                            ctx->bp_state, out_xyz_dev, out_rgb_dev, (unsigned long long)cap, reinterpret_cast<unsigned long long *>(out_n_dev));
+}
+
+int tl3d_frame_bounds(tl3d_ctx *ctx, int slot, const double R[9], const double t[3], double scale, uint32_t flags, int subsample,
+                      double min_depth, double max_depth, double out_min[3], double out_max[3], int64_t *out_n_blocks_used) {
+    int rc = check_slot(ctx, slot, true);
+    if (rc) return rc;
+    REQUIRE(out_min && out_max, TL3D_E_INVALID, "null out pointer");
+    REQUIRE((flags & TL3D_F_NO_POSE) || (R && t), TL3D_E_INVALID, "pose required unless TL3D_F_NO_POSE");
+    BpArgs a;
+    rc = make_bp_args(ctx, scale, flags, subsample, min_depth, max_depth, &a);
+    if (rc) return rc;
+    TL3D_HIP(hipSetDevice(ctx->device));
+    const Slot &s = ctx->slots[slot];
+    const PoseD p = make_pose_d(R, t, (flags & TL3D_F_NO_POSE) != 0);
+    const long long ns = (long long)a.Ws * a.Hs;
+    int nb = (int)((ns + 255) / 256);
+    if (nb > 1024) nb = 1024;
+    rc = launch_bp_bounds(ctx->stream, ctx->cam, a, p, s.depth, ctx->bp_factors, ctx->bp_factors + ctx->cam.W, ctx->bounds_slab, nb);
+    if (rc) return rc;
+    std::vector<float> h((size_t)nb * 6);
+    TL3D_HIP(hipMemcpyAsync(h.data(), ctx->bounds_slab, h.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    TL3D_HIP(hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < 3; ++k) { out_min[k] = INFINITY; out_max[k] = -INFINITY; }
+    for (int b = 0; b < nb; ++b)
+        for (int k = 0; k < 3; ++k) {
+            out_min[k] = fmin(out_min[k], (double)h[(size_t)b * 6 + k]);
+            out_max[k] = fmax(out_max[k], (double)h[(size_t)b * 6 + 3 + k]);
+        }
+    if (out_n_blocks_used) *out_n_blocks_used = nb;
+    return TL3D_OK;
 }
 
 // ------------------------------------------------------------------------------------------- centroid accumulation
@@ -866,8 +940,7 @@ int tl3d_build_normals(tl3d_ctx *ctx, int slot, double scale, double depth_jump)
     if (rc) return rc;
     TL3D_HIP(hipSetDevice(ctx->device));
     Slot &s = ctx->slots[slot];
-    const size_t npx = (size_t)ctx->cam.W * ctx->cam.H;
-    if (!s.nmap && hipMalloc(&s.nmap, npx * sizeof(float4)) != hipSuccess) return set_err(TL3D_E_NOMEM, "normal map alloc failed");
+    if (!s.nmap && !(s.nmap = (float4 *)pool_take(ctx->pool_nmap))) return set_err(TL3D_E_NOMEM, "normal map alloc failed");
     rc = order_after_lanes(ctx, slot, false, true);     // an uncollected ICP run may still read this slot's normal map
     if (rc) return rc;
     rc = launch_normals(ctx->stream, ctx->cam, s.depth, (float)scale, (float)ctx->cfg.min_depth, (float)ctx->cfg.max_depth,
@@ -1026,6 +1099,222 @@ int tl3d_icp_p2plane(tl3d_ctx *ctx, int slot_src, double scale_src, int slot_tgt
     int rc = tl3d_icp_enqueue(ctx, 0, slot_src, scale_src, slot_tgt, T_init, prm);
     if (rc) return rc;
     return tl3d_icp_collect(ctx, 0, out);
+}
+
+// ---- batched registration: all pairs, all levels, all iterations in one launch (icp_batch_kernel) ----------------------
+static void icp_batch_free(tl3d_ctx::IcpBatch &b) {
+    if (b.pairs) (void)hipFree(b.pairs);
+    if (b.states) (void)hipFree(b.states);
+    if (b.sync) (void)hipFree(b.sync);
+    if (b.ctl) (void)hipFree(b.ctl);
+    if (b.slab) (void)hipFree(b.slab);
+    if (b.dbg) (void)hipFree(b.dbg);
+    if (b.stage) (void)hipFree(b.stage);
+    if (b.pairs_host) (void)hipHostFree(b.pairs_host);
+    if (b.states_host) (void)hipHostFree(b.states_host);
+    if (b.ctl_host) (void)hipHostFree(b.ctl_host);
+    if (b.ev_ready) (void)hipEventDestroy(b.ev_ready);
+    if (b.ev_done) (void)hipEventDestroy(b.ev_done);
+    if (b.stream) (void)hipStreamDestroy(b.stream);
+    memset(&b, 0, sizeof(b));
+}
+
+static int icp_batch_reserve(tl3d_ctx *ctx, int n_pairs, size_t slab_doubles) {
+    tl3d_ctx::IcpBatch &b = ctx->icp_batch;
+    bool ok = true;
+    if (!b.stream) {
+        ok = hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&b.ev_ready, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&b.ev_done, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipMalloc(&b.ctl, 64) == hipSuccess;
+        ok = ok && hipHostMalloc(&b.ctl_host, 64, hipHostMallocDefault) == hipSuccess;
+    }
+    if (ok && n_pairs > b.cap_pairs) {
+        const int cap = n_pairs < 64 ? 64 : n_pairs;
+        if (b.pairs) (void)hipFree(b.pairs);
+        if (b.states) (void)hipFree(b.states);
+        if (b.sync) (void)hipFree(b.sync);
+        if (b.pairs_host) (void)hipHostFree(b.pairs_host);
+        if (b.states_host) (void)hipHostFree(b.states_host);
+        b.pairs = nullptr; b.states = nullptr; b.sync = nullptr; b.pairs_host = nullptr; b.states_host = nullptr;
+        b.cap_pairs = 0;
+        ok = hipMalloc(&b.pairs, (size_t)cap * sizeof(IcpBatchPair)) == hipSuccess;
+        ok = ok && hipMalloc(&b.states, (size_t)cap * sizeof(IcpState)) == hipSuccess;
+        int rows = (cap + 63) / 64;
+        if (rows < 68) rows = 68;                            // neighbours' lines 4352 B apart at least
+        ok = ok && hipMalloc(&b.sync, (size_t)2 * 64 * rows * 64) == hipSuccess;
+        if (ok) b.sync_rows = rows;
+        ok = ok && hipHostMalloc(&b.pairs_host, (size_t)cap * sizeof(IcpBatchPair), hipHostMallocDefault) == hipSuccess;
+        ok = ok && hipHostMalloc(&b.states_host, (size_t)cap * sizeof(IcpState), hipHostMallocDefault) == hipSuccess;
+        if (ok) b.cap_pairs = cap;
+    }
+    if (ok && slab_doubles > b.cap_slab) {
+        if (b.slab) (void)hipFree(b.slab);
+        b.slab = nullptr;
+        b.cap_slab = 0;
+        ok = hipMalloc(&b.slab, slab_doubles * sizeof(double)) == hipSuccess;
+        if (ok) b.cap_slab = slab_doubles;
+    }
+    if (!ok) {
+        (void)hipGetLastError();
+        icp_batch_free(b);
+        return set_err(TL3D_E_NOMEM, "ICP batch: stream / buffer allocation failed");
+    }
+    return TL3D_OK;
+}
+
+int tl3d_icp_batch_enqueue(tl3d_ctx *ctx, const tl3d_icp_pair *pairs, int n_pairs, const tl3d_icp_params *levels, int n_levels) {
+    REQUIRE(ctx && pairs && levels, TL3D_E_INVALID, "null argument");
+    REQUIRE(n_pairs >= 1 && n_pairs <= (1 << 20), TL3D_E_INVALID, "n_pairs %d out of range", n_pairs);
+    REQUIRE(n_levels >= 1 && n_levels <= TL3D_ICP_MAX_LEVELS, TL3D_E_INVALID, "n_levels %d out of range [1,%d]", n_levels, TL3D_ICP_MAX_LEVELS);
+    REQUIRE(!ctx->icp_batch.busy, TL3D_E_STATE, "an ICP batch is still uncollected");
+    IcpBatchArgs a;
+    memset(&a, 0, sizeof(a));
+    long long ns_max = 1;
+    for (int l = 0; l < n_levels; ++l) {
+        const tl3d_icp_params &p = levels[l];
+        REQUIRE(p.iters >= 0 && p.iters <= 1000, TL3D_E_INVALID, "iters out of range");
+        REQUIRE(p.stride >= 1, TL3D_E_INVALID, "stride must be >= 1");
+        REQUIRE(p.max_dist > 0, TL3D_E_INVALID, "max_dist must be positive");
+        IcpLevel &L = a.lv[l];
+        L.md2 = (float)p.max_dist * (float)p.max_dist;
+        L.stride = p.stride;
+        L.Ws = (ctx->cam.W + p.stride - 1) / p.stride;
+        L.Hs = (ctx->cam.H + p.stride - 1) / p.stride;
+        L.iters = p.iters;
+        L.damping = p.damping;
+        L.eps = p.eps;
+        L.eig_rel = p.eig_rel;
+        const long long ns = (long long)L.Ws * L.Hs;
+        if (ns > ns_max) ns_max = ns;
+    }
+    for (int i = 0; i < n_pairs; ++i) {
+        int rc = check_slot(ctx, pairs[i].slot_src, true);
+        if (rc) return rc;
+        rc = check_slot(ctx, pairs[i].slot_tgt, true);
+        if (rc) return rc;
+        REQUIRE(ctx->slots[pairs[i].slot_tgt].has_normals, TL3D_E_STATE, "target slot %d has no normal map (call tl3d_build_normals)", pairs[i].slot_tgt);
+    }
+    // workgroups per pair: a function of the level geometry only, so a pair's sums (and pose) do not depend on the batch it is in
+    long long members = (ns_max + ICP_BATCH_SAMPLES_PER_MEMBER - 1) / ICP_BATCH_SAMPLES_PER_MEMBER;
+    if (members > ICP_BATCH_MAX_MEMBERS) members = ICP_BATCH_MAX_MEMBERS;
+    if (const char *e = getenv("TL3D_ICP_MEMBERS")) {       // experiments only
+        const long long m = atoll(e);
+        if (m >= 1 && m <= ICP_BATCH_MAX_MEMBERS) members = m;
+    }
+    TL3D_HIP(hipSetDevice(ctx->device));
+    int rc = icp_batch_reserve(ctx, n_pairs, (size_t)n_pairs * (size_t)members * ICP_SLAB);
+    if (rc) return rc;
+    tl3d_ctx::IcpBatch &b = ctx->icp_batch;
+    for (int i = 0; i < n_pairs; ++i) {
+        const Slot &ss = ctx->slots[pairs[i].slot_src], &st = ctx->slots[pairs[i].slot_tgt];
+        b.pairs_host[i].depth_src = ss.depth;
+        b.pairs_host[i].nmap_tgt = st.nmap;
+        b.pairs_host[i].scale = (float)pairs[i].scale_src;
+        b.pairs_host[i].pad = 0;
+        IcpState &h = b.states_host[i];
+        memset(&h, 0, sizeof(h));
+        memcpy(h.T, pairs[i].T_init, sizeof(h.T));
+    }
+    // uploads and normal maps are issued on the main stream: everything issued there so far precedes the batch
+    TL3D_HIP(hipEventRecord(b.ev_ready, ctx->stream));
+    TL3D_HIP(hipStreamWaitEvent(b.stream, b.ev_ready, 0));
+    TL3D_HIP(hipMemcpyAsync(b.pairs, b.pairs_host, (size_t)n_pairs * sizeof(IcpBatchPair), hipMemcpyHostToDevice, b.stream));
+    TL3D_HIP(hipMemcpyAsync(b.states, b.states_host, (size_t)n_pairs * sizeof(IcpState), hipMemcpyHostToDevice, b.stream));
+    TL3D_HIP(hipMemsetAsync(b.sync, 0, (size_t)2 * 64 * b.sync_rows * 64, b.stream));
+    TL3D_HIP(hipMemsetAsync(b.ctl, 0, 64, b.stream));
+    a.pairs = b.pairs;
+    a.states = b.states;
+    a.sync = b.sync;
+    a.slab = b.slab;
+    a.ctl = b.ctl;
+    a.n_pairs = n_pairs;
+    a.members = (int)members;
+    a.n_levels = n_levels;
+    a.sync_rows = b.sync_rows;
+    a.poll_rmw = 1;
+    a.mind = (float)ctx->cfg.min_depth;
+    a.maxd = (float)ctx->cfg.max_depth;
+    if (getenv("TL3D_ICP_TRACE")) {                        // experiments: per-pass timestamps of pair 0
+        if (b.dbg) (void)hipFree(b.dbg);
+        b.dbg = nullptr;
+        TL3D_HIP(hipMalloc(&b.dbg, (size_t)members * 16 * 8 * sizeof(unsigned long long)));
+        TL3D_HIP(hipMemsetAsync(b.dbg, 0, (size_t)members * 16 * 8 * sizeof(unsigned long long), b.stream));
+        b.dbg_members = (int)members;
+        a.dbg = b.dbg;
+    }
+    if (getenv("TL3D_ICP_STAGES")) {
+        if (b.stage) (void)hipFree(b.stage);
+        b.stage = nullptr;
+        b.stage_n = (size_t)n_pairs * members;
+        TL3D_HIP(hipMalloc(&b.stage, b.stage_n * 16));
+        TL3D_HIP(hipMemsetAsync(b.stage, 0, b.stage_n * 16, b.stream));
+        a.stage = b.stage;
+    }
+    rc = launch_icp_batch(b.stream, ctx->cam, a);
+    if (rc) return rc;
+    TL3D_HIP(hipMemcpyAsync(b.states_host, b.states, (size_t)n_pairs * sizeof(IcpState), hipMemcpyDeviceToHost, b.stream));
+    TL3D_HIP(hipMemcpyAsync(b.ctl_host, b.ctl, 64, hipMemcpyDeviceToHost, b.stream));
+    TL3D_HIP(hipEventRecord(b.ev_done, b.stream));
+    b.n_pairs = n_pairs;
+    b.busy = true;
+    return TL3D_OK;
+}
+
+int tl3d_icp_batch_collect(tl3d_ctx *ctx, tl3d_icp_result *out, int n_out) {
+    REQUIRE(ctx && out, TL3D_E_INVALID, "null argument");
+    tl3d_ctx::IcpBatch &b = ctx->icp_batch;
+    REQUIRE(b.stream && b.busy, TL3D_E_STATE, "no ICP batch in flight");
+    REQUIRE(n_out == b.n_pairs, TL3D_E_INVALID, "the batch in flight has %d pairs, not %d", b.n_pairs, n_out);
+    TL3D_HIP(hipSetDevice(ctx->device));
+    TL3D_HIP(hipStreamSynchronize(b.stream));
+    b.busy = false;
+    if (b.dbg && getenv("TL3D_ICP_TRACE")) {
+        std::vector<unsigned long long> h((size_t)b.dbg_members * 16 * 8);
+        TL3D_HIP(hipMemcpy(h.data(), b.dbg, h.size() * 8, hipMemcpyDeviceToHost));
+        FILE *f = fopen(getenv("TL3D_ICP_TRACE"), "w");
+        if (f) {
+            unsigned long long t0 = ~0ull;
+            for (size_t i = 0; i < h.size(); ++i)
+                if ((i & 7) < 7 && h[i] && h[i] < t0) t0 = h[i];
+            for (int m = 0; m < b.dbg_members; ++m)
+                for (int g = 0; g < 16; ++g) {
+                    const unsigned long long *r = &h[((size_t)m * 16 + g) * 8];
+                    if (!r[0]) continue;
+                    fprintf(f, "%d %d %llu", m, g, r[7]);
+                    for (int k = 0; k < 7; ++k) fprintf(f, " %lld", r[k] ? (long long)(r[k] - t0) : -1ll);
+                    fprintf(f, "\n");
+                }
+            fclose(f);
+        }
+    }
+    if (b.stage && b.ctl_host[1] != 0 && getenv("TL3D_ICP_STAGES")) {
+        std::vector<unsigned> h(b.stage_n * 4);
+        TL3D_HIP(hipMemcpy(h.data(), b.stage, h.size() * 4, hipMemcpyDeviceToHost));
+        const size_t mem = b.stage_n / (size_t)b.n_pairs;
+        size_t hist[4] = {0, 0, 0, 0};
+        for (size_t i = 0; i < b.stage_n; ++i) hist[h[i * 4] & 3u]++;
+        fprintf(stderr, "stages: never started %zu, started %zu, accumulated %zu, arrived %zu\n", hist[0], hist[1], hist[2], hist[3]);
+        const size_t p0 = b.ctl_host[4];
+        for (size_t m = 0; m < mem; ++m) {
+            const unsigned *r = &h[(p0 * mem + m) * 4];
+            fprintf(stderr, "  pair %zu ticket-member %zu: stage %u pass %u block %u arrived-as %u hwid %08x\n", p0, m, r[0] & 15u, r[0] >> 4, r[1], r[2], r[3]);
+        }
+    }
+    REQUIRE(b.ctl_host[1] == 0, TL3D_E_HIP, "ICP batch: a workgroup timed out waiting for its pair (pair %u member %u pass %u level %u iteration %u: "
+            "%u of its workgroups had arrived, generation word %u; %u workgroups started, %u polls)", b.ctl_host[4], b.ctl_host[5], b.ctl_host[6],
+            b.ctl_host[10], b.ctl_host[11], b.ctl_host[8], b.ctl_host[9], b.ctl_host[0], b.ctl_host[7]);
+    for (int i = 0; i < n_out; ++i) {
+        const IcpState &h = b.states_host[i];
+        memcpy(out[i].T, h.T, sizeof(out[i].T));
+        out[i].n_corr = (int64_t)h.sums[28];
+        out[i].n_src = (int64_t)h.sums[29];
+        out[i].fitness = h.sums[29] > 0 ? h.sums[28] / h.sums[29] : 0.0;
+        out[i].rmse = h.sums[28] > 0 ? sqrt(h.sums[27] / h.sums[28]) : 0.0;
+        out[i].iters_run = h.iters_run;
+        out[i].status = h.status;
+    }
+    return TL3D_OK;
 }
 
 // ------------------------------------------------------------------------------------------- grids

@@ -51,7 +51,7 @@ struct IcpState {                // lives in device memory for the whole ICP run
     int done;                    // set on convergence or failure: remaining iteration kernels exit at once
     int status;
     int iters_run;
-    int pad;
+    int over;                    // batched runs: no further level follows (last level done, failed, or < 8 correspondences)
 };
 
 struct IcpRun {                  // per-run arguments of the ICP kernels, read from device memory so that a lane's
@@ -60,6 +60,38 @@ struct IcpRun {                  // per-run arguments of the ICP kernels, read f
     float scale, md2, mind, maxd;
     int stride, Ws, Hs, pad;
     double damping, eps, eig_rel;
+};
+
+// Batched registration (icp_batch_kernel): every pair of a batch runs ALL its levels and iterations inside one launch.
+constexpr int ICP_MAX_LEVELS = 4;
+constexpr int ICP_BATCH_MAX_MEMBERS = 64;    // workgroups that share one pair
+constexpr int ICP_BATCH_SAMPLES_PER_MEMBER = 4096;
+struct IcpBatchPair { const float *depth_src; const float4 *nmap_tgt; float scale; int pad; };
+struct IcpLevel { float md2; int stride, Ws, Hs, iters, pad; double damping, eps, eig_rel; };
+struct IcpBatchArgs {
+    const IcpBatchPair *pairs;   // [n_pairs]
+    IcpState *states;            // [n_pairs] initial pose in, result out
+    unsigned *sync;              // two arrays of 64 x sync_rows 64-B lines: arrival counters, then generation words (zero at launch);
+                                 // pair p owns line (p % 64) * sync_rows + p / 64 of each
+    double *slab;                // [n_pairs][members][ICP_SLAB] partial sums of the current pass
+    unsigned *ctl;               // [0] workgroup tickets handed out, [1] error (a wait timed out); zero at launch
+    int n_pairs, members, n_levels, sync_rows, poll_rmw, zero;
+    float mind, maxd;
+    unsigned *stage;             // experiments: [n_pairs * members][4] progress markers (null in production)
+    unsigned long long *dbg;     // experiments: [members][16 passes][8] timestamps of pair 0 (null in production)
+    IcpLevel lv[ICP_MAX_LEVELS];
+};
+
+// Frame buffers come from slabs, not one hipMalloc per buffer: a 1000-frame context used to make (and, slower, free) 4000
+// allocations.  One pool per buffer kind (equal-sized blocks); a slab holds up to 64 blocks and lives until tl3d_destroy.
+constexpr int FRAME_SLAB_BLOCKS = 64;
+struct FramePool {
+    size_t block = 0;             // bytes per block, rounded up to 256
+    int remaining = 0;            // blocks this pool may still hand out (= frame slots without a buffer of this kind)
+    char *cur = nullptr;          // next free block of the newest slab
+    int cur_left = 0;
+    void **slabs = nullptr;       // [max_slabs]
+    int n_slabs = 0, max_slabs = 0;
 };
 
 struct Slot {
@@ -94,6 +126,7 @@ struct tl3d_ctx {
     tl3d::Grid grid;
     size_t nvox;
     tl3d::Slot *slots;
+    tl3d::FramePool pool_depth, pool_u16, pool_bgr, pool_nmap;
     int2 *tsdf;                  // [nvox] {sum_q, weight}
     unsigned long long *centroid;// [nvox][4]
     bool own_tsdf, own_centroid;
@@ -156,6 +189,21 @@ struct tl3d_ctx {
         int src_slot, tgt_slot;  // the run reads slots[src].depth and slots[tgt].nmap
     };
     IcpLane icp_lanes[TL3D_ICP_LANES];
+    struct IcpBatch {            // one batch of registrations in flight, on its own stream
+        hipStream_t stream;
+        hipEvent_t ev_ready, ev_done;
+        int cap_pairs; size_t cap_slab;          // capacities of the buffers below
+        int sync_rows;                           // geometry of `sync` (see IcpBatchArgs)
+        tl3d::IcpBatchPair *pairs, *pairs_host;  // device / pinned
+        tl3d::IcpState *states, *states_host;
+        unsigned *sync, *ctl, *ctl_host;
+        double *slab;
+        int n_pairs;             // of the run in flight
+        unsigned *stage; size_t stage_n;  // experiments (TL3D_ICP_STAGES)
+        unsigned long long *dbg; // experiments (TL3D_ICP_TRACE)
+        int dbg_members;
+        bool busy;
+    } icp_batch;
     float *bounds_slab;
     // stats / profiling
     tl3d_stats stats;
@@ -191,6 +239,8 @@ __device__ __forceinline__ size_t vox_index(int i, int j, int k, int nbx, int nb
 int launch_u16_to_f32(hipStream_t s, const uint16_t *in, float *out, size_t n);
 // back-projection
 int launch_scan(hipStream_t s, const unsigned *counts, unsigned long long *offsets, int n, unsigned long long *total);
+int launch_bp_bounds(hipStream_t s, const Cam &cam, const BpArgs &a, const PoseD &p, const float *depth, const double *xf, const double *yf,
+                     float *slab, int nblocks);
 int bp_fused_tiles(const BpArgs &a);
 int bp_state_words(const BpArgs &a);
 int launch_bp_fused(hipStream_t s, const Cam &cam, const BpArgs &a, const PoseD &p, const float *depth, const uint8_t *bgr,
@@ -211,6 +261,7 @@ int launch_tsdf_update(hipStream_t s, const Cam &cam, const Grid &g, const PoseF
 int launch_fold_free(hipStream_t s, const Grid &g, int2 *grid, unsigned *free_cnt);
 // normals + icp
 int launch_normals(hipStream_t s, const Cam &cam, const float *depth, float scale, float mind, float maxd, float jump, float4 *nmap);
+int launch_icp_batch(hipStream_t s, const Cam &cam, const IcpBatchArgs &a);
 int launch_icp_iteration(hipStream_t s, const Cam &cam, const IcpRun *run, int final_pass, double *slab, IcpState *state, int nblocks,
                          unsigned *ticket);
 // extraction

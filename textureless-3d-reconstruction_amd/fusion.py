@@ -196,6 +196,16 @@ class FusionContext:
         abi.check(self._lib.tl3d_backproject_device(self._h, int(slot), abi.ptr(r), abi.ptr(t), float(scale), flags, int(subsample),
                                                     mn, mx, abi.ptr(out_xyz), abi.ptr(out_rgb), cap, abi.ptr(out_n)))
 
+    def frame_bounds(self, slot: int, pose=None, scale=1.0, subsample: int = 1, min_depth=None, max_depth=None, scale_f64: bool = False):
+        """(min[3], max[3]) of the points backproject() would return, computed on the device (+-inf when there are none)."""
+        r, t, flags = self._pose_args(pose, abi.F_SCALE_F64 if scale_f64 else 0)
+        mn_d = self.min_depth if min_depth is None else float(min_depth)
+        mx_d = self.max_depth if max_depth is None else float(max_depth)
+        lo, hi = np.zeros(3), np.zeros(3)
+        abi.check(self._lib.tl3d_frame_bounds(self._h, int(slot), abi.ptr(r), abi.ptr(t), float(scale), flags, int(subsample), mn_d, mx_d,
+                                              abi.ptr(lo), abi.ptr(hi), None))
+        return lo, hi
+
     # ---- fusion ----------------------------------------------------------------------------
     def accumulate_centroid(self, slot: int, pose=None, scale=1.0, subsample: int = 1, min_depth=None, max_depth=None,
                             scale_f64: bool = False):
@@ -257,6 +267,37 @@ class FusionContext:
         abi.check(self._lib.tl3d_icp_collect(self._h, int(lane), C.byref(res)))
         return dict(T=np.array(res.T).reshape(4, 4), fitness=res.fitness, rmse=res.rmse, n_corr=res.n_corr,
                     n_src=res.n_src, iters_run=res.iters_run, status=res.status)
+
+    def icp_batch_enqueue(self, pairs, levels, T_init=None, scales=None):
+        """Register every (slot_src, slot_tgt) of `pairs` through all of `levels` in ONE launch (asynchronous).
+
+        levels: sequence of dicts with the keyword arguments of icp() (iters, stride, max_dist, damping, eps, eig_rel),
+        coarse to fine.  T_init: one 4x4 per pair (default identity); scales: metric scale of each pair's source depth."""
+        n = len(pairs)
+        arr = (abi.IcpPair * n)()
+        eye = np.eye(4)
+        for i, (a, b_) in enumerate(pairs):
+            arr[i].slot_src, arr[i].slot_tgt = int(a), int(b_)
+            arr[i].scale_src = 1.0 if scales is None else float(scales[i])
+            T0 = eye if T_init is None or T_init[i] is None else np.asarray(T_init[i], np.float64).reshape(4, 4)
+            arr[i].T_init[:] = T0.ravel().tolist()
+        lv = (abi.IcpParams * len(levels))()
+        for i, kw in enumerate(levels):
+            lv[i] = abi.IcpParams(int(kw.get("iters", 10)), int(kw.get("stride", 4)), float(kw.get("max_dist", 0.05)),
+                                  float(kw.get("damping", 1e-6)), float(kw.get("eps", 1e-9)), float(kw.get("eig_rel", 1e-4)))
+        abi.check(self._lib.tl3d_icp_batch_enqueue(self._h, arr, n, lv, len(levels)))
+        self._icp_batch_n = n
+
+    def icp_batch_collect(self):
+        n = self._icp_batch_n
+        res = (abi.IcpResult * n)()
+        abi.check(self._lib.tl3d_icp_batch_collect(self._h, res, n))
+        return [dict(T=np.array(r.T).reshape(4, 4), fitness=r.fitness, rmse=r.rmse, n_corr=r.n_corr, n_src=r.n_src,
+                     iters_run=r.iters_run, status=r.status) for r in res]
+
+    def icp_batch(self, pairs, levels, T_init=None, scales=None):
+        self.icp_batch_enqueue(pairs, levels, T_init, scales)
+        return self.icp_batch_collect()
 
     # ---- grids -----------------------------------------------------------------------------
     def reset(self):

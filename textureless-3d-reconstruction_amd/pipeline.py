@@ -14,6 +14,8 @@ from __future__ import annotations
 
 from typing import List, Optional, Tuple
 
+import time
+
 import numpy as np
 
 from . import _cabi as abi
@@ -139,6 +141,7 @@ class DepthToReconstructionPipeline:
         self.frame_index: List[int] = []          # which loaded frame each pose belongs to
         self.icp_log: List[dict] = []
         self.stats: dict = {}
+        self.timings: dict = {}                   # wall seconds per stage of the last reconstruct()
         self.grid: Optional[GridSpec] = None      # the fusion volume of the last reconstruct()
 
     # ---- a2 --------------------------------------------------------------------------------------
@@ -179,13 +182,11 @@ class DepthToReconstructionPipeline:
 
     # ---- poses: ICP replaces detect_and_match / compute_pose ---------------------------------------
     def _register(self, ctx: FusionContext, scales, init_poses=None):
-        """Frame-to-frame registration.  Consecutive pairs are independent, so they are enqueued on the library's ICP
-        lanes in batches (each run is a latency-bound chain of small kernels; several chains fill the GPU) and collected
-        in order.  A failed pair drops its frame (reference rule, D2R:598-615): the following pair is then re-registered
-        against the last kept frame."""
+        """Frame-to-frame registration.  Consecutive pairs are independent: they go to the device in batches, every pair of
+        a batch through all its levels and iterations inside one launch.  A failed pair drops its frame (reference rule,
+        D2R:598-615): the following pair is then re-registered against the last kept frame."""
         cfg = self.config
         n = len(self.depths)
-        lanes = abi.ICP_LANES
         if not isinstance(scales, (list, tuple)):
             scales = [float(scales)] * n
         # coarse-to-fine: each level is (iterations, pixel stride, correspondence gate); every level starts from the
@@ -197,14 +198,10 @@ class DepthToReconstructionPipeline:
         def level_kw(lv):
             return dict(iters=int(lv[0]), stride=int(lv[1]), max_dist=float(lv[2]), **common)
 
+        level_list = [level_kw(lv) for lv in levels]
+
         def blocking(src, cur, T0):
-            res = None
-            for lv in levels:
-                res = ctx.icp(src, cur, T_init=T0, scale_src=scales[src], **level_kw(lv))
-                if res["status"] == 2 or res["n_corr"] < 8:
-                    break
-                T0 = res["T"]
-            return res
+            return ctx.icp_batch([(src, cur)], level_list, T_init=[T0], scales=[scales[src]])[0]
         poses = [(np.eye(3), np.zeros((3, 1)))]
         index = [0]
         prev = 0
@@ -224,17 +221,12 @@ class DepthToReconstructionPipeline:
 
         i = 1
         while i < n:
-            batch = list(range(i, min(n, i + lanes)))
+            # every pair of a batch runs all its levels inside ONE launch (tl3d_icp_batch_*); batches only exist so that the
+            # constant-velocity prior of the next one can come from the last pose found (a short first batch gets one early)
+            batch = list(range(i, min(n, i + (16 if i == 1 else 128))))
             srcs = [prev if cur == batch[0] else cur - 1 for cur in batch]
             T0s = [prior(src, cur) for src, cur in zip(srcs, batch)]
-            results = [None] * len(batch)
-            for li, lv in enumerate(levels):                    # all pairs of the batch advance level by level
-                live = [k for k in range(len(batch)) if li == 0 or not (results[k]["status"] == 2 or results[k]["n_corr"] < 8)]
-                for k in live:
-                    ctx.icp_enqueue(k, srcs[k], batch[k], T_init=T0s[k], scale_src=scales[srcs[k]], **level_kw(lv))
-                for k in live:
-                    results[k] = ctx.icp_collect(k)
-                    T0s[k] = results[k]["T"]
+            results = ctx.icp_batch(list(zip(srcs, batch)), level_list, T_init=T0s, scales=[scales[src] for src in srcs])
             for lane, cur in enumerate(batch):
                 print(f"\nProcessing image {cur}...")
                 res = results[lane]
@@ -279,6 +271,7 @@ class DepthToReconstructionPipeline:
             print(f"Using depth scale = {scale} (depth assumed metric, as D2R:555-558)")
         # one context: every frame is uploaded once and stays resident in HBM through registration, bounding and fusion
         # (288 GB holds ~19 000 frames of 1080x1920 depth+colour); the grid is attached once the scene bounds are known
+        clock, marks = time.perf_counter, [("start", time.perf_counter())]
         ctx = FusionContext(w, h, cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.min_depth, cfg.max_depth, n_slots=n, grid=None,
                             device=cfg.device)
         try:
@@ -297,21 +290,22 @@ class DepthToReconstructionPipeline:
             # depth maps may be GPU tensors (depth estimated in this process): the scale rule then reads them back per frame
             host_depths = [d if isinstance(d, np.ndarray) else None for d in self.depths]
             self.scales = per_frame_scales(host_depths, anchors, default=scale, fetch=ctx.download_depth)
+            marks.append(("upload", clock()))
             if poses is not None:
                 self.camera_poses, self.frame_index = list(poses), list(range(len(poses)))
             else:
                 print("\n--- Step 1: Register frames (point-to-plane ICP, frame to frame) ---")
                 self.camera_poses, self.frame_index = self._register(ctx, self.scales, init_poses)
+            marks.append(("register", clock()))
             if len(self.camera_poses) < 2:
                 print("Pose estimation failed")
                 return None, None, None
             if grid is None:
                 print("\n--- Step 2: Bound the scene ---")
                 mn, mx = np.full(3, np.inf), np.full(3, -np.inf)
-                for pose, fi in zip(self.camera_poses, self.frame_index):
-                    pts, _ = ctx.backproject(fi, pose=pose, scale=self.scales[fi], subsample=cfg.subsample_factor)
-                    if len(pts):
-                        mn, mx = np.minimum(mn, pts.min(0)), np.maximum(mx, pts.max(0))
+                for pose, fi in zip(self.camera_poses, self.frame_index):        # extent of each frame's cloud, on the device
+                    lo_, hi_ = ctx.frame_bounds(fi, pose=pose, scale=self.scales[fi], subsample=cfg.subsample_factor)
+                    mn, mx = np.minimum(mn, lo_), np.maximum(mx, hi_)
                 if not np.all(np.isfinite(mn)):
                     print("Reconstruction failed")
                     return None, None, None
@@ -323,6 +317,7 @@ class DepthToReconstructionPipeline:
             print(f"  Grid {grid.dims} @ {grid.voxel_size * 1e3:g} mm, origin {np.round(grid.origin, 4)}")
             self.grid = grid
             ctx.attach_grid(grid)
+            marks.append(("bound_and_allocate", clock()))
             print("\n--- Step 3: Fuse depth frames (TSDF + voxel centroids) ---")
             for pose, fi in zip(self.camera_poses, self.frame_index):
                 if grid.channels & abi.CH_TSDF:
@@ -330,6 +325,7 @@ class DepthToReconstructionPipeline:
                 ctx.accumulate_centroid(fi, pose, scale=self.scales[fi], subsample=cfg.subsample_factor)
                 print(f"Camera {fi}: fused")
             st = ctx.stats()
+            marks.append(("fuse", clock()))
             print("\n--- Step 4: Extract and clean point cloud ---")
             xyz, rgb = ctx.extract(abi.EXTRACT_CENTROID, min_count=1, min_weight=cfg.tsdf_min_weight,
                                    max_abs_tsdf=cfg.tsdf_max_abs)
@@ -339,6 +335,9 @@ class DepthToReconstructionPipeline:
                 xyz, rgb = xyz[keep], rgb[keep]
             self.stats = dict(points_accumulated=st["centroid_points"], points_dropped=st["centroid_dropped"],
                               voxels=n_vox, after_outlier_filter=len(xyz))
+            marks.append(("extract_and_filter", clock()))
+            # wall time of each stage of this call (host clock; stages end at a point where the host has the stage's result)
+            self.timings = {name + "_s": round(t1 - t0, 4) for (name, t1), (_, t0) in zip(marks[1:], marks[:-1])}
         finally:
             ctx.close()
         print(f"\nFinal reconstruction: {len(xyz)} points, {len(self.camera_poses)} cameras")
@@ -346,13 +345,12 @@ class DepthToReconstructionPipeline:
 
     # ---- multi-GPU: frames shard across ranks, one exchange step at merge time -------------
     def _register_pairs(self, ctx: FusionContext, pairs, slot_of, scales, init_poses=None, T_guess=None):
-        """Independent registrations (src, cur) -> result dict, `lanes` at a time, every pair through the coarse-to-fine
-        levels.  slot_of maps a global frame index to its resident slot."""
+        """Independent registrations (src, cur) -> result dict, every pair through the coarse-to-fine levels inside one
+        launch per batch.  slot_of maps a global frame index to its resident slot."""
         cfg = self.config
         levels = [tuple(l) for l in cfg.icp_coarse] + [(cfg.icp_iters, cfg.icp_stride, cfg.icp_max_dist)]
         common = dict(damping=cfg.icp_damping, eig_rel=cfg.icp_eig_rel, eps=cfg.icp_eps)
         out = {}
-        lanes = abi.ICP_LANES
 
         def prior(a, b_):
             if init_poses is None:
@@ -364,19 +362,11 @@ class DepthToReconstructionPipeline:
             T[:3, :3], T[:3, 3] = rr, (np.asarray(t1).reshape(3) - rr @ np.asarray(t0).reshape(3))
             return T
 
-        for i0 in range(0, len(pairs), lanes):
-            batch = pairs[i0:i0 + lanes]
-            T0s = [prior(a, b_) for a, b_ in batch]
-            results = [None] * len(batch)
-            for li, lv in enumerate(levels):
-                live = [k for k in range(len(batch)) if li == 0 or not (results[k]["status"] == 2 or results[k]["n_corr"] < 8)]
-                for k in live:
-                    a, b_ = batch[k]
-                    ctx.icp_enqueue(k, slot_of[a], slot_of[b_], T_init=T0s[k], scale_src=scales[a], iters=int(lv[0]), stride=int(lv[1]),
-                                    max_dist=float(lv[2]), **common)
-                for k in live:
-                    results[k] = ctx.icp_collect(k)
-                    T0s[k] = results[k]["T"]
+        level_list = [dict(iters=int(lv[0]), stride=int(lv[1]), max_dist=float(lv[2]), **common) for lv in levels]
+        for i0 in range(0, len(pairs), 256):
+            batch = pairs[i0:i0 + 256]
+            results = ctx.icp_batch([(slot_of[a], slot_of[b_]) for a, b_ in batch], level_list, T_init=[prior(a, b_) for a, b_ in batch],
+                                    scales=[scales[a] for a, _ in batch])
             for (a, b_), res in zip(batch, results):
                 out[b_] = dict(res, against=a)
         return out
@@ -463,9 +453,8 @@ class DepthToReconstructionPipeline:
                 say("\n--- Step 2: Bound the scene ---")
                 mn, mx = np.full(3, np.inf), np.full(3, -np.inf)
                 for g in mine:
-                    pts, _ = ctx.backproject(slot_of[g], pose=pose_of[g], scale=self.scales[g], subsample=cfg.subsample_factor)
-                    if len(pts):
-                        mn, mx = np.minimum(mn, pts.min(0)), np.maximum(mx, pts.max(0))
+                    lo_, hi_ = ctx.frame_bounds(slot_of[g], pose=pose_of[g], scale=self.scales[g], subsample=cfg.subsample_factor)
+                    mn, mx = np.minimum(mn, lo_), np.maximum(mx, hi_)
                 mn, mx = dd.allreduce_bounds(mn, mx, dist)
                 if not np.all(np.isfinite(mn)):
                     say("Reconstruction failed")

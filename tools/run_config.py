@@ -104,7 +104,7 @@ def main():
         pts, col, est = pipe.reconstruct()
     t_rec = time.perf_counter() - t0
     out = dict(config=name, frames=n, width=W, height=H, valid_pixel_fraction=round(valid_frac, 3), render_s=round(t_render, 1),
-               reconstruct_s=round(t_rec, 2), frames_per_s_whole_pipeline=round(n / t_rec, 1))
+               reconstruct_s=round(t_rec, 2), frames_per_s_whole_pipeline=round(n / t_rec, 1), stage_s=pipe.timings)
     if pts is None:
         out["error"] = "reconstruction failed"
         print(json.dumps(out))
