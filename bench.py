@@ -132,25 +132,25 @@ def main():
             T0 = np.eye(4)
             T0[:3, :3], T0[:3, 3] = r_rel, t_rel.ravel()
             T_rel.append(T0)
-    LANES = tl3d.ICP_LANES
+
+    icp_level = [dict(iters=args.icp_iters, stride=4, max_dist=0.05)]
 
     def step(s, icp=args.icp, centroid=args.centroid, frames=F):
-        # registration of group g+1 (half of the lanes) runs while group g is fused (the other half was collected before)
-        G = max(1, LANES // 2)
+        # registration of group g+1 (one batched launch: every pair through all its iterations) runs while group g is fused
+        G = 64
         groups = [[(s * frames + j) % n_res for j in range(j0, min(frames, j0 + G))] for j0 in range(0, frames, G)]
 
         def enqueue(gi):
-            for i, k in enumerate(groups[gi]):
-                ctx.icp_enqueue((gi & 1) * G + i, (k - 1) % n_res, k, T_init=T_rel[k], iters=args.icp_iters, stride=4, max_dist=0.05)
+            ks = groups[gi]
+            ctx.icp_batch_enqueue([((k - 1) % n_res, k) for k in ks], icp_level, T_init=[T_rel[k] for k in ks])
 
         if icp:
             enqueue(0)
         for gi, ks in enumerate(groups):
             if icp:
+                ctx.icp_batch_collect()
                 if gi + 1 < len(groups):
                     enqueue(gi + 1)
-                for i in range(len(ks)):
-                    ctx.icp_collect((gi & 1) * G + i)
             for k in ks:
                 ctx.integrate(k, poses[k])
                 if centroid:
@@ -353,9 +353,21 @@ def main():
         ctx.reset()
         t_s = timed(lambda k: step(k, icp=True, centroid=True, frames=nf), 2)
         rows["icp_in_loop_tsdf_plus_centroid_fps"] = round(nf / t_s, 1)
-        rows["icp"] = {"iters": args.icp_iters, "stride": 4, "lanes": LANES, "prior": "analytic inter-frame motion"}
+        rows["icp"] = {"iters": args.icp_iters, "stride": 4, "pairs_per_launch": 64, "prior": "analytic inter-frame motion"}
         one = timed(lambda k: ctx.icp((k - 1) % n_res, k % n_res, T_init=T_rel[k % n_res], iters=args.icp_iters, stride=4, max_dist=0.05, eps=0.0), 24)
         rows["icp_single_chain_us_per_iteration"] = round(1e6 * one / (args.icp_iters + 1), 2)
+        # batched registration alone: every resident pair in ONE launch (all iterations inside the kernel), and the pipeline's
+        # two-level coarse-to-fine schedule (10 x stride 4 @ 20 cm, then 15 x stride 2 @ 5 cm, stop at a 1e-7 update)
+        all_pairs = [((k - 1) % n_res, k) for k in range(n_res)]
+        fixed = [dict(iters=args.icp_iters, stride=4, max_dist=0.05, eps=0.0)]
+        t_b = timed(lambda k: ctx.icp_batch(all_pairs, fixed, T_init=T_rel), 4)
+        rows["icp_batch_pairs_per_s"] = round(n_res / t_b, 1)
+        rows["icp_batch_us_per_pair_iteration"] = round(1e6 * t_b / n_res / (args.icp_iters + 1), 3)
+        two = [dict(iters=10, stride=4, max_dist=0.2, eps=1e-7), dict(iters=15, stride=2, max_dist=0.05, eps=1e-7)]
+        t_b = timed(lambda k: ctx.icp_batch(all_pairs, two), 4)
+        rows["icp_batch_two_level_from_identity_pairs_per_s"] = round(n_res / t_b, 1)
+        t_b = timed(lambda k: ctx.icp_batch(all_pairs[1:2], fixed, T_init=T_rel[1:2]), 16)
+        rows["icp_batch_one_pair_us_per_iteration"] = round(1e6 * t_b / (args.icp_iters + 1), 2)
         cap_pts = H * W
         xyz_d = torch.empty((cap_pts, 3), dtype=torch.float32, device=dev)
         rgb_d = torch.empty((cap_pts, 3), dtype=torch.uint8, device=dev)

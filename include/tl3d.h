@@ -173,6 +173,12 @@ int tl3d_frame_bounds(tl3d_ctx *ctx, int slot, const double R[9], const double t
                       int subsample, double min_depth, double max_depth, double out_min[3], double out_max[3],
                       int64_t *out_reserved /* may be NULL */);
 
+/* The same over n_frames frames with ONE read-back per 16 frames: R = n_frames x 9, t = n_frames x 3 (NULL with
+ * TL3D_F_NO_POSE), scales = n_frames entries (NULL = 1.0).  The scene-bounding pass of the pipeline (D2R:404-410 bounds the
+ * merged cloud; the extent of the union is the union of the extents). */
+int tl3d_frames_bounds(tl3d_ctx *ctx, int n_frames, const int32_t *slots, const double *R, const double *t, const double *scales,
+                       uint32_t flags, int subsample, double min_depth, double max_depth, double out_min[3], double out_max[3]);
+
 /* a7 (fusion half): accumulate the same points straight into the centroid channel, no point list
  * (replaces np.vstack + Open3D voxel_down_sample's hash-map insert, D2R:401-410). */
 int tl3d_accumulate_centroid(tl3d_ctx *ctx, int slot, const double R[9], const double t[3], double scale,

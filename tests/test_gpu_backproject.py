@@ -217,3 +217,22 @@ def test_frame_bounds_equal_the_extent_of_the_point_list():
                 assert np.array_equal(lo, pts.min(0).astype(np.float64)) and np.array_equal(hi, pts.max(0).astype(np.float64))
         lo, hi = ctx.frame_bounds(1, pose=pose)
         assert np.all(np.isinf(lo)) and np.all(lo > 0) and np.all(np.isinf(hi)) and np.all(hi < 0)
+
+
+def test_frames_bounds_is_the_union_of_the_frames_extents():
+    rng = np.random.default_rng(9)
+    h, w, n = 60, 80, 37                                   # more frames than one read-back round holds
+    with tl3d.FusionContext(w, h, 70.0, 72.0, 40.0, 30.0, n_slots=n) as ctx:
+        poses, lo, hi = [], np.full(3, np.inf), np.full(3, -np.inf)
+        scales = 0.5 + rng.random(n)
+        for i in range(n):
+            d = (0.3 + 3.0 * rng.random((h, w))).astype(np.float32)
+            d[rng.random((h, w)) < 0.2] = 0.0
+            ctx.upload(i, d, None)
+            q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+            q *= np.sign(np.linalg.det(q))
+            poses.append((q, rng.normal(size=3)))
+            a, b = ctx.frame_bounds(i, pose=poses[-1], scale=scales[i], subsample=2)
+            lo, hi = np.minimum(lo, a), np.maximum(hi, b)
+        got = ctx.frames_bounds(list(range(n)), poses, scales, subsample=2)
+    assert np.array_equal(got[0], lo) and np.array_equal(got[1], hi)

@@ -46,6 +46,7 @@ def test_bench_json_contract():
     # the rest of the path, measured in the same run (registration in the loop, centroid channel, back-projection, extraction)
     rows = d["rows"]
     for k in ("tsdf_plus_centroid_s2_fps", "icp_in_loop_tsdf_fps", "icp_in_loop_tsdf_plus_centroid_fps", "icp_single_chain_us_per_iteration",
+              "icp_batch_pairs_per_s", "icp_batch_two_level_from_identity_pairs_per_s", "icp_batch_one_pair_us_per_iteration",
               "backproject_s1_device_us", "backproject_s1_GBps", "extract_centroid_to_host_ms", "outlier_filter_k20_ms"):
         assert rows[k] > 0, k
     assert rows["extract_points"] > 100 and rows["outlier_filter_kept"] <= rows["extract_points"]

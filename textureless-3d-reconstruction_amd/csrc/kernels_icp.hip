@@ -393,7 +393,12 @@ __device__ __forceinline__ int solve6_wave(const double *__restrict__ a21, const
     return used == 0;
 }
 
-__device__ void se3_apply(const double x[6], double *T) {
+// State words another workgroup of the same launch reads next (batched runs): write-through (agent-scope) stores, so that
+// they need no L2 write-back before the hand-off; the reader acquires as before.
+template <typename V> __device__ __forceinline__ void st_agent(V *p, V v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename V> __device__ __forceinline__ V ld_agent(const V *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ void se3_apply(const double x[6], double *T, float *T_f32 = nullptr) {
     const double wx = x[0], wy = x[1], wz = x[2];
     const double th2 = wx * wx + wy * wy + wz * wz;
     const double th = sqrt(th2);
@@ -417,12 +422,16 @@ __device__ void se3_apply(const double x[6], double *T) {
         Tn[4 * i + 3] += x[3 + i];
     }
     Tn[12] = 0; Tn[13] = 0; Tn[14] = 0; Tn[15] = 1;
-    for (int i = 0; i < 16; ++i) T[i] = Tn[i];
+    for (int i = 0; i < 16; ++i) st_agent(T + i, Tn[i]);
+    if (T_f32)
+        for (int i = 0; i < 12; ++i) T_f32[i] = (float)Tn[i];
 }
 
 // The last workgroup's part: fixed-order sum of the published partials, solve, pose update.
-__device__ __forceinline__ void icp_finish(const double *slab, int nblocks, IcpState *state, double damping, double eps, double eig_rel,
-                                           int final_pass, double (*part)[ICP_SLAB], double *sums) {
+// Returns (thread 0 only) 1 when the run converged, 2 when it failed in this pass, else 0.  T_f32: where thread 0 leaves the
+// new pose as the 12 floats a pass uses (LDS; untouched when the pose did not change).
+__device__ __forceinline__ int icp_finish(const double *slab, int nblocks, IcpState *state, double damping, double eps, double eig_rel,
+                                          int final_pass, double (*part)[ICP_SLAB], double *sums, float *T_f32 = nullptr, int updates_so_far = -1) {
     const int t = threadIdx.x;
     {   // slab reduction: 8 groups x 32 components, loads batched 8 deep, combined in a fixed order (deterministic).
         // The partials were written by other CUs in THIS launch: agent-scope (sc1) loads, never served from this CU's L1
@@ -448,23 +457,25 @@ __device__ __forceinline__ void icp_finish(const double *slab, int nblocks, IcpS
         state->sums[t] = s;
     }
     __syncthreads();
-    if (final_pass || t >= 64) return;                     // wave 0 solves
+    if (final_pass || t >= 64) return 0;                   // wave 0 solves
     double x[6];
     const int fail = (sums[28] < 6.0) ? 1 : solve6_wave(sums, sums + 21, damping, eig_rel, x);
-    if (t != 0) return;
+    if (t != 0) return 0;
     if (fail) {
-        state->done = 1;
-        state->status = 2;
-        return;
+        st_agent(&state->done, 1);
+        st_agent(&state->status, 2);
+        return 2;
     }
-    se3_apply(x, state->T);
-    state->iters_run += 1;
+    se3_apply(x, state->T, T_f32);
+    st_agent(&state->iters_run, (updates_so_far >= 0 ? updates_so_far : ld_agent(&state->iters_run)) + 1);    // (the load is a round trip)
     double mx = 0.0;
     for (int i = 0; i < 6; ++i) mx = fmax(mx, fabs(x[i]));
     if (mx < eps) {
-        state->done = 1;
-        state->status = 1;
+        st_agent(&state->done, 1);
+        st_agent(&state->status, 1);
+        return 1;
     }
+    return 0;
 }
 
 // One ICP iteration in one launch.  Hand-off between workgroups inside the launch (MI355X guide, Guideline 16 / the
@@ -495,20 +506,24 @@ __global__ __launch_bounds__(256) void icp_iter_kernel(Cam cam, const IcpRun *__
     }
     __syncthreads();
     if (!s_last) return;
-    icp_finish(slab, (int)gridDim.x, state, run->damping, run->eps, run->eig_rel, final_pass, sm, tot);
+    (void)icp_finish(slab, (int)gridDim.x, state, run->damping, run->eps, run->eig_rel, final_pass, sm, tot);
     if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // re-arm for the next launch
 }
 
 // A batch of registrations, each through all its levels and iterations, in ONE launch.  `members` workgroups share a
 // pair; after every pass they meet at the pair's barrier in device memory: partial sums as agent-scope stores (drained),
-// one arrival ticket per workgroup, the last arriver sums the partials in member order, solves, updates the pose and
-// publishes the next generation word (pass count + the done / over flags) with a release store; the others poll that
-// word (one lane per workgroup; a long first sleep, then short ones: polls of one word from a hundred CUs at full rate
-// saturate its memory channel and starve the arrivals).  Arrival counter and generation word of a pair sit in different
-// cache lines, and consecutive pairs' lines are > 4 KB apart (different channels).
+// one arrival ticket per workgroup; the last arriver acquires, sums the partials in member order, solves, updates the
+// pose (write-through stores, drained) and publishes the pair's 64-B generation line: words 1..12 = the new pose as the
+// twelve floats the next pass uses, then word 0 = pass count + the done / over / failed flags.  The others poll that line with ONE
+// wave instruction (13 lanes, one 64-B request) that returns the flags and the pose together: no fence and no load on
+// the waiting side.  Publishing and polling are read-modify-write atomics, which execute at the memory side: polls by
+// agent-scope (sc1) LOADS were seen to return a word their XCD had cached before the store for seconds (88 of 113
+// members of a pair stuck, the 25 on the publisher's XCD gone ahead), whatever the allocation flags.  A long first sleep,
+// then short ones: polls of one line from a hundred CUs at full rate saturate its channel and starve the arrivals.
+// Arrival counter and generation line of a pair are different lines; consecutive pairs' lines are > 4 KB apart.
 // Waiting needs the pair's other workgroups to be running: workgroups therefore take their (pair, member) from a ticket
 // counter as they START, so the members of every pair but the newest are all resident (or done) whatever the dispatch
-// order, and the newest pair gets the slots the older ones free -- the grid always drains (members <= 128 workgroups
+// order, and the newest pair gets the slots the older ones free -- the grid always drains (members <= 64 workgroups
 // against >= 256 resident ones).  Every wait is bounded in time; a time-out raises the error word and ends the launch.
 constexpr unsigned long long ICP_WAIT_LIMIT_TICKS = 200000000ull;          // 2 s of the 100 MHz wall clock
 __device__ __forceinline__ size_t icp_sync_line(int pair, int rows) {        // 16-word line of `pair`: neighbours are rows*64 B (> 4 KB) apart
@@ -517,7 +532,7 @@ __device__ __forceinline__ size_t icp_sync_line(int pair, int rows) {        // 
 __global__ __launch_bounds__(256) void icp_batch_kernel(Cam cam, IcpBatchArgs a) {
     __shared__ double sm[8][ICP_SLAB];
     __shared__ double tot[ICP_SLAB];
-    __shared__ double sT[12];
+    __shared__ float sT[12];
     __shared__ int s_flag[4];                              // [0] ticket, [1] last arriver, [2] generation word seen, [3] wait failed
     const int tid = threadIdx.x;
     if (tid == 0) s_flag[0] = (int)__hip_atomic_fetch_add(a.ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -530,24 +545,24 @@ __global__ __launch_bounds__(256) void icp_batch_kernel(Cam cam, IcpBatchArgs a)
     unsigned *stage = a.stage ? a.stage + (size_t)ticket * 4 : nullptr;      // experiments: how far this workgroup got
     if (stage && tid == 0) { stage[0] = 1u; stage[1] = (unsigned)blockIdx.x; stage[3] = __builtin_amdgcn_s_getreg((4 << 11) | (0 << 6) | 20); }
     unsigned *arrive = a.sync + icp_sync_line(pair, a.sync_rows);
-    unsigned *genw = a.sync + (size_t)64 * a.sync_rows * 16 + icp_sync_line(pair, a.sync_rows);
+    unsigned *genl = a.sync + (size_t)64 * a.sync_rows * 16 + icp_sync_line(pair, a.sync_rows);
     double *slab = a.slab + (size_t)pair * a.members * ICP_SLAB;
     unsigned gen = 0;
+    int failed_run = 0;                                    // a pass of this pair found the system singular (status 2)
     unsigned long long *dbg = (a.dbg && pair == 0 && tid == 0) ? a.dbg + (size_t)member * 16 * 8 : nullptr;
 #define ICP_STAMP(k_) do { if (dbg && gen < 16u) dbg[gen * 8 + (k_)] = wall_clock64(); } while (0)
+    if (tid < 12) sT[tid] = (float)st->T[tid];             // the initial pose: uploaded before the launch
+    __syncthreads();
     for (int lv = 0; lv < a.n_levels; ++lv) {
         const IcpLevel L = a.lv[lv];
         int done = 0, over = 0;
         for (int it = 0;; ++it) {
             const int final_pass = (done || it >= L.iters);
             ICP_STAMP(0);
-            // the pose of this pass: after the first pass it was written by another CU inside this launch
-            if (tid < 12) sT[tid] = __hip_atomic_load(st->T + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __syncthreads();
             float r[9], t[3];
-            r[0] = (float)sT[0]; r[1] = (float)sT[1]; r[2] = (float)sT[2];  t[0] = (float)sT[3];
-            r[3] = (float)sT[4]; r[4] = (float)sT[5]; r[5] = (float)sT[6];  t[1] = (float)sT[7];
-            r[6] = (float)sT[8]; r[7] = (float)sT[9]; r[8] = (float)sT[10]; t[2] = (float)sT[11];
+            r[0] = sT[0]; r[1] = sT[1]; r[2] = sT[2];  t[0] = sT[3];
+            r[3] = sT[4]; r[4] = sT[5]; r[5] = sT[6];  t[1] = sT[7];
+            r[6] = sT[8]; r[7] = sT[9]; r[8] = sT[10]; t[2] = sT[11];
             ICP_STAMP(1);
             icp_accumulate_core(cam, pr.depth_src, pr.nmap_tgt, pr.scale, a.mind, a.maxd, L.md2, L.stride, L.Ws, L.Hs, r, t, member, a.members, sm, tot,
                                 (dbg && gen < 16u) ? dbg + gen * 8 + 3 : nullptr);
@@ -571,54 +586,66 @@ __global__ __launch_bounds__(256) void icp_batch_kernel(Cam cam, IcpBatchArgs a)
             }
             ICP_STAMP(5);
             __syncthreads();
-            if (s_flag[1]) {
-                icp_finish(slab, a.members, st, L.damping, L.eps, L.eig_rel, final_pass, sm, tot);
-                if (tid == 0) {
-                    int over_ = 0;
-                    if (final_pass) {                      // what the host did between levels: stop on failure or < 8 correspondences
-                        if (lv == a.n_levels - 1 || __hip_atomic_load(&st->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2 || tot[28] < 8.0) {
-                            st->over = 1;
-                            over_ = 1;
-                        } else {
-                            st->done = 0;
-                            st->status = 0;
-                            st->iters_run = 0;
+            const int last = s_flag[1];
+            if (last) {
+                const int fin = icp_finish(slab, a.members, st, L.damping, L.eps, L.eig_rel, final_pass, sm, tot, sT, it);
+                if (tid < 64) {                            // wave 0 publishes
+                    // thread 0 may just have written the new pose to sT: make that visible to lanes 1..12 of this wave
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    // pose words and the arrival counter of the next pass: one instruction, issued before the state stores have drained
+                    // (returning forms: their data comes back only after the memory side has performed them)
+                    unsigned old = 0;
+                    if (tid >= 1 && tid <= 12) old = __hip_atomic_exchange(genl + tid, __float_as_uint(sT[tid - 1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (tid == 13) old = __hip_atomic_exchange(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("" ::"v"(old));
+                    unsigned word = 0;
+                    if (tid == 0) {
+                        int fl_done = (done || fin != 0), fl_fail = (failed_run || fin == 2), fl_over = 0;
+                        if (final_pass) {                  // what the host did between levels: stop on failure or < 8 correspondences
+                            if (lv == a.n_levels - 1 || fl_fail || tot[28] < 8.0) {
+                                st_agent(&st->over, 1);
+                                fl_over = 1;
+                            } else {
+                                st_agent(&st->done, 0);
+                                st_agent(&st->status, 0);
+                                st_agent(&st->iters_run, 0);
+                                fl_done = 0;
+                            }
                         }
+                        word = ((gen + 1u) << 3) | (fl_fail ? 4u : 0u) | (fl_over ? 2u : 0u) | (fl_done ? 1u : 0u);
+                        s_flag[2] = (int)word;
+                        s_flag[3] = 0;
                     }
-                    const unsigned word = ((gen + 1u) << 2) | (over_ ? 2u : 0u) | (__hip_atomic_load(&st->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1u : 0u);
-                    if (a.poll_rmw) {
-                        (void)__hip_atomic_exchange(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);             // arrivals of the next pass
-                        (void)__hip_atomic_exchange(genw, word, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);            // state above is visible first
-                    } else {
-                        __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(genw, word, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    s_flag[2] = (int)word;
-                    s_flag[3] = 0;
+                    // state stores written through, pose words and arrival counter in place: only then the flags word says so
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (tid == 0) (void)__hip_atomic_exchange(genl, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-            } else if (tid == 0) {
+            } else if (tid < 64) {                         // wave 0 waits for the generation line
                 const unsigned long long t0 = wall_clock64();
-                unsigned word, polls = 0;
-                bool failed = false;
+                unsigned w = 0, word = 0, polls = 0;
+                int failed = 0;
                 __builtin_amdgcn_s_sleep(100);             // the last arriver needs >= 3 us (sum, solve, update)
-                while (((word = a.poll_rmw ? __hip_atomic_fetch_add(genw, (unsigned)a.zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                           : __hip_atomic_load(genw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 2) == gen) {
+                for (;;) {
+                    if (tid < 13) w = __hip_atomic_fetch_add(genl + tid, (unsigned)a.zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    word = __builtin_amdgcn_readfirstlane(w);
+                    if ((word >> 3) != gen) break;
                     if ((++polls & 63u) == 0u &&
                         (wall_clock64() - t0 > ICP_WAIT_LIMIT_TICKS || __hip_atomic_load(a.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
-                        failed = true;
+                        failed = 1;
                         break;
                     }
                     __builtin_amdgcn_s_sleep(16);
                 }
-                if (failed && __hip_atomic_exchange(a.ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                if (failed && tid == 0 && __hip_atomic_exchange(a.ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
                     a.ctl[4] = (unsigned)pair; a.ctl[5] = (unsigned)member; a.ctl[6] = gen; a.ctl[7] = polls;      // the first time-out, for the host's message
                     a.ctl[8] = __hip_atomic_fetch_add(arrive, (unsigned)a.zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    a.ctl[9] = __hip_atomic_fetch_add(genw, (unsigned)a.zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    a.ctl[9] = word;
                     a.ctl[10] = (unsigned)lv; a.ctl[11] = (unsigned)it;
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                s_flag[2] = (int)word;
-                s_flag[3] = failed;
+                if (tid >= 1 && tid <= 12) sT[tid - 1] = __uint_as_float(w);
+                if (tid == 0) { s_flag[2] = (int)word; s_flag[3] = failed; }
             }
             ICP_STAMP(6);
             __syncthreads();
@@ -626,6 +653,7 @@ __global__ __launch_bounds__(256) void icp_batch_kernel(Cam cam, IcpBatchArgs a)
             const int word = s_flag[2], failed = s_flag[3];
             done = word & 1;
             over = (word >> 1) & 1;
+            failed_run = (word >> 2) & 1;
             __syncthreads();                               // s_flag is rewritten by the next pass
             if (failed) return;                            // a wait timed out: the error word is set, the host reports it
             if (final_pass) break;

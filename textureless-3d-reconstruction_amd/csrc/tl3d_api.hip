@@ -699,34 +699,54 @@ int tl3d_backproject_device(tl3d_ctx *ctx, int slot, const double R[9], const do
                            ctx->bp_state, out_xyz_dev, out_rgb_dev, (unsigned long long)cap, reinterpret_cast<unsigned long long *>(out_n_dev));
 }
 
-int tl3d_frame_bounds(tl3d_ctx *ctx, int slot, const double R[9], const double t[3], double scale, uint32_t flags, int subsample,
-                      double min_depth, double max_depth, double out_min[3], double out_max[3], int64_t *out_n_blocks_used) {
-    int rc = check_slot(ctx, slot, true);
-    if (rc) return rc;
-    REQUIRE(out_min && out_max, TL3D_E_INVALID, "null out pointer");
-    REQUIRE((flags & TL3D_F_NO_POSE) || (R && t), TL3D_E_INVALID, "pose required unless TL3D_F_NO_POSE");
+int tl3d_frames_bounds(tl3d_ctx *ctx, int n_frames, const int32_t *slots, const double *R, const double *t, const double *scales,
+                       uint32_t flags, int subsample, double min_depth, double max_depth, double out_min[3], double out_max[3]) {
+    REQUIRE(ctx && slots && out_min && out_max, TL3D_E_INVALID, "null argument");
+    REQUIRE(n_frames >= 1, TL3D_E_INVALID, "n_frames must be positive");
+    REQUIRE((flags & TL3D_F_NO_POSE) || (R && t), TL3D_E_INVALID, "poses required unless TL3D_F_NO_POSE");
+    for (int i = 0; i < n_frames; ++i) {
+        const int rc = check_slot(ctx, slots[i], true);
+        if (rc) return rc;
+    }
     BpArgs a;
-    rc = make_bp_args(ctx, scale, flags, subsample, min_depth, max_depth, &a);
+    int rc = make_bp_args(ctx, scales ? scales[0] : 1.0, flags, subsample, min_depth, max_depth, &a);
     if (rc) return rc;
     TL3D_HIP(hipSetDevice(ctx->device));
-    const Slot &s = ctx->slots[slot];
-    const PoseD p = make_pose_d(R, t, (flags & TL3D_F_NO_POSE) != 0);
     const long long ns = (long long)a.Ws * a.Hs;
     int nb = (int)((ns + 255) / 256);
-    if (nb > 1024) nb = 1024;
-    rc = launch_bp_bounds(ctx->stream, ctx->cam, a, p, s.depth, ctx->bp_factors, ctx->bp_factors + ctx->cam.W, ctx->bounds_slab, nb);
-    if (rc) return rc;
-    std::vector<float> h((size_t)nb * 6);
-    TL3D_HIP(hipMemcpyAsync(h.data(), ctx->bounds_slab, h.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    TL3D_HIP(hipStreamSynchronize(ctx->stream));
+    if (nb > 64) nb = 64;                                  // 16 frames share the 1024-row slab between two read-backs
+    const int per_round = 1024 / nb;
     for (int k = 0; k < 3; ++k) { out_min[k] = INFINITY; out_max[k] = -INFINITY; }
-    for (int b = 0; b < nb; ++b)
-        for (int k = 0; k < 3; ++k) {
-            out_min[k] = fmin(out_min[k], (double)h[(size_t)b * 6 + k]);
-            out_max[k] = fmax(out_max[k], (double)h[(size_t)b * 6 + 3 + k]);
+    std::vector<float> h((size_t)1024 * 6);
+    for (int i0 = 0; i0 < n_frames; i0 += per_round) {
+        const int cnt = n_frames - i0 < per_round ? n_frames - i0 : per_round;
+        for (int j = 0; j < cnt; ++j) {
+            const int i = i0 + j;
+            if (scales) {
+                rc = make_bp_args(ctx, scales[i], flags, subsample, min_depth, max_depth, &a);
+                if (rc) return rc;
+            }
+            const PoseD p = make_pose_d(R ? R + (size_t)9 * i : nullptr, t ? t + (size_t)3 * i : nullptr, (flags & TL3D_F_NO_POSE) != 0);
+            rc = launch_bp_bounds(ctx->stream, ctx->cam, a, p, ctx->slots[slots[i]].depth, ctx->bp_factors, ctx->bp_factors + ctx->cam.W,
+                                  ctx->bounds_slab + (size_t)j * nb * 6, nb);
+            if (rc) return rc;
         }
-    if (out_n_blocks_used) *out_n_blocks_used = nb;
+        TL3D_HIP(hipMemcpyAsync(h.data(), ctx->bounds_slab, (size_t)cnt * nb * 6 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        TL3D_HIP(hipStreamSynchronize(ctx->stream));
+        for (int b = 0; b < cnt * nb; ++b)
+            for (int k = 0; k < 3; ++k) {
+                out_min[k] = fmin(out_min[k], (double)h[(size_t)b * 6 + k]);
+                out_max[k] = fmax(out_max[k], (double)h[(size_t)b * 6 + 3 + k]);
+            }
+    }
     return TL3D_OK;
+}
+
+int tl3d_frame_bounds(tl3d_ctx *ctx, int slot, const double R[9], const double t[3], double scale, uint32_t flags, int subsample,
+                      double min_depth, double max_depth, double out_min[3], double out_max[3], int64_t *out_reserved) {
+    const int32_t s = slot;
+    if (out_reserved) *out_reserved = 0;
+    return tl3d_frames_bounds(ctx, 1, &s, R, t, &scale, flags, subsample, min_depth, max_depth, out_min, out_max);
 }
 
 // ------------------------------------------------------------------------------------------- centroid accumulation
@@ -1232,7 +1252,6 @@ int tl3d_icp_batch_enqueue(tl3d_ctx *ctx, const tl3d_icp_pair *pairs, int n_pair
     a.members = (int)members;
     a.n_levels = n_levels;
     a.sync_rows = b.sync_rows;
-    a.poll_rmw = 1;
     a.mind = (float)ctx->cfg.min_depth;
     a.maxd = (float)ctx->cfg.max_depth;
     if (getenv("TL3D_ICP_TRACE")) {                        // experiments: per-pass timestamps of pair 0

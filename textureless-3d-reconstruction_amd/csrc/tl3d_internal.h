@@ -71,11 +71,11 @@ struct IcpLevel { float md2; int stride, Ws, Hs, iters, pad; double damping, eps
 struct IcpBatchArgs {
     const IcpBatchPair *pairs;   // [n_pairs]
     IcpState *states;            // [n_pairs] initial pose in, result out
-    unsigned *sync;              // two arrays of 64 x sync_rows 64-B lines: arrival counters, then generation words (zero at launch);
+    unsigned *sync;              // two arrays of 64 x sync_rows 64-B lines: arrival counters, then generation lines (zero at launch);
                                  // pair p owns line (p % 64) * sync_rows + p / 64 of each
     double *slab;                // [n_pairs][members][ICP_SLAB] partial sums of the current pass
     unsigned *ctl;               // [0] workgroup tickets handed out, [1] error (a wait timed out); zero at launch
-    int n_pairs, members, n_levels, sync_rows, poll_rmw, zero;
+    int n_pairs, members, n_levels, sync_rows, zero;    // zero: 0 the compiler cannot see (an add of it stays a read-modify-write)
     float mind, maxd;
     unsigned *stage;             // experiments: [n_pairs * members][4] progress markers (null in production)
     unsigned long long *dbg;     // experiments: [members][16 passes][8] timestamps of pair 0 (null in production)

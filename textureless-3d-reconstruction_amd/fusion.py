@@ -206,6 +206,20 @@ class FusionContext:
                                               abi.ptr(lo), abi.ptr(hi), None))
         return lo, hi
 
+    def frames_bounds(self, slots, poses, scales=None, subsample: int = 1, min_depth=None, max_depth=None):
+        """(min[3], max[3]) over the clouds of many frames (poses: one (R, t) per frame), one read-back per 16 frames."""
+        n = len(slots)
+        sl = np.ascontiguousarray(slots, np.int32)
+        R = np.ascontiguousarray(np.stack([np.asarray(p[0], np.float64).reshape(3, 3) for p in poses]))
+        t = np.ascontiguousarray(np.stack([np.asarray(p[1], np.float64).reshape(3) for p in poses]))
+        sc = np.ascontiguousarray(np.ones(n) if scales is None else np.asarray(scales, np.float64))
+        mn_d = self.min_depth if min_depth is None else float(min_depth)
+        mx_d = self.max_depth if max_depth is None else float(max_depth)
+        lo, hi = np.zeros(3), np.zeros(3)
+        abi.check(self._lib.tl3d_frames_bounds(self._h, n, abi.ptr(sl), abi.ptr(R), abi.ptr(t), abi.ptr(sc), 0, int(subsample), mn_d, mx_d,
+                                               abi.ptr(lo), abi.ptr(hi)))
+        return lo, hi
+
     # ---- fusion ----------------------------------------------------------------------------
     def accumulate_centroid(self, slot: int, pose=None, scale=1.0, subsample: int = 1, min_depth=None, max_depth=None,
                             scale_f64: bool = False):

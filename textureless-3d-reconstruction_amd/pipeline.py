@@ -302,10 +302,9 @@ class DepthToReconstructionPipeline:
                 return None, None, None
             if grid is None:
                 print("\n--- Step 2: Bound the scene ---")
-                mn, mx = np.full(3, np.inf), np.full(3, -np.inf)
-                for pose, fi in zip(self.camera_poses, self.frame_index):        # extent of each frame's cloud, on the device
-                    lo_, hi_ = ctx.frame_bounds(fi, pose=pose, scale=self.scales[fi], subsample=cfg.subsample_factor)
-                    mn, mx = np.minimum(mn, lo_), np.maximum(mx, hi_)
+                # extent of the union of the frames' clouds, on the device
+                mn, mx = ctx.frames_bounds(self.frame_index, self.camera_poses, [self.scales[fi] for fi in self.frame_index],
+                                           subsample=cfg.subsample_factor)
                 if not np.all(np.isfinite(mn)):
                     print("Reconstruction failed")
                     return None, None, None
@@ -452,9 +451,9 @@ class DepthToReconstructionPipeline:
             if grid is None:
                 say("\n--- Step 2: Bound the scene ---")
                 mn, mx = np.full(3, np.inf), np.full(3, -np.inf)
-                for g in mine:
-                    lo_, hi_ = ctx.frame_bounds(slot_of[g], pose=pose_of[g], scale=self.scales[g], subsample=cfg.subsample_factor)
-                    mn, mx = np.minimum(mn, lo_), np.maximum(mx, hi_)
+                if mine:
+                    mn, mx = ctx.frames_bounds([slot_of[g] for g in mine], [pose_of[g] for g in mine], [self.scales[g] for g in mine],
+                                               subsample=cfg.subsample_factor)
                 mn, mx = dd.allreduce_bounds(mn, mx, dist)
                 if not np.all(np.isfinite(mn)):
                     say("Reconstruction failed")
