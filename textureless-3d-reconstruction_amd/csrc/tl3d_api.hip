@@ -987,7 +987,8 @@ static void icp_lane_free(tl3d_ctx::IcpLane &ln) {
     if (ln.slab) (void)hipFree(ln.slab);
     if (ln.ticket) (void)hipFree(ln.ticket);
     if (ln.state) (void)hipFree(ln.state);
-    if (ln.graph) (void)hipGraphExecDestroy(ln.graph);
+    for (int g = 0; g < 4; ++g)
+        if (ln.graphs[g]) (void)hipGraphExecDestroy(ln.graphs[g]);
     if (ln.host) (void)hipHostFree(ln.host);
     if (ln.run) (void)hipFree(ln.run);
     if (ln.run_host) (void)hipHostFree(ln.run_host);
@@ -1013,8 +1014,8 @@ static int icp_lane_init(tl3d_ctx *ctx, int lane) {
         icp_lane_free(ln);
         return set_err(TL3D_E_NOMEM, "ICP lane %d: stream / buffer allocation failed", lane);
     }
-    ln.graph = nullptr;
-    ln.graph_iters = -1;
+    for (int g = 0; g < 4; ++g) { ln.graphs[g] = nullptr; ln.graph_iters[g] = -1; }
+    ln.graph_next = 0;
     ln.busy = false;
     ln.src_slot = ln.tgt_slot = -1;
     return TL3D_OK;
@@ -1065,8 +1066,13 @@ int tl3d_icp_enqueue(tl3d_ctx *ctx, int lane, int slot_src, double scale_src, in
     r->eig_rel = prm->eig_rel;
     // The chain's launch arguments never change (everything per-run sits behind ln.run / ln.state / pinned buffers), so
     // it is captured once per iteration count and replayed: one host call per registration instead of ~25.
-    if (!ln.graph || ln.graph_iters != prm->iters) {
-        if (ln.graph) { (void)hipGraphExecDestroy(ln.graph); ln.graph = nullptr; }
+    int gi = -1;
+    for (int g = 0; g < 4; ++g)
+        if (ln.graphs[g] && ln.graph_iters[g] == prm->iters) gi = g;
+    if (gi < 0) {
+        gi = ln.graph_next;
+        ln.graph_next = (ln.graph_next + 1) & 3;
+        if (ln.graphs[gi]) { (void)hipGraphExecDestroy(ln.graphs[gi]); ln.graphs[gi] = nullptr; }
         hipGraph_t g = nullptr;
         TL3D_HIP(hipStreamBeginCapture(ln.stream, hipStreamCaptureModeThreadLocal));
         hipError_t ce = hipMemcpyAsync(ln.run, ln.run_host, sizeof(IcpRun), hipMemcpyHostToDevice, ln.stream);
@@ -1081,12 +1087,12 @@ int tl3d_icp_enqueue(tl3d_ctx *ctx, int lane, int slot_src, double scale_src, in
             if (g) (void)hipGraphDestroy(g);
             return set_err(TL3D_E_HIP, "ICP graph capture failed: %s", hipGetErrorString(ce != hipSuccess ? ce : ee));
         }
-        hipError_t ie = hipGraphInstantiate(&ln.graph, g, nullptr, nullptr, 0);
+        hipError_t ie = hipGraphInstantiate(&ln.graphs[gi], g, nullptr, nullptr, 0);
         (void)hipGraphDestroy(g);
-        if (ie != hipSuccess) { ln.graph = nullptr; return set_err(TL3D_E_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ie)); }
-        ln.graph_iters = prm->iters;
+        if (ie != hipSuccess) { ln.graphs[gi] = nullptr; return set_err(TL3D_E_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ie)); }
+        ln.graph_iters[gi] = prm->iters;
     }
-    TL3D_HIP(hipGraphLaunch(ln.graph, ln.stream));
+    TL3D_HIP(hipGraphLaunch(ln.graphs[gi], ln.stream));
     TL3D_HIP(hipEventRecord(ln.ev_done, ln.stream));
     ln.busy = true;
     ln.src_slot = slot_src;

@@ -182,8 +182,11 @@ struct tl3d_ctx {
         tl3d::IcpState *host;    // pinned: initial state in, final state out
         tl3d::IcpRun *run;       // device descriptor of the current run
         tl3d::IcpRun *run_host;  // pinned
-        hipGraphExec_t graph;    // captured chain: descriptor + state upload, ticket re-arm, (iters+1) iteration kernels, state download
-        int graph_iters;
+        // captured chains: descriptor + state upload, ticket re-arm, (iters+1) iteration kernels, state download -- one per
+        // iteration count used lately (a coarse-to-fine caller alternates between two or three)
+        hipGraphExec_t graphs[4];
+        int graph_iters[4];
+        int graph_next;          // slot the next new iteration count replaces
         bool busy;               // a run was enqueued and not collected yet
         hipEvent_t ev_done;      // recorded on the lane's stream behind the run: writers of the slots it reads wait on it
         int src_slot, tgt_slot;  // the run reads slots[src].depth and slots[tgt].nmap

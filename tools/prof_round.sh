@@ -16,6 +16,9 @@ rm -rf "$OUT"; mkdir -p "$OUT"
 echo "[prof] kernel trace of: python3 bench.py --no-cpu-baseline --no-rows"
 timeout -k 5 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --no-cpu-baseline --no-rows > "$OUT/bench_trace.log" 2>&1
 echo "rc=$?"
+echo "[prof] kernel trace of the per-row measurements: python3 bench.py --no-cpu-baseline --steps 1 --warmup 1 (rows on)"
+timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_rows" -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 1 > "$OUT/bench_trace_rows.log" 2>&1
+echo "rc=$?"
 PMC=(--no-cpu-baseline --no-rows --steps 1 --warmup 0 --frames-per-step 32 --resident-frames 32)
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM SQ_WAVES" "GRBM_GUI_ACTIVE TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TA_TOTAL_WAVEFRONTS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"; do

@@ -32,6 +32,17 @@ for f in glob.glob(os.path.join(out, "bench_trace.log")):
             print("== bench line of the traced run ==")
             print(line.strip())
 
+print("== kernel stats of the per-row run (registration in the loop, centroid channel, back-projection, extraction, filter) ==")
+for r in rows("trace_rows/**/*kernel_stats.csv"):
+    if "tl3d" in r.get("Name", ""):
+        print(f"{r.get('Name','')[:72]:72s} calls={r.get('Calls'):>6s} avg_ns={float(r.get('AverageNs',0)):11.1f} "
+              f"min={r.get('MinNs')} max={r.get('MaxNs')} pct={r.get('Percentage')}")
+for f in glob.glob(os.path.join(out, "bench_trace_rows.log")):
+    for line in open(f):
+        if line.startswith("{"):
+            print("== rows of that run ==")
+            print(json.dumps(json.loads(line).get("rows")))
+
 agg = defaultdict(lambda: defaultdict(float))
 cnt = defaultdict(lambda: defaultdict(int))
 for r in rows("pmc_*/**/*counter_collection.csv"):
