@@ -119,8 +119,9 @@ __global__ __launch_bounds__(256) void bp_fused_kernel(Cam cam, BpArgs a, PoseD 
             dval[j] = depth[pix];
             col[j] = 0u;
             if (WRITE && bgr) {
-                const uint8_t *px = bgr + 3 * pix;
-                col[j] = (unsigned)px[2] | ((unsigned)px[1] << 8) | ((unsigned)px[0] << 16);           // r | g << 8 | b << 16
+                unsigned w;                                // the pixel's b, g, r bytes in one unaligned load (frame buffers have 16 B of slack)
+                __builtin_memcpy(&w, bgr + 3 * pix, 4);
+                col[j] = ((w >> 16) & 0xffu) | (w & 0xff00u) | ((w & 0xffu) << 16);                      // r | g << 8 | b << 16
             }
             u += 256;
             while (u >= a.Ws) { u -= a.Ws; ++v; }

@@ -44,71 +44,98 @@ __device__ __forceinline__ CenAdd centroid_key(const Grid &g, const float p[3], 
     return o;
 }
 
-__device__ __forceinline__ unsigned long long shfl_up_u64(unsigned long long v, int d) {
-    const unsigned lo = __shfl_up((unsigned)(v & 0xffffffffull), d), hi = __shfl_up((unsigned)(v >> 32), d);
-    return ((unsigned long long)hi << 32) | lo;
-}
-__device__ __forceinline__ unsigned long long shfl_down_u64(unsigned long long v, int d) {
-    const unsigned lo = __shfl_down((unsigned)(v & 0xffffffffull), d), hi = __shfl_down((unsigned)(v >> 32), d);
-    return ((unsigned long long)hi << 32) | lo;
-}
-
 // Neighbouring pixels of an image row usually land in the same voxel (a 5 mm voxel spans ~8 pixels at 1 m), so a wave
-// first sums each run of adjacent lanes with equal record index (segmented inclusive scan: 6 shuffle steps) and only the
-// last lane of a run issues the four 64-bit atomics.  Integer sums: the grid is the same bit for bit, with ~4-8x fewer
-// atomics.  Every lane of the wave must call this (the shuffles need a full EXEC mask).
+// first sums each run of adjacent lanes with equal record index and only the last lane of a run goes on (to the LDS table
+// or to the grid).  Integer sums: the grid is the same bit for bit, with ~4-8x fewer atomics.
+// The scan works inside rows of 16 lanes with DPP row shifts (plain vector-ALU moves): a wave-wide scan through
+// ds_bpermute shuffles cost ~2 us per call -- 54 dependent LDS round trips -- which was 16 of the 45 us of a stride-1 frame;
+// a run that crosses a row boundary is simply two runs.  Payload packed into five dwords for the scan (64 lanes x 4095 < 2^18,
+// counts < 2^7, colour sums < 2^14).  Every lane of the wave must call this (DPP reads need the neighbours' registers live).
+template <int N> __device__ __forceinline__ unsigned dpp_row_shr(unsigned v) {      // lane i of a 16-lane row <- lane i - N (0 beyond the row)
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + N, 0xF, 0xF, true);
+}
+template <int N> __device__ __forceinline__ unsigned dpp_row_shl(unsigned v) {      // lane i <- lane i + N (0 beyond the row)
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x100 + N, 0xF, 0xF, true);
+}
 __device__ __forceinline__ bool centroid_reduce_runs(CenAdd &k) {
-    const int lane = threadIdx.x & 63;
-    const unsigned long long prev_rec = shfl_up_u64(k.rec, 1), next_rec = shfl_down_u64(k.rec, 1);   // all lanes, no short-circuit
-    const bool head = (lane == 0) | (prev_rec != k.rec);
-    int start = head ? lane : 0;                                  // first lane of my run = max of head positions so far
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(start, d);
-        if (lane >= d) start = max(start, o);
+    const int li = threadIdx.x & 15;                                // lane within its row
+    const unsigned rlo = (unsigned)(k.rec & 0xffffffffull), rhi = (unsigned)(k.rec >> 32);
+    // (every DPP read sits in uniform control flow: a read from a lane that a branch has switched off returns 0)
+    const unsigned plo = dpp_row_shr<1>(rlo), phi = dpp_row_shr<1>(rhi), nlo = dpp_row_shl<1>(rlo), nhi = dpp_row_shl<1>(rhi);
+    const bool same_prev = (li != 0) & (plo == rlo) & (phi == rhi);
+    const bool same_next = (li != 15) & (nlo == rlo) & (nhi == rhi);
+    unsigned start = same_prev ? 0u : (unsigned)li;                 // first lane of my run = max of the head positions so far
+    {
+        unsigned o;
+        o = dpp_row_shr<1>(start); start = max(start, o);
+        o = dpp_row_shr<2>(start); start = max(start, o);
+        o = dpp_row_shr<4>(start); start = max(start, o);
+        o = dpp_row_shr<8>(start); start = max(start, o);
     }
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const unsigned long long oa = shfl_up_u64(k.a, d), ob = shfl_up_u64(k.b, d), oc = shfl_up_u64(k.c, d), od = shfl_up_u64(k.d, d);
-        if (lane - d >= start) { k.a += oa; k.b += ob; k.c += oc; k.d += od; }
+    unsigned w0 = (unsigned)(k.a & 0xffffffffull), w1 = (unsigned)(k.a >> 32), w2 = (unsigned)(k.b & 0xffffffffull);
+    unsigned w3 = (unsigned)(k.b >> 32) | ((unsigned)(k.c & 0xffffffffull) << 7);           // n | r << 7
+    unsigned w4 = (unsigned)(k.c >> 32) | ((unsigned)k.d << 14);                             // g | b << 14
+#define CEN_SCAN_STEP(N_)                                                                             \
+    {                                                                                                 \
+        const unsigned o0 = dpp_row_shr<N_>(w0), o1 = dpp_row_shr<N_>(w1), o2 = dpp_row_shr<N_>(w2);   \
+        const unsigned o3 = dpp_row_shr<N_>(w3), o4 = dpp_row_shr<N_>(w4);                             \
+        if ((unsigned)li >= start + N_) { w0 += o0; w1 += o1; w2 += o2; w3 += o3; w4 += o4; }          \
     }
-    const bool tail = (lane == 63) | (next_rec != k.rec);
-    return tail && k.rec != ~0ull;                                // this lane now carries its run's sums
+    CEN_SCAN_STEP(1)
+    CEN_SCAN_STEP(2)
+    CEN_SCAN_STEP(4)
+    CEN_SCAN_STEP(8)
+#undef CEN_SCAN_STEP
+    k.a = (unsigned long long)w0 | ((unsigned long long)w1 << 32);
+    k.b = (unsigned long long)w2 | ((unsigned long long)(w3 & 0x7fu) << 32);
+    k.c = (unsigned long long)(w3 >> 7) | ((unsigned long long)(w4 & 0x3fffu) << 32);
+    k.d = (unsigned long long)(w4 >> 14);
+    return !same_next && k.rec != ~0ull;                            // this lane now carries its run's sums
 }
 
-__device__ __forceinline__ void centroid_commit_runs(CenAdd k, unsigned long long *__restrict__ grid) {
-    if (centroid_reduce_runs(k)) {
-        unsigned long long *rec = grid + 4 * k.rec;
-        atomicAdd(rec + 0, k.a);
-        atomicAdd(rec + 1, k.b);
-        atomicAdd(rec + 2, k.c);
-        atomicAdd(rec + 3, k.d);
+// Tails of a wave straight to the grid.  The L2's atomic units are bound by REQUESTS (an 8-B add costs a 64-B request) and
+// lanes that add to consecutive words in one instruction share one: the tails are listed in LDS and lanes 4j .. 4j+3 add
+// the four words of tail j's record.  stage: this wave's [64][5] words.
+__device__ __forceinline__ void centroid_commit_runs(CenAdd k, unsigned long long *__restrict__ grid, unsigned long long (*stage)[5]) {
+    const bool tail = centroid_reduce_runs(k);
+    const int lane = threadIdx.x & 63;
+    const unsigned long long m = __ballot(tail);
+    if (tail) {
+        unsigned long long *e = stage[__popcll(m & ((1ull << lane) - 1ull))];
+        e[0] = k.rec; e[1] = k.a; e[2] = k.b; e[3] = k.c; e[4] = k.d;
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int n4 = 4 * (int)__popcll(m);
+    for (int i = lane; i < n4; i += 64) atomicAdd(grid + 4 * stage[i >> 2][0] + (i & 3), stage[i >> 2][1 + (i & 3)]);
 }
 
 // LDS table of the per-frame kernel: open addressing, 1024 slots for the at most 1024 samples of a 32 x 32 tile (never more
 // distinct keys than slots, so every probe sequence ends); key = record index + 1 (0 = empty), four 64-bit sums per slot.
 // Dense sampling only (stride 1 and 2: 74 / 18 pixels per 5 mm voxel at 1 m); from stride 3 on neighbouring samples
 // rarely share a voxel and the points go straight to the grid (centroid_direct_kernel).
-constexpr int CEN_TW = 32, CEN_TH = 32, CEN_SLOTS = 1024;
+constexpr int CEN_TW = 32, CEN_TH = 32;      // (tiles of 32 x 8 / 32 x 16 samples: the same time within 2 us)
 
+// xf / yf: the context's tables of (u - cx) / fx and (v - cy) / fy (the same IEEE quotients bp_pixel computes, without the
+// two fp64 divisions); colour: the pixel's three bytes in one unaligned 4-byte load (frame buffers have 16 B of slack)
 __device__ __forceinline__ CenAdd centroid_sample(const Cam &cam, const Grid &g, const BpArgs &a, const PoseD &p, const float *__restrict__ depth,
-                                                  const uint8_t *__restrict__ bgr, int us, int vs, bool &valid) {
+                                                  const uint8_t *__restrict__ bgr, const double *__restrict__ xf, const double *__restrict__ yf,
+                                                  int us, int vs, bool &valid) {
     CenAdd k;
     k.rec = ~0ull;
     k.a = k.b = k.c = k.d = 0;
     valid = false;
     if (us < a.Ws && vs < a.Hs) {
         const int u = us * a.sub, v = vs * a.sub;
+        const size_t pix = (size_t)v * cam.W + u;
+        const float d32 = depth[pix];
+        unsigned w = 0u;
+        if (bgr) __builtin_memcpy(&w, bgr + 3 * pix, 4);
         float pt[3];
-        if (bp_pixel(cam, a, p, depth, u, v, pt)) {
+        if (bp_point_f(a, p, d32, xf[u], yf[v], pt)) {
             valid = true;
-            unsigned r8 = 0, g8 = 0, b8 = 0;
-            if (bgr) {
-                const uint8_t *px = bgr + 3 * ((size_t)v * cam.W + u);
-                b8 = px[0]; g8 = px[1]; r8 = px[2];
-            }
-            k = centroid_key(g, pt, r8, g8, b8);
+            k = centroid_key(g, pt, (w >> 16) & 0xffu, (w >> 8) & 0xffu, w & 0xffu);       // bytes b, g, r
         }
     }
     return k;
@@ -132,9 +159,12 @@ __device__ __forceinline__ void centroid_stats(int nvalid_thread, int nkept_thre
     }
 }
 
+template <int VAR>
 __global__ __launch_bounds__(256) void centroid_frame_kernel(Cam cam, Grid g, BpArgs a, PoseD p, const float *__restrict__ depth,
-                                                             const uint8_t *__restrict__ bgr, unsigned long long *__restrict__ grid,
+                                                             const uint8_t *__restrict__ bgr, const double *__restrict__ xf,
+                                                             const double *__restrict__ yf, unsigned long long *__restrict__ grid,
                                                              unsigned long long *__restrict__ counters, int tiles_x) {
+    constexpr int CEN_SLOTS = CEN_TW * CEN_TH;
     __shared__ unsigned long long s_key[CEN_SLOTS];
     __shared__ unsigned long long s_val[CEN_SLOTS][4];
     for (int h = threadIdx.x; h < CEN_SLOTS; h += 256) {
@@ -151,9 +181,10 @@ __global__ __launch_bounds__(256) void centroid_frame_kernel(Cam cam, Grid g, Bp
     for (int r = 0; r < CEN_TH / 8; ++r) {
         const int vs = ty * CEN_TH + r * 8 + (threadIdx.x >> 5);
         bool valid;
-        CenAdd k = centroid_sample(cam, g, a, p, depth, bgr, us, vs, valid);
+        CenAdd k = centroid_sample(cam, g, a, p, depth, VAR == 4 ? nullptr : bgr, xf, yf, us, vs, valid);
         nvalid += valid ? 1 : 0;
         nkept += (k.rec != ~0ull) ? 1 : 0;
+        if (VAR == 3) { if (k.rec == 12345ull) nkept += (int)k.a; continue; }      // timing ablation: samples only
         if (centroid_reduce_runs(k)) {                            // one lane per run of equal voxels: into the LDS table
             const unsigned long long key = k.rec + 1ull;
             unsigned h = (unsigned)((k.rec * 0x9E3779B97F4A7C15ull) >> 54) & (CEN_SLOTS - 1);
@@ -169,29 +200,44 @@ __global__ __launch_bounds__(256) void centroid_frame_kernel(Cam cam, Grid g, Bp
         }
     }
     centroid_stats(nvalid, nkept, counters);                      // (its barriers also complete the table)
-    for (int h = threadIdx.x; h < CEN_SLOTS; h += 256) {          // one set of grid atomics per distinct voxel of the tile
-        const unsigned long long key = s_key[h];
-        if (key != 0ull) {
-            unsigned long long *rec = grid + 4 * (key - 1ull);
-            atomicAdd(rec + 0, s_val[h][0]);
-            atomicAdd(rec + 1, s_val[h][1]);
-            atomicAdd(rec + 2, s_val[h][2]);
-            atomicAdd(rec + 3, s_val[h][3]);
-        }
+    // One set of grid atomics per distinct voxel of the tile.  The L2's atomic units are bound by REQUESTS, not bytes (an 8-B
+    // add costs a 64-B request: 1.2 M of them per 1080p frame at stride 2 were 23 of the kernel's 36 us), and lanes that add to
+    // consecutive words in one instruction share a request: so the used slots are listed first and lanes 4k .. 4k+3 add the
+    // four words of one record (32 B, one request instead of four).
+    __shared__ unsigned s_used[CEN_SLOTS];
+    __shared__ unsigned s_nused;
+    if (threadIdx.x == 0) s_nused = 0u;
+    __syncthreads();
+    for (int h = threadIdx.x; h < CEN_SLOTS; h += 256) {
+        const bool used = s_key[h] != 0ull;
+        const unsigned long long m = __ballot(used);
+        unsigned base = 0u;
+        if ((threadIdx.x & 63) == 0 && m) base = atomicAdd(&s_nused, (unsigned)__popcll(m));
+        base = __shfl(base, 0);
+        if (used) s_used[base + (unsigned)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull))] = (unsigned)h;
+    }
+    __syncthreads();
+    if (VAR == 2) return;                                         // timing ablation: no grid atomics
+    const unsigned n4 = 4u * s_nused;
+    for (unsigned i = threadIdx.x; i < n4; i += 256) {
+        const unsigned h = s_used[i >> 2], c = i & 3u;
+        atomicAdd(grid + 4 * (s_key[h] - 1ull) + c, s_val[h][c]);
     }
 }
 
 // sparse sampling (stride >= 3): one thread per sample in row-major order, runs combined in the wave, straight to the grid
 __global__ __launch_bounds__(256) void centroid_direct_kernel(Cam cam, Grid g, BpArgs a, PoseD p, const float *__restrict__ depth,
-                                                              const uint8_t *__restrict__ bgr, unsigned long long *__restrict__ grid,
+                                                              const uint8_t *__restrict__ bgr, const double *__restrict__ xf,
+                                                              const double *__restrict__ yf, unsigned long long *__restrict__ grid,
                                                               unsigned long long *__restrict__ counters) {
     const long long s = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long ns = (long long)a.Ws * a.Hs;
     const int vs = (int)(s / a.Ws), us = (int)(s - (long long)vs * a.Ws);
     bool valid;
-    CenAdd k = centroid_sample(cam, g, a, p, depth, bgr, s < ns ? us : a.Ws, vs, valid);
+    CenAdd k = centroid_sample(cam, g, a, p, depth, bgr, xf, yf, s < ns ? us : a.Ws, vs, valid);
     centroid_stats(valid ? 1 : 0, (k.rec != ~0ull) ? 1 : 0, counters);
-    centroid_commit_runs(k, grid);
+    __shared__ unsigned long long s_stage[4][64][5];
+    centroid_commit_runs(k, grid, s_stage[threadIdx.x >> 6]);
 }
 
 __global__ __launch_bounds__(256) void centroid_points_kernel(Grid g, const float *__restrict__ xyz, const uint8_t *__restrict__ rgb,
@@ -208,7 +254,8 @@ __global__ __launch_bounds__(256) void centroid_points_kernel(Grid g, const floa
         k = centroid_key(g, pt, rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]);
     }
     centroid_stats(valid ? 1 : 0, (k.rec != ~0ull) ? 1 : 0, counters);
-    centroid_commit_runs(k, grid);
+    __shared__ unsigned long long s_stage[4][64][5];
+    centroid_commit_runs(k, grid, s_stage[threadIdx.x >> 6]);
 }
 
 // per-block min/max of a point list -> slab[block][6]
@@ -259,14 +306,21 @@ __global__ __launch_bounds__(256) void add_u64_kernel(ulonglong2 *__restrict__ d
 }
 
 int launch_centroid_frame(hipStream_t s, const Cam &cam, const Grid &g, const BpArgs &a, const PoseD &p, const float *depth,
-                          const uint8_t *bgr, unsigned long long *grid, unsigned long long *counters) {
+                          const uint8_t *bgr, const double *xf, const double *yf, unsigned long long *grid, unsigned long long *counters) {
     if (a.sub >= 3) {
         const long long ns = (long long)a.Ws * a.Hs;
-        hipLaunchKernelGGL(centroid_direct_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, s, cam, g, a, p, depth, bgr, grid, counters);
+        hipLaunchKernelGGL(centroid_direct_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, s, cam, g, a, p, depth, bgr, xf, yf, grid, counters);
     } else {
+        // TL3D_CEN_VARIANT: timing ablations only (2: no grid atomics, 3: samples only, 4: no colour loads); DESIGN.md 7.5
+        static const int var = getenv("TL3D_CEN_VARIANT") ? atoi(getenv("TL3D_CEN_VARIANT")) : 0;
         const int tiles_x = (a.Ws + CEN_TW - 1) / CEN_TW, tiles_y = (a.Hs + CEN_TH - 1) / CEN_TH;
-        hipLaunchKernelGGL(centroid_frame_kernel, dim3((unsigned)tiles_x * (unsigned)tiles_y), dim3(256), 0, s, cam, g, a, p, depth, bgr, grid,
-                           counters, tiles_x);
+        const dim3 gr((unsigned)tiles_x * (unsigned)tiles_y);
+#define CEN_LAUNCH(V_) hipLaunchKernelGGL((centroid_frame_kernel<V_>), gr, dim3(256), 0, s, cam, g, a, p, depth, bgr, xf, yf, grid, counters, tiles_x)
+        if (var == 2) CEN_LAUNCH(2);
+        else if (var == 3) CEN_LAUNCH(3);
+        else if (var == 4) CEN_LAUNCH(4);
+        else CEN_LAUNCH(0);
+#undef CEN_LAUNCH
     }
     TL3D_HIP(hipGetLastError());
     return TL3D_OK;

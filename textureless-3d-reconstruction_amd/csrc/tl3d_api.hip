@@ -330,7 +330,7 @@ int tl3d_create(const tl3d_config *cfg, int device, tl3d_ctx **out) {
         FramePool *pools[4] = {&ctx->pool_depth, &ctx->pool_u16, &ctx->pool_bgr, &ctx->pool_nmap};
         for (int k = 0; k < 4; ++k) {
             FramePool &fp = *pools[k];
-            fp.block = (bytes[k] + 255) & ~(size_t)255;
+            fp.block = (bytes[k] + 16 + 255) & ~(size_t)255;      // 16 B of slack: a pixel's 3 colour bytes are read as one 4-byte word
             fp.remaining = cfg->n_slots;
             fp.max_slabs = (cfg->n_slots + FRAME_SLAB_BLOCKS - 1) / FRAME_SLAB_BLOCKS;
             fp.slabs = (void **)calloc((size_t)fp.max_slabs, sizeof(void *));
@@ -763,7 +763,8 @@ int tl3d_accumulate_centroid(tl3d_ctx *ctx, int slot, const double R[9], const d
     const Slot &s = ctx->slots[slot];
     const PoseD p = make_pose_d(R, t, (flags & TL3D_F_NO_POSE) != 0);
     ctx->grid_epoch++;
-    rc = launch_centroid_frame(ctx->stream, ctx->cam, ctx->grid, a, p, s.depth, s.has_color ? s.bgr : nullptr, ctx->centroid, ctx->d_cen_counters);
+    rc = launch_centroid_frame(ctx->stream, ctx->cam, ctx->grid, a, p, s.depth, s.has_color ? s.bgr : nullptr, ctx->bp_factors, ctx->bp_factors + ctx->cam.W,
+                               ctx->centroid, ctx->d_cen_counters);
     if (rc) return rc;
     ctx->stats.centroid_launches++;
     return TL3D_OK;

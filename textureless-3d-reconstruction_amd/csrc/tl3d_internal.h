@@ -251,7 +251,7 @@ int launch_bp_fused(hipStream_t s, const Cam &cam, const BpArgs &a, const PoseD 
                     unsigned long long *total_out, bool force_dynamic = false);
 // centroid
 int launch_centroid_frame(hipStream_t s, const Cam &cam, const Grid &g, const BpArgs &a, const PoseD &p, const float *depth,
-                          const uint8_t *bgr, unsigned long long *grid, unsigned long long *counters);
+                          const uint8_t *bgr, const double *xf, const double *yf, unsigned long long *grid, unsigned long long *counters);
 int launch_centroid_points(hipStream_t s, const Grid &g, const float *xyz, const uint8_t *rgb, long long n,
                            unsigned long long *grid, unsigned long long *counters);
 int launch_bounds(hipStream_t s, const float *xyz, long long n, float *slab, int nblocks);

@@ -13,6 +13,8 @@ scene, poses = synth.cylinder_scene(ground=True), synth.orbit_poses(n, 1.5, 0.36
 ctx = FusionContext(W, H, cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.min_depth, cfg.max_depth, n_slots=n, grid=None)
 for i, p in enumerate(poses):
     d, c = synth.render(scene, p, W, H, cfg.fx, cfg.fy, cfg.cx, cfg.cy, xp=torch, device=dev)
+    torch.cuda.synchronize()
+    torch.cuda.synchronize()
     ctx.upload(i, d.contiguous(), c.contiguous()); ctx.build_normals(i)
 ctx.sync()
 levels = [tuple(l) for l in cfg.icp_coarse] + [(cfg.icp_iters, cfg.icp_stride, cfg.icp_max_dist)]
