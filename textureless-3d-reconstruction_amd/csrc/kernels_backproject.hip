@@ -50,6 +50,9 @@ __global__ __launch_bounds__(1024) void scan_kernel(const unsigned *__restrict__
 }
 
 // ---- one-launch back-projection -------------------------------------------------------------------------------
+#ifndef TL3D_BP_SLEEP
+#define TL3D_BP_SLEEP 1                        // x 64 cycles between two polls of a granule
+#endif
 #ifndef TL3D_BP_PAD
 #define TL3D_BP_PAD 0                          // diagnostic builds only: unused LDS bytes in front of and behind the block
 #endif
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(256) void bp_fused_kernel(Cam cam, BpArgs a, PoseD 
                         // every spin ends: a bound, and one tile's time-out ends every other tile's wait at once
                         if (++spins > BP_SPIN_LIMIT) { failed = true; break; }
                         if ((spins & 255u) == 0u && __hip_atomic_load(state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) { failed = true; break; }
-                        __builtin_amdgcn_s_sleep(1);
+                        __builtin_amdgcn_s_sleep(TL3D_BP_SLEEP);
                     }
                 }
                 if ((g[k] >> 62) == 2ull && near_pfx == 0xffffffffu) near_pfx = (unsigned)(k * 256 + tid);
