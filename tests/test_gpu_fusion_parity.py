@@ -571,3 +571,34 @@ def test_icp_batch_matches_oracle_and_the_per_level_calls():
     assert got[5]["status"] == 2 and got[5]["n_corr"] == 0 and chained[5]["status"] == 2
     assert np.array_equal(alone["T"], got[2]["T"]) and alone["n_corr"] == got[2]["n_corr"]
     assert np.linalg.norm(got[0]["T"] - ores["T"]) <= 1e-9 and got[0]["iters_run"] == ores["iters_run"] and got[0]["n_src"] == ores["n_src"]
+
+
+def test_centroid_runs_of_every_length_and_the_point_list_path():
+    """Runs of adjacent samples that share a voxel are summed in the wave (inside 16-lane rows) before the LDS table and
+    the grid: voxels of 2 mm ... 40 cm give runs from 1 sample to whole rows (split at row boundaries), invalid pixels cut
+    them, strides 1-4 take the table and the direct kernel; the accumulated grid stays the oracle's bit for bit.  Then the
+    same cloud through tl3d_accumulate_points (the merge_pointclouds seam)."""
+    rng = np.random.default_rng(11)
+    poses, frames = small_scene_frames(n=2, deg=3.0)
+    for voxel, dims in ((0.002, (192, 192, 192)), (0.05, (64, 64, 64)), (0.4, (16, 16, 16))):
+        ctx, orc = make_pair(dims=dims, voxel=voxel, centre=(0.0, -0.2, 0.3), channels=tl3d.CH_CENTROID)
+        with ctx:
+            for i, ((depth, bgr), pose) in enumerate(zip(frames, poses)):
+                depth = depth.copy()
+                depth[rng.random(depth.shape) < 0.07] = 0.0                 # holes break runs at random places
+                ctx.upload(i, depth, bgr)
+                for sub in (1, 2, 3, 4):
+                    ctx.accumulate_centroid(i, pose, subsample=sub)
+                    orc.centroid_accumulate(depth, bgr, pose[0], pose[1], subsample=sub)
+            g = ctx.download_grid(tl3d.CH_CENTROID)
+            st = ctx.stats()
+            assert np.array_equal(g, orc.centroid), voxel
+            assert st["centroid_points"] == orc.n_acc.value and st["centroid_dropped"] == orc.n_drop.value
+            # the point-list path: the same points as an explicit cloud
+            pts, col = ctx.backproject(0, pose=poses[0], subsample=1)
+            ctx.reset()
+            ctx.accumulate_points(pts, col)
+            g_pts = ctx.download_grid(tl3d.CH_CENTROID)
+            ctx.reset()
+            ctx.accumulate_centroid(0, poses[0], subsample=1)
+            assert np.array_equal(g_pts, ctx.download_grid(tl3d.CH_CENTROID)), voxel
