@@ -155,3 +155,7 @@ def test_icp_at_the_headline_resolution_matches_oracle():
             assert dT <= 1e-4 and dT <= 1e-8, (stride, dT)
             assert abs(res["rmse"] - ores["rmse"]) < 1e-9
             assert np.linalg.norm(res["T"] - T_true) < 2e-3, stride
+            # the batched kernel (64 workgroups share this pair at strides 1 and 2, 32 at stride 4)
+            bres = ctx.icp_batch([(0, 1)], [dict(iters=iters, stride=stride, max_dist=0.1)])[0]
+            assert bres["n_src"] == ores["n_src"] and abs(bres["n_corr"] - ores["n_corr"]) <= 2 and bres["iters_run"] == ores["iters_run"]
+            assert np.linalg.norm(bres["T"] - ores["T"]) <= 1e-8, (stride, "batched")

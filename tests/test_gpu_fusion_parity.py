@@ -557,6 +557,8 @@ def test_icp_batch_matches_oracle_and_the_per_level_calls():
             chained.append(res)
         got = ctx.icp_batch(pairs, levels, T_init=T0)
         alone = ctx.icp_batch([pairs[2]], levels)[0]
+        single_wg = ctx.icp_batch([(0, 1)], [dict(iters=6, stride=4, max_dist=0.2)])[0]
+        ref_single = ctx.icp(0, 1, iters=6, stride=4, max_dist=0.2)
         with pytest.raises(tl3d.Tl3dError):
             ctx.icp_batch_collect()                                  # nothing in flight
         onm = orc.normals(frames[1][0])
@@ -568,6 +570,8 @@ def test_icp_batch_matches_oracle_and_the_per_level_calls():
         assert np.linalg.norm(a["T"] - b["T"]) <= 1e-9 and abs(a["n_corr"] - b["n_corr"]) <= 2 and a["n_src"] == b["n_src"]
         # (the sums are added over different trees in the two kernels: a pose entry that rounds to the neighbouring f32 moves rmse by ~1e-9)
         assert a["iters_run"] == b["iters_run"] and a["status"] == b["status"] and abs(a["rmse"] - b["rmse"]) < 1e-8
+    # one workgroup per pair (1 200 samples at stride 4): no waiting side at all
+    assert np.linalg.norm(single_wg["T"] - ref_single["T"]) <= 1e-9 and single_wg["iters_run"] == ref_single["iters_run"]
     assert got[5]["status"] == 2 and got[5]["n_corr"] == 0 and chained[5]["status"] == 2
     assert np.array_equal(alone["T"], got[2]["T"]) and alone["n_corr"] == got[2]["n_corr"]
     assert np.linalg.norm(got[0]["T"] - ores["T"]) <= 1e-9 and got[0]["iters_run"] == ores["iters_run"] and got[0]["n_src"] == ores["n_src"]
