@@ -236,9 +236,15 @@ static int alloc_grid(tl3d_ctx *ctx, const tl3d_config *cfg) {
         ctx->tsdf_batch = nb ? atoi(nb) : 32;
         if (ctx->tsdf_batch < 1) ctx->tsdf_batch = 1;
         if (ctx->tsdf_batch > TL3D_TSDF_MAXBATCH) ctx->tsdf_batch = TL3D_TSDF_MAXBATCH;
-        for (int b = 0; b < 2 * ctx->tsdf_batch; ++b) {
-            if (hipMalloc(&ctx->tsdf_scratch[b], tsdf_scratch_bytes(ctx->cam, g)) != hipSuccess) return set_err(TL3D_E_NOMEM, "TSDF scratch alloc failed");
-            if (hipEventCreateWithFlags(&ctx->ev_prep[b], hipEventDisableTiming) != hipSuccess) return set_err(TL3D_E_HIP, "event create failed");
+        {   // the per-frame scratch of both batches: one allocation (64 of them cost ~6 ms to make and as long to free)
+            const size_t each = (tsdf_scratch_bytes(ctx->cam, g) + 255) & ~(size_t)255;
+            void *slab = nullptr;
+            if (hipMalloc(&slab, each * (size_t)(2 * ctx->tsdf_batch)) != hipSuccess) return set_err(TL3D_E_NOMEM, "TSDF scratch alloc failed");
+            ctx->tsdf_scratch_slab = slab;
+            for (int b = 0; b < 2 * ctx->tsdf_batch; ++b) {
+                ctx->tsdf_scratch[b] = (char *)slab + each * (size_t)b;
+                if (hipEventCreateWithFlags(&ctx->ev_prep[b], hipEventDisableTiming) != hipSuccess) return set_err(TL3D_E_HIP, "event create failed");
+            }
         }
         for (int h = 0; h < 2; ++h)
             if (hipEventCreateWithFlags(&ctx->ev_upd[h], hipEventDisableTiming) != hipSuccess) return set_err(TL3D_E_HIP, "event create failed");
@@ -425,10 +431,9 @@ int tl3d_destroy(tl3d_ctx *ctx) {
     if (ctx->own_centroid && ctx->centroid) (void)hipFree(ctx->centroid);
     for (int q = 0; q < 2; ++q)
         if (ctx->prep_stream[q]) (void)hipStreamSynchronize(ctx->prep_stream[q]);
-    for (int b = 0; b < TL3D_TSDF_NBUF; ++b) {
-        if (ctx->tsdf_scratch[b]) (void)hipFree(ctx->tsdf_scratch[b]);
+    if (ctx->tsdf_scratch_slab) (void)hipFree(ctx->tsdf_scratch_slab);
+    for (int b = 0; b < TL3D_TSDF_NBUF; ++b)
         if (ctx->ev_prep[b]) (void)hipEventDestroy(ctx->ev_prep[b]);
-    }
     for (int q = 0; q < 2; ++q)
         if (ctx->prep_stream[q]) (void)hipStreamDestroy(ctx->prep_stream[q]);
     if (ctx->block_counts) (void)hipFree(ctx->block_counts);

@@ -136,6 +136,7 @@ struct tl3d_ctx {
     hipStream_t prep_stream[2];  // consecutive frames alternate, so two prep chains are in flight
     int n_prep_streams;
     void *tsdf_scratch[TL3D_TSDF_NBUF];   // depth tiles + compact brick list, one per frame of the two batches in flight
+    void *tsdf_scratch_slab;              // the one allocation they are carved from
     hipEvent_t ev_prep[TL3D_TSDF_NBUF];   // prep of the frame using scratch b is done (recorded on its prep stream)
     hipEvent_t ev_upd[2];                 // all updates of the last batch that used half h are done (main stream)
     bool upd_recorded[2];
