@@ -303,11 +303,12 @@ class FusionContext:
         self._icp_batch_n = n
 
     def icp_batch_collect(self):
-        n = self._icp_batch_n
-        res = (abi.IcpResult * n)()
+        n = getattr(self, "_icp_batch_n", 0)
+        res = (abi.IcpResult * max(1, n))()
         abi.check(self._lib.tl3d_icp_batch_collect(self._h, res, n))
+        self._icp_batch_n = 0
         return [dict(T=np.array(r.T).reshape(4, 4), fitness=r.fitness, rmse=r.rmse, n_corr=r.n_corr, n_src=r.n_src,
-                     iters_run=r.iters_run, status=r.status) for r in res]
+                     iters_run=r.iters_run, status=r.status) for r in res[:n]]
 
     def icp_batch(self, pairs, levels, T_init=None, scales=None):
         self.icp_batch_enqueue(pairs, levels, T_init, scales)
