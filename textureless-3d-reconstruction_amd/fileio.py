@@ -208,25 +208,36 @@ def load_data(rgb_folder, depth_folder, verbose: bool = True):
     if verbose:
         print(f"Found {len(files)} RGB images")
     images, depths, names = [], [], []
-    for f in files:
+
+    def one(f):                                        # decode of one pair (PIL's decoders and file reads run outside the interpreter lock)
         img = read_image_bgr(f)
         if img is None:
-            continue
+            return None, None, None
         dfile = DepthImageLoader.find_matching_depth(f.name, depth_path)
         if dfile is None:
-            if verbose:
-                print(f"  Warning: No depth found for {f.name}")
-            continue
+            return img, None, None
         depth = DepthImageLoader.load_depth(dfile)
-        if depth is None:
-            continue
-        if depth.shape[:2] != img.shape[:2]:
+        if depth is not None and depth.shape[:2] != img.shape[:2]:
             depth = resize_bilinear(depth, img.shape[1], img.shape[0])
-        images.append(img)
-        depths.append(depth)
-        names.append(f.name)
-        if verbose:
-            print(f"  Loaded: {f.name} with depth")
+        return img, dfile, depth
+
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(16, max(1, usable_cpus()))) as pool:
+        decoded = pool.map(one, files)                 # results in file order: the messages and lists are the serial loop's
+        for f, (img, dfile, depth) in zip(files, decoded):
+            if img is None:
+                continue
+            if dfile is None:
+                if verbose:
+                    print(f"  Warning: No depth found for {f.name}")
+                continue
+            if depth is None:
+                continue
+            images.append(img)
+            depths.append(depth)
+            names.append(f.name)
+            if verbose:
+                print(f"  Loaded: {f.name} with depth")
     if verbose:
         print(f"Loaded {len(images)} image-depth pairs")
     return images, depths, names
