@@ -337,7 +337,7 @@ class FramePrefetcher:
             slot = i % self.ctx.n_slots
             self.ctx.upload_async(slot, depth, bgr)
             in_flight.append(i)
-            while len(in_flight) > max(1, S - 2):      # keep most of the ring for decoders
+            while len(in_flight) > 2:                  # an upload takes ~1 ms, a decode 10-30: the ring belongs to the decoders
                 self.ctx.slot_wait(in_flight.popleft() % self.ctx.n_slots)
             yield i, slot
         while in_flight:
