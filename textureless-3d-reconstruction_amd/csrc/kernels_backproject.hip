@@ -172,7 +172,12 @@ __global__ __launch_bounds__(256) void bp_fused_kernel(Cam cam, BpArgs a, PoseD 
                 if (mine >= 0) {
                     unsigned spins = 0;
                     for (;;) {
-                        g[k] = __hip_atomic_load(gran + mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        // an agent-scope load is served by this XCD's L2, which may go on returning the copy it fetched before
+                        // the predecessor (on another XCD) published -- seen in the batched ICP kernel, for seconds, on an otherwise
+                        // quiet chip.  After a few misses the poll becomes a read-modify-write (add of zero),
+                        // which executes at the memory side and always returns the current word.
+                        g[k] = spins < 16u ? __hip_atomic_load(gran + mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                           : __hip_atomic_fetch_add(gran + mine, a.zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if ((g[k] >> 62) != 0ull) break;
                         // every spin ends: a bound, and one tile's time-out ends every other tile's wait at once
                         if (++spins > BP_SPIN_LIMIT) { failed = true; break; }

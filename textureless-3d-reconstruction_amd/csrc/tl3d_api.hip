@@ -596,6 +596,7 @@ static int make_bp_args(tl3d_ctx *ctx, double scale, uint32_t flags, int subsamp
     a->scale = scale;
     a->min_d = min_d;
     a->max_d = max_d;
+    a->zero = 0ull;
     return TL3D_OK;
 }
 

@@ -38,6 +38,7 @@ struct BpArgs {                  // back-projection arguments common to count / 
     int sub, Ws, Hs;             // stride and subsampled extent (ceil)
     unsigned flags;
     double scale, min_d, max_d;
+    unsigned long long zero;     // 0 the compiler cannot see: fetch_add(p, zero) stays a read-modify-write (a fresh read, see bp look-back)
 };
 
 // frustum side planes for brick culling: inside iff nx*x + nz*z >= -rad (left/right), ny*y + nz*z >= -rad
