@@ -217,6 +217,13 @@ int tl3d_icp_enqueue(tl3d_ctx *ctx, int lane, int slot_src, double scale_src, in
                      const tl3d_icp_params *prm);
 int tl3d_icp_collect(tl3d_ctx *ctx, int lane, tl3d_icp_result *out);
 
+/* a2 (host side of the decode pipeline; no GPU call): the decode workers of a host copy image rows into pinned staging
+ * buffers without holding their interpreter's lock (a foreign call releases it).  rows = `height` pointers to image rows as an
+ * image library keeps them: R,G,B,X 4-byte pixels -> packed B,G,R (what cv2.imread hands the reference, D2R:454), or rows
+ * of row_bytes bytes copied as they are (16-bit depth PNGs, D2R:86-90). */
+int tl3d_host_pack_bgr_rows(uint8_t *dst, const uint8_t *const *rows, int height, int width);
+int tl3d_host_copy_rows(uint8_t *dst, const uint8_t *const *rows, int height, size_t row_bytes);
+
 /* a10, batched: n_pairs independent registrations, each through ALL of `levels` (coarse to fine: a level starts from the
  * pose the previous one ended with; a pair stops early when a level fails or ends with fewer than 8 correspondences, as
  * the per-level calls above are used by a host) in ONE kernel launch: no host round trip and no launch per iteration.

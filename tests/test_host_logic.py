@@ -270,3 +270,29 @@ def test_exr_depth_reader(tmp_path, capsys):
     assert "compression 4 is not supported" in capsys.readouterr().out
     (tmp_path / "junk.exr").write_bytes(b"not an exr")
     assert fileio.DepthImageLoader.load_depth(tmp_path / "junk.exr") is None
+
+
+def test_decode_bgr_into_equals_the_cv2_imread_contract(tmp_path, monkeypatch):
+    """fileio.decode_bgr_into (the prefetcher's decode: image rows copied by tl3d_host_pack_bgr_rows without the interpreter
+    lock) == read_image_bgr (uint8 BGR, alpha dropped, grey replicated: what cv2.imread hands the reference, D2R:454), through
+    PIL's row pointers and through the tobytes() fall-back."""
+    from PIL import Image
+    from tl3d import fileio
+    rng = np.random.default_rng(3)
+    h, w = 37, 53
+    rgb = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    cases = {"rgb.png": Image.fromarray(rgb), "grey.png": Image.fromarray(rgb[..., 0]),
+             "rgba.png": Image.fromarray(np.dstack([rgb, rng.integers(0, 256, (h, w), dtype=np.uint8)])), "photo.jpg": Image.fromarray(rgb)}
+    for name, im in cases.items():
+        im.save(tmp_path / name)
+    for fallback in (False, True):
+        if fallback:
+            monkeypatch.setattr(fileio, "_pil_row_pointers", lambda *a, **k: None)
+        for name in cases:
+            ref = fileio.read_image_bgr(tmp_path / name)
+            dst = np.zeros((h, w, 3), np.uint8)
+            assert fileio.decode_bgr_into(tmp_path / name, dst) and np.array_equal(dst, ref), (name, fallback)
+    assert np.array_equal(fileio.read_image_bgr(tmp_path / "rgb.png"), rgb[..., ::-1])
+    with pytest.raises(ValueError):
+        fileio.decode_bgr_into(tmp_path / "rgb.png", np.zeros((h + 1, w, 3), np.uint8))
+    assert fileio.decode_bgr_into(tmp_path / "missing.png", np.zeros((h, w, 3), np.uint8)) is False

@@ -1134,6 +1134,31 @@ int tl3d_icp_p2plane(tl3d_ctx *ctx, int slot_src, double scale_src, int slot_tgt
     return tl3d_icp_collect(ctx, 0, out);
 }
 
+// ---- host helpers of the decode pipeline (no device work) -----------------------------------------------------------------
+int tl3d_host_pack_bgr_rows(uint8_t *dst, const uint8_t *const *rows, int height, int width) {
+    REQUIRE(dst && rows && height >= 0 && width >= 0, TL3D_E_INVALID, "bad argument");
+    for (int y = 0; y < height; ++y) {
+        const uint8_t *__restrict__ s = rows[y];
+        uint8_t *__restrict__ d = dst + (size_t)y * width * 3;
+        REQUIRE(s != nullptr, TL3D_E_INVALID, "null row %d", y);
+        for (int x = 0; x < width; ++x) {
+            d[3 * x + 0] = s[4 * x + 2];
+            d[3 * x + 1] = s[4 * x + 1];
+            d[3 * x + 2] = s[4 * x + 0];
+        }
+    }
+    return TL3D_OK;
+}
+
+int tl3d_host_copy_rows(uint8_t *dst, const uint8_t *const *rows, int height, size_t row_bytes) {
+    REQUIRE(dst && rows && height >= 0, TL3D_E_INVALID, "bad argument");
+    for (int y = 0; y < height; ++y) {
+        REQUIRE(rows[y] != nullptr, TL3D_E_INVALID, "null row %d", y);
+        memcpy(dst + (size_t)y * row_bytes, rows[y], row_bytes);
+    }
+    return TL3D_OK;
+}
+
 // ---- batched registration: all pairs, all levels, all iterations in one launch (icp_batch_kernel) ----------------------
 static void icp_batch_free(tl3d_ctx::IcpBatch &b) {
     if (b.pairs) (void)hipFree(b.pairs);

@@ -144,6 +144,60 @@ def read_exr_depth(path) -> np.ndarray:
     return planes[names[0]]
 
 
+def _pil_row_pointers(im, width: int, height: int, pixelsize: int):
+    """Address of PIL's table of row pointers for a loaded image, or None.  im.getim() hands out the library's image
+    struct (the capsule Tk / Qt bindings use); its layout is read defensively -- bands / xsize / ysize / pixelsize /
+    linesize at the offsets of Pillow 11-12 must all agree with what the image says -- and anything else falls back to
+    tobytes().  What it buys: the pixels never pass through a Python bytes object under the interpreter lock."""
+    import ctypes
+    try:
+        cap = im.getim()
+        api = ctypes.pythonapi
+        api.PyCapsule_GetName.restype, api.PyCapsule_GetName.argtypes = ctypes.c_char_p, [ctypes.py_object]
+        api.PyCapsule_GetPointer.restype, api.PyCapsule_GetPointer.argtypes = ctypes.c_void_p, [ctypes.py_object, ctypes.c_char_p]
+        name = api.PyCapsule_GetName(cap)
+        if name != b"Pillow Imaging":
+            return None
+        base = api.PyCapsule_GetPointer(cap, name)
+        if not base:
+            return None
+        ints = (ctypes.c_int32 * 20).from_address(base)
+        xs, ys, px, ls = ints[4], ints[5], ints[18], ints[19]
+        if (xs, ys, px, ls) != (width, height, pixelsize, width * pixelsize):
+            return None
+        rows = ctypes.c_void_p.from_address(base + 48).value
+        return rows or None
+    except Exception:
+        return None
+
+
+def decode_bgr_into(path, dst: np.ndarray) -> bool:
+    """Decode an image file straight into dst (uint8 [H, W, 3], C-contiguous, e.g. pinned staging) in B, G, R order.
+    False if the file cannot be read; ValueError if its size is not dst's."""
+    from PIL import Image
+    h, w = dst.shape[:2]
+    try:
+        with Image.open(str(path)) as im:
+            if im.mode != "RGB":
+                im = im.convert("RGB")
+            else:
+                im.load()                                  # the decoders release the interpreter lock
+            if im.size != (w, h):
+                raise ValueError(f"image {path} is {(im.size[1], im.size[0])}, expected {(h, w)}")
+            rows = _pil_row_pointers(im, w, h, 4)
+            if rows is not None:
+                from . import _cabi as abi
+                abi.check(abi.load().tl3d_host_pack_bgr_rows(dst.ctypes.data, rows, h, w))       # no lock held in here
+            else:
+                data = im.tobytes("raw", "BGR")
+                copy_bytes(dst, data, len(data))
+            return True
+    except ValueError:
+        raise
+    except Exception:
+        return False
+
+
 def _image_bgr_bytes(path):
     """(bytes in B, G, R order, height, width) or None.  The pack to BGR happens inside PIL's raw encoder (2.6 ms per
     1080p frame); np.array(im.convert("RGB")) followed by a [..., ::-1] copy held the interpreter lock for 25 ms."""
@@ -160,11 +214,14 @@ def _image_bgr_bytes(path):
 
 def read_image_bgr(path) -> Optional[np.ndarray]:
     """uint8 [H,W,3] in BGR order, what cv2.imread returns (alpha dropped, grey replicated)."""
-    got = _image_bgr_bytes(path)
-    if got is None:
+    from PIL import Image
+    try:
+        with Image.open(str(path)) as im:
+            w, h = im.size
+        out = np.empty((h, w, 3), np.uint8)
+        return out if decode_bgr_into(path, out) else None
+    except Exception:
         return None
-    b, h, w = got
-    return np.frombuffer(b, np.uint8).reshape(h, w, 3).copy()
 
 
 def copy_bytes(dst: np.ndarray, src, nbytes: int):
@@ -289,14 +346,8 @@ class FramePrefetcher:
         t0 = time.perf_counter()
         h, w = self.ctx.height, self.ctx.width
         bgr = None
-        if self.rgb_files[i] is not None:
-            got = _image_bgr_bytes(self.rgb_files[i])
-            if got is not None:
-                data, ih, iw = got
-                if (ih, iw) != (h, w):
-                    raise ValueError(f"image {self.rgb_files[i]} is {(ih, iw)}, expected {(h, w)}")
-                bgr = self._bgr[b].array
-                copy_bytes(bgr, data, len(data))
+        if self.rgb_files[i] is not None and decode_bgr_into(self.rgb_files[i], self._bgr[b].array):
+            bgr = self._bgr[b].array
         path = Path(self.depth_files[i])
         dst = None
         if path.suffix == ".npy":
@@ -305,6 +356,19 @@ class FramePrefetcher:
                 dst = self._f32[b].array
                 copy_bytes(dst, m, dst.nbytes)
             del m
+        if dst is None and path.suffix == ".png" and self.raw_u16:
+            from PIL import Image
+            try:
+                with Image.open(str(path)) as im:
+                    if im.mode in ("I;16", "I;16L") and im.size == (w, h):
+                        im.load()
+                        rows = _pil_row_pointers(im, w, h, 2)
+                        if rows is not None:
+                            from . import _cabi as abi
+                            dst = self._u16[b].array
+                            abi.check(abi.load().tl3d_host_copy_rows(dst.ctypes.data, rows, h, 2 * w))
+            except Exception:
+                dst = None
         if dst is None:
             d = DepthImageLoader.load_depth(path, raw_u16=self.raw_u16)
             if d is None:
