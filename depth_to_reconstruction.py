@@ -71,8 +71,10 @@ def main(argv=None):
     parser.add_argument("--tsdf-min-weight", type=int, default=0, help="> 0: keep only voxels the TSDF saw this often")
     parser.add_argument("--ascii", action="store_true", help="write the reference's ASCII fallback PLY instead of binary")
     parser.add_argument("--device", type=int, default=0)
-    parser.add_argument("--stream", action="store_true",
-                        help="decode on worker threads into pinned buffers with asynchronous uploads; host RAM never holds the sequence")
+    parser.add_argument("--stream", dest="stream", action="store_true", default=True,
+                        help="(default) decode on worker threads into pinned buffers with asynchronous uploads; host RAM never holds the sequence")
+    parser.add_argument("--no-stream", dest="stream", action="store_false",
+                        help="decode every frame into host memory first, as the reference does (D2R:434-437)")
     parser.add_argument("--gpus", type=int, default=1,
                         help="one process per GPU: frames shard across ranks, the per-GPU grids are summed with one RCCL all-reduce "
                              "(also honoured under torchrun: RANK / WORLD_SIZE in the environment)")
