@@ -12,6 +12,10 @@
 // 38 us -> see DESIGN.md section 7.  No host round trip inside the loop: the host replays one captured hipGraph per run
 // ((iters+1) kernels + the state copies) and reads the state once.  Bytes per iteration and sampled pixel: 4 (source
 // depth) + 16 (target normal+depth gather) = 20 B.
+//
+// Batched form (icp_batch_kernel, tl3d_icp_batch_*): many pairs, each through all its coarse-to-fine levels and all its
+// iterations, in ONE launch; the workgroups that share a pair meet at a per-pair barrier in device memory after every
+// pass.  Same accumulate / solve code as the per-iteration kernel; what the pipeline uses.
 #include "tl3d_internal.h"
 
 namespace tl3d {
