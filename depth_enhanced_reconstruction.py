@@ -87,7 +87,8 @@ def main(argv=None):
         loaded = 0
         for c in cands:
             if c is not None and Path(c).is_dir():
-                loaded = pipeline.load_data(str(inp), str(c))
+                # per-frame clouds are exported from host arrays; otherwise the frames stream from the files to the GPU
+                loaded = (pipeline.load_data if args.per_frame_ply else pipeline.load_data_streaming)(str(inp), str(c))
                 if loaded >= 2:
                     break
         if loaded < 2:
