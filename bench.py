@@ -31,7 +31,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames-per-step", type=int, default=512)
-    ap.add_argument("--resident-frames", type=int, default=32, help="distinct synthetic frames kept in HBM per GPU")
+    ap.add_argument("--resident-frames", type=int, default=512,
+                    help="distinct synthetic frames kept in HBM per GPU (512 = one frame per 0.7 degrees of the orbit, the sequence SURVEY.md 8d names)")
     ap.add_argument("--grid", type=int, default=512)
     ap.add_argument("--voxel", type=float, default=0.005)
     ap.add_argument("--width", type=int, default=1080)
@@ -86,9 +87,10 @@ def main():
     F = args.frames_per_step
     n_res = min(args.resident_frames, F * max(1, args.steps))
     total_frames_rank = F * args.steps
-    deg = 360.0 / max(1, world * n_res)
+    # the orbit is divided by the frames a full run keeps resident (a shorter run renders the first n_res of them)
+    deg = 360.0 / max(1, world * args.resident_frames)
     scene = synth.object_scene(with_room=True)
-    poses = synth.orbit_poses(n_res, 1.0, deg, start_deg=rank * n_res * deg)
+    poses = synth.orbit_poses(n_res, 1.0, deg, start_deg=rank * args.resident_frames * deg)
     want_rows = world == 1 and not args.no_rows
     channels = tl3d.CH_TSDF | (tl3d.CH_CENTROID if (args.centroid or want_rows) else 0)
     spec = tl3d.GridSpec.cube(n, args.voxel, centre=(0.0, -0.1, 0.0), channels=channels)
@@ -203,35 +205,39 @@ def main():
     # ---- roofline of the dominant kernel (tsdf_integrate), rank 0 ----------------------------------------
     depth_bpp = 2.0 if args.depth_format == "u16" else 4.0
 
-    def measure_roofline(c_, steps_):
+    def measure_roofline(c_, steps_, nres_=None, F_=None):
         """Counted algorithmic bytes per launch (a counting pass over the resident frames) and the kernel's own duration
-        (hipEvent pairs around every batch of back-to-back launches, on the launching stream) over `steps_` steps."""
+        (hipEvent pairs around every batch of back-to-back launches, on the launching stream) over `steps_` steps.  A launch
+        may update two consecutive frames (frames_per_sweep = frames / launches): the bytes are what the launch moves."""
+        nres_ = n_res if nres_ is None else nres_
+        F_ = F if F_ is None else F_
         c_.reset_stats()
         c_.set_profile(count_records=True, time_kernels=False)
-        for j in range(n_res):
+        for j in range(nres_):
             c_.integrate(j, poses[j])
         st = c_.stats()
         nl = max(1, st["tsdf_launches"])
+        fps_ = nres_ / nl
         rec_per_launch = (st["tsdf_records_read"] + st["tsdf_records_written"]) / nl
         counted_free = st["tsdf_bricks_free_counted"] / nl
         c_.reset_stats()
         c_.reset()
         c_.set_profile(count_records=False, time_kernels=True)
         for s_ in range(steps_):
-            for j in range(F):
-                c_.integrate((s_ * F + j) % n_res, poses[(s_ * F + j) % n_res])
+            for j in range(F_):
+                c_.integrate((s_ * F_ + j) % nres_, poses[(s_ * F_ + j) % nres_])
         st2 = c_.stats()
         c_.set_profile(False, False)
         c_.reset()
         k_ms = st2["tsdf_kernel_ms"] / max(1, st2["tsdf_kernel_timed"])
         # voxel records read + written (8 B each), one 4-byte counter read + written per free-space brick that was counted
-        # instead of streamed, and the depth frame read once
-        bytes_launch = 8.0 * rec_per_launch + 8.0 * counted_free + depth_bpp * H * W
+        # instead of streamed, and the depth frame(s) of the launch read once
+        bytes_launch = 8.0 * rec_per_launch + 8.0 * counted_free + fps_ * depth_bpp * H * W
         achieved = bytes_launch / (k_ms * 1e-3) / 1e9
         return {"achieved": round(achieved, 1), "frac": round(achieved / 8000.0, 4), "bytes_per_launch": int(bytes_launch),
                 "records_per_launch": int(rec_per_launch), "bricks_visited_per_launch": int(st["tsdf_bricks_visited"] / nl),
                 "free_space_bricks_per_launch": int(st["tsdf_bricks_free"] / nl), "free_space_bricks_counted_per_launch": int(counted_free),
-                "ms_per_launch": round(k_ms, 4)}
+                "ms_per_launch": round(k_ms, 4), "frames_per_sweep": round(fps_, 3), "us_per_frame": round(1e3 * k_ms / fps_, 2)}
 
     roof = None
     if rank == 0:
@@ -247,42 +253,25 @@ def main():
                     tj = json.load(f)
                 # a PMC measurement only speaks for the kernel and input it was taken on
                 if (tj.get("grid") == n and tj.get("width") == W and tj.get("height") == H and tj.get("depth_format", "f32") == args.depth_format
-                        and bool(tj.get("free_space_counters", False)) == counters_on):
+                        and bool(tj.get("free_space_counters", False)) == counters_on
+                        and int(tj.get("frames_per_sweep", 1)) == int(round(m["frames_per_sweep"]))):
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roof = {"bound": "hbm", "kernel": "tsdf_integrate_kernel", "achieved": m["achieved"], "peak": 8000.0,
+        paired = m["frames_per_sweep"] > 1.01
+        roof = {"bound": "hbm", "kernel": "tsdf_pair_kernel" if paired else "tsdf_integrate_kernel", "achieved": m["achieved"], "peak": 8000.0,
                 "unit": "GB/s", "frac": m["frac"], "traffic": traffic,
                 "bytes_per_launch": m["bytes_per_launch"], "records_per_launch": m["records_per_launch"],
                 "dense_sweep_bytes": int(16.0 * n ** 3 + 4.0 * H * W), "bricks_visited_per_launch": m["bricks_visited_per_launch"],
                 "free_space_bricks_per_launch": m["free_space_bricks_per_launch"],
                 "free_space_bricks_counted_per_launch": m["free_space_bricks_counted_per_launch"],
-                "ms_per_launch": m["ms_per_launch"], "ms_per_frame_all_kernels": round(region_ms, 4),
-                "launches": launches, "frames_per_sweep": 1}
-        if counters_on and world == 1 and args.depth_format == "f32":
-            # the same frames in the round-1 formulation (free-space bricks streamed: 8 KB of records per brick and frame):
-            # more bytes, moved faster per byte, more time per frame -- both are reported
-            os.environ["TL3D_FREE_COUNTERS"] = "0"
-            try:
-                ctx_s = tl3d.FusionContext(W, H, cam["fx"], cam["fy"], cam["cx"], cam["cy"], min_depth=0.1, max_depth=50.0, n_slots=n_res,
-                                           grid=tl3d.GridSpec.cube(n, args.voxel, centre=(0.0, -0.1, 0.0), channels=tl3d.CH_TSDF),
-                                           device=local_rank, stream=stream.cuda_stream)
-            finally:
-                del os.environ["TL3D_FREE_COUNTERS"]
-            for i in range(n_res):
-                ctx_s.upload(i, ctx.download_depth(i), None)
-            for j in range(F):                                     # one untimed step: a fresh 1 GiB grid has cold TLBs
-                ctx_s.integrate(j % n_res, poses[j % n_res])
-            ctx_s.reset()
-            ms_ = measure_roofline(ctx_s, max(1, min(args.steps, 4)))
-            ctx_s.set_profile(False, False)
-            tq = time.perf_counter()
-            for j in range(F):
-                ctx_s.integrate(j % n_res, poses[j % n_res])
-            ctx_s.sync()
-            ms_["frames_per_s"] = round(F / (time.perf_counter() - tq), 1)
-            ctx_s.close()
-            roof["free_space_streamed"] = ms_
+                "ms_per_launch": m["ms_per_launch"], "us_per_frame": m["us_per_frame"], "ms_per_frame_all_kernels": round(region_ms, 4),
+                "launches": int(round(launches / m["frames_per_sweep"])), "frames_per_sweep": m["frames_per_sweep"]}
+        if paired:
+            # the same frames, one per launch (F = 1: what the fraction was quoted on before), same context, same buffers
+            ctx.set_tsdf_pairing(False)
+            roof["single_frame_per_sweep"] = measure_roofline(ctx, max(1, min(args.steps, 4)))
+            ctx.set_tsdf_pairing(True)
 
     # ---- CPU baseline: the oracle on the host cores, bounded sample, rank 0 at N=1 only --------------------
     cpu = None

@@ -37,9 +37,13 @@ def test_bench_json_contract():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["achieved"] > 0
     assert d["config"]["depth_format"] == "f32"
     # (per-launch averages are truncated to integers in the JSON: equal up to that)
-    assert abs(r["bytes_per_launch"] - (8 * r["records_per_launch"] + 8 * r["free_space_bricks_counted_per_launch"] + 4 * 270 * 480)) <= 16
-    fs = r["free_space_streamed"]                       # the same frames with free-space bricks streamed (round-1 formulation)
-    assert fs["free_space_bricks_counted_per_launch"] == 0 and fs["bytes_per_launch"] > r["bytes_per_launch"] and fs["ms_per_launch"] > 0
+    fps = r["frames_per_sweep"]                         # a launch updates one frame, or two consecutive overlapping ones
+    assert 1.0 <= fps <= 2.0
+    assert abs(r["bytes_per_launch"] - (8 * r["records_per_launch"] + 8 * r["free_space_bricks_counted_per_launch"] + fps * 4 * 270 * 480)) <= 64
+    assert abs(r["us_per_frame"] - 1e3 * r["ms_per_launch"] / fps) < 0.05
+    if fps > 1.01:
+        one = r["single_frame_per_sweep"]               # the same frames, one per launch
+        assert one["frames_per_sweep"] == 1.0 and one["records_per_launch"] < r["records_per_launch"] < 2 * one["records_per_launch"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert d["value"] > 0 and abs(d["ms_per_step"] - 1e3 * 4 / d["value"]) / d["ms_per_step"] < 0.05
@@ -63,4 +67,4 @@ def test_single_rank_rccl_merge_rehearsal():
     assert d["value"] > 0 and d["config"]["centroid_channel"] is True and d["config"]["depth_format"] == "u16"
     assert d["config"]["grid_merges_in_timed_region"] == 1 and d["rows"] is None
     r = d["roofline"]
-    assert abs(r["bytes_per_launch"] - (8 * r["records_per_launch"] + 8 * r["free_space_bricks_counted_per_launch"] + 2 * 270 * 480)) <= 16
+    assert abs(r["bytes_per_launch"] - (8 * r["records_per_launch"] + 8 * r["free_space_bricks_counted_per_launch"] + r["frames_per_sweep"] * 2 * 270 * 480)) <= 64

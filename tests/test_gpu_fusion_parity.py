@@ -606,3 +606,36 @@ def test_centroid_runs_of_every_length_and_the_point_list_path():
             ctx.reset()
             ctx.accumulate_centroid(0, poses[0], subsample=1)
             assert np.array_equal(g_pts, ctx.download_grid(tl3d.CH_CENTROID)), voxel
+
+
+def test_two_frames_per_launch_give_the_oracle_grid_bit_for_bit():
+    """tl3d_integrate updates two consecutive overlapping frames in one launch (records of the bricks both see are read and
+    written once): 7 frames 1 degree apart -> 3 pair launches + 1 single, grid == oracle == one frame per launch; a jump of 20
+    degrees in the sequence falls back to single launches; 16-bit frames take the same path."""
+    poses, frames = small_scene_frames(n=7, deg=1.0)
+    far_poses, far_frames = small_scene_frames(n=2, deg=20.0)
+    for as_u16 in (False, True):
+        ctx, orc = make_pair(dims=(96, 96, 96), voxel=0.025, centre=(0.0, -0.2, 0.0), n_slots=9, channels=tl3d.CH_TSDF)
+        with ctx:
+            seq = list(zip(frames, poses)) + list(zip(far_frames, far_poses))
+            for i, ((d, c), _) in enumerate(seq):
+                if as_u16:
+                    mm = np.clip(np.round(d * 1000.0), 0, 65535).astype(np.uint16)
+                    ctx.upload(i, mm, None)
+                    seq[i] = ((mm.astype(np.float32) / np.float32(1000.0), c), seq[i][1])
+                else:
+                    ctx.upload(i, d, None)
+            grids, launches = [], []
+            for pairing in (True, False):
+                ctx.reset()
+                ctx.reset_stats()
+                ctx.set_tsdf_pairing(pairing)
+                for i, (_, pose) in enumerate(seq):
+                    ctx.integrate(i, pose)
+                grids.append(ctx.download_grid(tl3d.CH_TSDF))
+                launches.append(ctx.stats()["tsdf_launches"])
+            for (d, _), pose in seq:
+                orc.tsdf_integrate(d, pose[0], pose[1])
+        # (0,1) (2,3) (4,5) pair up; frame 6 and the two far frames are more than 5 degrees from their neighbours
+        assert launches[1] == 9 and launches[0] == 6, launches
+        assert np.array_equal(grids[0], orc.tsdf) and np.array_equal(grids[1], orc.tsdf), as_u16

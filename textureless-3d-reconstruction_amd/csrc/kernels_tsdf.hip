@@ -152,7 +152,8 @@ __device__ __forceinline__ bool sphere_in_view(const Frustum &fr, float x, float
 
 __global__ __launch_bounds__(256) void brick_cull_kernel(Cam cam, Grid g, PoseF pose, Frustum fr, Pyramid py,
                                                          const float4 *__restrict__ tiles, unsigned *__restrict__ list,
-                                                         unsigned *__restrict__ list_counts, unsigned *__restrict__ free_cnt) {
+                                                         unsigned *__restrict__ list_counts, unsigned *__restrict__ free_cnt,
+                                                         unsigned char *__restrict__ cls_map) {
     __shared__ unsigned s_cnt[4][2];
     __shared__ unsigned s_base[2];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -161,8 +162,14 @@ __global__ __launch_bounds__(256) void brick_cull_kernel(Cam cam, Grid g, PoseF 
     const unsigned nbricks = (unsigned)(g.nbx * g.nby * g.nbz);
     int cls = 0;                                                  // 0 skip, 1 mixed, 2 free
     int brick = 0;
+    bool in_grid = false;
     if (cell < ncx * ncy * ncz) {
         const int ccx = cell % ncx, ccy = (cell / ncx) % ncy, ccz = cell / (ncx * ncy);
+        {
+            const int bx0 = ccx * 4 + (lane & 3), by0 = ccy * 4 + ((lane >> 2) & 3), bz0 = ccz * 4 + (lane >> 4);
+            in_grid = bx0 < g.nbx && by0 < g.nby && bz0 < g.nbz;
+            brick = (bz0 * g.nby + by0) * g.nbx + bx0;
+        }
         const float crad = 27.712812f * g.vs * 1.01f;               // half diagonal of a 32^3-voxel cell, +1 %
         const float qx = fmaf((float)(ccx * 32 + 16), g.vs, g.ox), qy = fmaf((float)(ccy * 32 + 16), g.vs, g.oy);
         const float qz = fmaf((float)(ccz * 32 + 16), g.vs, g.oz);
@@ -170,8 +177,7 @@ __global__ __launch_bounds__(256) void brick_cull_kernel(Cam cam, Grid g, PoseF 
         const float ey = pose.r[3] * qx + pose.r[4] * qy + pose.r[5] * qz + pose.t[1];
         const float ez = pose.r[6] * qx + pose.r[7] * qy + pose.r[8] * qz + pose.t[2];
         const int bx = ccx * 4 + (lane & 3), by = ccy * 4 + ((lane >> 2) & 3), bz = ccz * 4 + (lane >> 4);
-        if (sphere_in_view(fr, ex, ey, ez, crad) && bx < g.nbx && by < g.nby && bz < g.nbz) {
-            brick = (bz * g.nby + by) * g.nbx + bx;
+        if (sphere_in_view(fr, ex, ey, ez, crad) && in_grid) {
             const float rad = 6.9282032f * g.vs * 1.01f;             // half diagonal of a brick, +1 %
             const float wx = fmaf((float)(bx * 8 + 4), g.vs, g.ox);
             const float wy = fmaf((float)(by * 8 + 4), g.vs, g.oy);
@@ -234,6 +240,9 @@ __global__ __launch_bounds__(256) void brick_cull_kernel(Cam cam, Grid g, PoseF 
             }
         }
     }
+    // the class of EVERY brick of the grid, for the kernel that updates two frames per visit (it asks whether a brick on one
+    // frame's list is on the other's too)
+    if (in_grid) cls_map[brick] = (unsigned char)cls;
     const unsigned long long mm = __ballot(cls == 1), mf = __ballot(cls == 2);
     if (lane == 0) { s_cnt[wid][0] = (unsigned)__popcll(mm); s_cnt[wid][1] = (unsigned)__popcll(mf); }
     __syncthreads();
@@ -519,6 +528,111 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(Cam cam, Grid g, Po
     }
 }
 
+// Two frames per visit of a brick.  The update is bound by the CU's vector L1: a brick's depth gathers and its record lines
+// queue there one after the other.  The gathers are per frame; the records need not be: a brick that two
+// consecutive frames both see near a surface is read and written ONCE for both (integer sums: the same grid bit for bit).
+// Tasks = frame A's MIXED list, then frame B's; a brick of A's list that is MIXED in B too (B's class map) takes both
+// frames' gathers before its one read-modify-write; a brick of B's list that was on A's is skipped.  MAP 1 / 2 as above.
+template <bool COUNT, int MAP, typename DT>
+__global__ __launch_bounds__(256) void tsdf_pair_kernel(Cam cam, Grid g, PoseF poseA, PoseF poseB, TsdfConst cA, TsdfConst cB,
+                                                        const DT *__restrict__ depthA, const DT *__restrict__ depthB,
+                                                        const unsigned *__restrict__ listA, const unsigned *__restrict__ countsA,
+                                                        const unsigned char *__restrict__ clsA,
+                                                        const unsigned *__restrict__ listB, const unsigned *__restrict__ countsB,
+                                                        const unsigned char *__restrict__ clsB,
+                                                        int2 *__restrict__ grid, unsigned long long *__restrict__ counters) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const unsigned nbricks = (unsigned)(g.nbx * g.nby * g.nbz);
+    const unsigned nA = min(countsA[0], nbricks), nB = min(countsB[0], nbricks);        // clamped: see tsdf_integrate_kernel
+    const unsigned ntask = nA + nB;
+    unsigned nread = 0, nwritten = 0;
+    // blocks that share an XCD (blockIdx % 8) take one contiguous eighth of the tasks: a slab of the volume
+    const bool grouped = XCD_GROUPS > 1 && (gridDim.x % XCD_GROUPS) == 0 && cA.xcd_group != 0;
+    const unsigned ngrp = grouped ? XCD_GROUPS : 1u;
+    const unsigned grp = grouped ? blockIdx.x % XCD_GROUPS : 0u, bi = grouped ? blockIdx.x / XCD_GROUPS : blockIdx.x;
+    // every group takes its eighth of BOTH lists (B's entries are mostly skipped: a group that got only those would idle)
+    const unsigned perA = (nA + ngrp - 1u) / ngrp, perB = (nB + ngrp - 1u) / ngrp;
+    const unsigned a_beg = min(nA, grp * perA), a_len = min(nA, a_beg + perA) - a_beg;
+    const unsigned b_beg = min(nB, grp * perB), b_len = min(nB, b_beg + perB) - b_beg;
+    const unsigned lstep = (gridDim.x / ngrp) * 4u;
+    const int la = lane & 7, lb = lane >> 3;
+    (void)ntask;
+    for (unsigned t = bi * 4u + wid; t < a_len + b_len; t += lstep) {
+        const bool fromA = t < a_len;
+        const unsigned brick = (unsigned)__builtin_amdgcn_readfirstlane((int)(fromA ? listA[a_beg + t] : listB[b_beg + (t - a_len)]));
+        const int other = __builtin_amdgcn_readfirstlane((int)(fromA ? clsB[brick] : clsA[brick]));
+        if (!fromA && other == 1) continue;                          // handled from A's list
+        const bool both = fromA && other == 1;
+        const int bx = (int)(brick % (unsigned)g.nbx), by = (int)((brick / (unsigned)g.nbx) % (unsigned)g.nby), bz = (int)(brick / (unsigned)(g.nbx * g.nby));
+        int2 *__restrict__ recs2 = grid + ((size_t)brick << 9);
+        const int i = bx * 8 + la;
+        const float px = fmaf((float)i + 0.5f, g.vs, g.ox);
+        int qs[8], ws[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { qs[k] = 0; ws[k] = 0; }
+        // both frames' gathers are issued before either frame's values are needed (one wait for 16 instead of two for 8)
+        const bool useA = fromA, useB = fromA ? both : true;         // wave-uniform
+        float zcA[8], dvA[8], zcB[8], dvB[8];
+        bool okA[8], okB[8];
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            if (!(f ? useB : useA)) continue;
+            const PoseF &pose = f ? poseB : poseA;
+            const TsdfConst &c = f ? cB : cA;
+            const DT *__restrict__ depth = f ? depthB : depthA;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int j = by * 8 + (MAP == 1 ? lb : k);
+                const int kk = bz * 8 + (MAP == 1 ? k : lb);
+                const float py = fmaf((float)j + 0.5f, g.vs, g.oy);
+                const float pz = fmaf((float)kk + 0.5f, g.vs, g.oz);
+                const float xc = fmaf(pose.r[0], px, fmaf(pose.r[1], py, fmaf(pose.r[2], pz, pose.t[0])));
+                const float yc = fmaf(pose.r[3], px, fmaf(pose.r[4], py, fmaf(pose.r[5], pz, pose.t[1])));
+                const float z = fmaf(pose.r[6], px, fmaf(pose.r[7], py, fmaf(pose.r[8], pz, pose.t[2])));
+                int pix;
+                const bool ok = tsdf_project(cam, c, xc, yc, z, pix);
+                const float d = ld_depth(depth, (size_t)pix);
+                if (f) { zcB[k] = z; okB[k] = ok; dvB[k] = d; } else { zcA[k] = z; okA[k] = ok; dvA[k] = d; }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            int q;
+            if (useA && tsdf_finish(g, cA, okA[k], dvA[k], zcA[k], q)) { qs[k] += q; ws[k] += 1; }
+            if (useB && tsdf_finish(g, cB, okB[k], dvB[k], zcB[k], q)) { qs[k] += q; ws[k] += 1; }
+        }
+        int2 rec[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (ws[k]) rec[k] = recs2[MAP == 1 ? (k * 64 + lane) : (lb * 64 + k * 8 + la)];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (ws[k]) {
+                rec[k].x += qs[k];
+                rec[k].y += ws[k];
+                recs2[MAP == 1 ? (k * 64 + lane) : (lb * 64 + k * 8 + la)] = rec[k];
+                if (COUNT) { nread += 1; nwritten += 1; }
+            }
+    }
+    if (COUNT) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            nread += __shfl_down(nread, d);
+            nwritten += __shfl_down(nwritten, d);
+        }
+        if (lane == 0) {
+            atomicAdd(counters + 2, (unsigned long long)nread);
+            atomicAdd(counters + 3, (unsigned long long)nwritten);
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            const unsigned fA = min(countsA[1], nbricks - nA), fB = min(countsB[1], nbricks - nB);
+            atomicAdd(counters + 4, (unsigned long long)(nA + fA) + (nB + fB));
+            atomicAdd(counters + 5, (unsigned long long)fA + fB);
+            atomicAdd(counters + 6, (unsigned long long)fA + fB);
+        }
+    }
+}
+
 static Pyramid make_pyramid(const Cam &cam) {
     Pyramid p;
     memset(&p, 0, sizeof(p));
@@ -540,23 +654,25 @@ static size_t pyramid_tiles(const Pyramid &p) { return (size_t)p.off[p.nlev - 1]
 size_t tsdf_scratch_bytes(const Cam &cam, const Grid &g) {
     const Pyramid p = make_pyramid(cam);
     const size_t nbricks = (size_t)g.nbx * g.nby * g.nbz;
-    return 256 + pyramid_tiles(p) * sizeof(float4) + (nbricks + 64) * sizeof(unsigned);
+    return 256 + pyramid_tiles(p) * sizeof(float4) + (nbricks + 64) * sizeof(unsigned) + ((nbricks + 255) & ~(size_t)255);
 }
 
 struct TsdfScratch {
     unsigned *list_counts;       // [0] mixed, [1] free
     float4 *tiles;
     unsigned *list;
+    unsigned char *cls;          // [nbricks] class of every brick (0 skip, 1 mixed, 2 free)
     Pyramid py;
 };
 
-static TsdfScratch carve(const Cam &cam, void *scratch) {
+static TsdfScratch carve(const Cam &cam, const Grid &g, void *scratch) {
     TsdfScratch t;
     t.py = make_pyramid(cam);
-    // scratch layout: [list_counts (256 B)] [tile pyramid] [brick list]
+    // scratch layout: [list_counts (256 B)] [tile pyramid] [brick list] [brick classes]
     t.list_counts = reinterpret_cast<unsigned *>(scratch);
     t.tiles = reinterpret_cast<float4 *>(reinterpret_cast<char *>(scratch) + 256);
     t.list = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(scratch) + 256 + pyramid_tiles(t.py) * sizeof(float4));
+    t.cls = reinterpret_cast<unsigned char *>(t.list + ((size_t)g.nbx * g.nby * g.nbz + 64));
     return t;
 }
 
@@ -577,7 +693,7 @@ static TsdfConst make_const(const Cam &cam, float scale, float mind, float maxd,
 int launch_tsdf_prepare(hipStream_t s, const Cam &cam, const Grid &g, const PoseF &p, const Frustum &fr, const void *depth, bool depth_u16,
                         float scale, float mind, float maxd, void *scratch, unsigned *free_cnt) {
     const TsdfConst c = make_const(cam, scale, mind, maxd);
-    const TsdfScratch t = carve(cam, scratch);
+    const TsdfScratch t = carve(cam, g, scratch);
     const int ntiles = t.py.ntx[0] * t.py.nty[0];
     if (depth_u16)
         hipLaunchKernelGGL(depth_tiles_kernel<uint16_t>, dim3(ntiles < 1024 ? ntiles : 1024), dim3(256), 0, s, cam, c,
@@ -592,7 +708,7 @@ int launch_tsdf_prepare(hipStream_t s, const Cam &cam, const Grid &g, const Pose
     }
     const int ncells = ((g.nbx + 3) / 4) * ((g.nby + 3) / 4) * ((g.nbz + 3) / 4);
     hipLaunchKernelGGL(brick_cull_kernel, dim3((ncells + 3) / 4), dim3(256), 0, s, cam, g, p, fr, t.py, t.tiles, t.list,
-                       t.list_counts, free_cnt);
+                       t.list_counts, free_cnt, t.cls);
     TL3D_HIP(hipGetLastError());
     return TL3D_OK;
 }
@@ -606,10 +722,50 @@ int launch_fold_free(hipStream_t s, const Grid &g, int2 *grid, unsigned *free_cn
     return TL3D_OK;
 }
 
+// which lane map the update of a frame with pose p uses: the grid axis most vertical in the image (largest |R[1][a]|):
+// y -> MAP 2, z -> MAP 1, x -> generic MAP 0
+int tsdf_lane_map(const PoseF &p) {
+    static const int force_map = getenv("TL3D_TSDF_MAP") ? atoi(getenv("TL3D_TSDF_MAP")) : -1;
+    const float ax = fabsf(p.r[3]), ay = fabsf(p.r[4]), az = fabsf(p.r[5]);
+    int map = (ay >= ax && ay >= az) ? 2 : (az >= ax ? 1 : 0);
+    if (force_map >= 0 && force_map <= 2) map = force_map;
+    return map;
+}
+
+// two prepared frames in one launch (callers check tsdf_lane_map(pA) == tsdf_lane_map(pB) != 0, both depth images of one kind,
+// free-space bricks counted)
+int launch_tsdf_update_pair(hipStream_t s, const Cam &cam, const Grid &g, const PoseF &pA, const PoseF &pB, const void *depthA, const void *depthB,
+                            bool depth_u16, float scaleA, float scaleB, float mind, float maxd, int2 *grid, void *scratchA, void *scratchB,
+                            unsigned long long *counters, bool count) {
+    const TsdfConst cA = make_const(cam, scaleA, mind, maxd, true), cB = make_const(cam, scaleB, mind, maxd, true);
+    const TsdfScratch tA = carve(cam, g, scratchA), tB = carve(cam, g, scratchB);
+    const int nbricks = g.nbx * g.nby * g.nbz;
+    static const int max_blk = getenv("TL3D_UPDATE_BLOCKS") ? atoi(getenv("TL3D_UPDATE_BLOCKS")) : 1536;
+    int nblk = (nbricks + 3) / 4;
+    if (nblk > max_blk) nblk = max_blk;
+    const int map = tsdf_lane_map(pA);
+#define TL3D_LAUNCH_PAIR(C_, M_)                                                                                                        \
+    do {                                                                                                                              \
+        if (depth_u16)                                                                                                                \
+            hipLaunchKernelGGL((tsdf_pair_kernel<C_, M_, uint16_t>), dim3(nblk), dim3(256), 0, s, cam, g, pA, pB, cA, cB,              \
+                               static_cast<const uint16_t *>(depthA), static_cast<const uint16_t *>(depthB), tA.list, tA.list_counts,  \
+                               tA.cls, tB.list, tB.list_counts, tB.cls, grid, counters);                                               \
+        else                                                                                                                          \
+            hipLaunchKernelGGL((tsdf_pair_kernel<C_, M_, float>), dim3(nblk), dim3(256), 0, s, cam, g, pA, pB, cA, cB,                 \
+                               static_cast<const float *>(depthA), static_cast<const float *>(depthB), tA.list, tA.list_counts,        \
+                               tA.cls, tB.list, tB.list_counts, tB.cls, grid, counters);                                               \
+    } while (0)
+    if (map == 2) { if (count) TL3D_LAUNCH_PAIR(true, 2); else TL3D_LAUNCH_PAIR(false, 2); }
+    else { if (count) TL3D_LAUNCH_PAIR(true, 1); else TL3D_LAUNCH_PAIR(false, 1); }
+#undef TL3D_LAUNCH_PAIR
+    TL3D_HIP(hipGetLastError());
+    return TL3D_OK;
+}
+
 int launch_tsdf_update(hipStream_t s, const Cam &cam, const Grid &g, const PoseF &p, const void *depth, bool depth_u16, float scale, float mind,
                        float maxd, int2 *grid, void *scratch, unsigned long long *counters, bool count, bool free_counted) {
     const TsdfConst c = make_const(cam, scale, mind, maxd, free_counted);
-    const TsdfScratch t = carve(cam, scratch);
+    const TsdfScratch t = carve(cam, g, scratch);
     const int nbricks = g.nbx * g.nby * g.nbz;
     // 6 workgroups per CU.  The update saturates from 4 per CU upwards; with the update launches batched
     // back to back, 6 measured best (frame period 59.5 us vs 62.3 at 4 and 60.2 at 7): the prep kernels of later frames,
@@ -618,11 +774,7 @@ int launch_tsdf_update(hipStream_t s, const Cam &cam, const Grid &g, const PoseF
     int nblk = (nbricks + 3) / 4;
     if (nblk > max_blk) nblk = max_blk;
     static const int dbg = getenv("TL3D_DEBUG_ONLY") ? atoi(getenv("TL3D_DEBUG_ONLY")) : 0;
-    static const int force_map = getenv("TL3D_TSDF_MAP") ? atoi(getenv("TL3D_TSDF_MAP")) : -1;
-    // the grid axis most vertical in the image (largest |R[1][a]|): y -> MAP 2, z -> MAP 1, x -> generic MAP 0
-    const float ax = fabsf(p.r[3]), ay = fabsf(p.r[4]), az = fabsf(p.r[5]);
-    int map = (ay >= ax && ay >= az) ? 2 : (az >= ax ? 1 : 0);
-    if (force_map >= 0 && force_map <= 2) map = force_map;
+    const int map = tsdf_lane_map(p);
 #define TL3D_LAUNCH_UPD(C_, D_, M_, V_, F_)                                                                                            \
     do {                                                                                                                         \
         if (depth_u16)                                                                                                           \

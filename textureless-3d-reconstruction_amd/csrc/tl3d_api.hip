@@ -232,6 +232,7 @@ static int alloc_grid(tl3d_ctx *ctx, const tl3d_config *cfg) {
             if (hipMemsetAsync(ctx->free_cnt, 0, nbr * sizeof(unsigned), ctx->stream) != hipSuccess) return set_err(TL3D_E_HIP, "memset failed");
         }
         ctx->tsdf_use_u16 = !(getenv("TL3D_U16_GATHER") && atoi(getenv("TL3D_U16_GATHER")) == 0);
+        ctx->tsdf_pairing = !(getenv("TL3D_TSDF_PAIR") && atoi(getenv("TL3D_TSDF_PAIR")) == 0);      // read when the grid is attached
         const char *nb = getenv("TL3D_TSDF_BATCH");
         ctx->tsdf_batch = nb ? atoi(nb) : 32;
         if (ctx->tsdf_batch < 1) ctx->tsdf_batch = 1;
@@ -886,10 +887,32 @@ static int flush_updates(tl3d_ctx *ctx) {
     // between), so the two marker packets are shared by n launches instead of being charged to each
     const int kt = ktimer_begin(ctx);
     int launched = 0;
+    // two consecutive frames share one visit of the bricks both see near a surface (records read and written once for both)
+    // when they use the same lane map and depth kind; TL3D_TSDF_PAIR=0: one frame per sweep
+    const bool pairing = ctx->tsdf_pairing;
+    static const bool plain = !getenv("TL3D_DEBUG_ONLY") && !getenv("TL3D_TSDF_VARIANT");
     for (int k = 0; k < n && rc == TL3D_OK; ++k) {
         const tl3d_ctx::PendingUpdate &u = ctx->pend[k];
         const Slot &us = ctx->slots[u.slot];
         const bool u16 = us.has_u16 && ctx->tsdf_use_u16;
+        if (pairing && plain && ctx->free_cnt != nullptr && k + 1 < n) {
+            const tl3d_ctx::PendingUpdate &v = ctx->pend[k + 1];
+            const Slot &vs = ctx->slots[v.slot];
+            const bool v16 = vs.has_u16 && ctx->tsdf_use_u16;
+            const int map = tsdf_lane_map(u.pose);
+            // worth it only when the two views overlap (otherwise the pair is two singles in one launch): < 5 degrees apart
+            const float tr = u.pose.r[0] * v.pose.r[0] + u.pose.r[1] * v.pose.r[1] + u.pose.r[2] * v.pose.r[2] +
+                             u.pose.r[3] * v.pose.r[3] + u.pose.r[4] * v.pose.r[4] + u.pose.r[5] * v.pose.r[5] +
+                             u.pose.r[6] * v.pose.r[6] + u.pose.r[7] * v.pose.r[7] + u.pose.r[8] * v.pose.r[8];      // trace(Ru Rv^T) = 1 + 2 cos(angle)
+            if (v16 == u16 && map != 0 && map == tsdf_lane_map(v.pose) && tr > 1.0f + 2.0f * 0.9961947f) {
+                rc = launch_tsdf_update_pair(ctx->stream, ctx->cam, ctx->grid, u.pose, v.pose, u16 ? (const void *)us.depth_u16 : (const void *)us.depth,
+                                             v16 ? (const void *)vs.depth_u16 : (const void *)vs.depth, u16, u.scale, v.scale, mind, maxd, ctx->tsdf,
+                                             ctx->tsdf_scratch[u.buf], ctx->tsdf_scratch[v.buf], ctx->d_counters, ctx->count_records);
+                if (rc == TL3D_OK) { ctx->stats.tsdf_launches++; ++launched; }
+                ++k;
+                continue;
+            }
+        }
         rc = launch_tsdf_update(ctx->stream, ctx->cam, ctx->grid, u.pose, u16 ? (const void *)us.depth_u16 : (const void *)us.depth, u16, u.scale, mind, maxd, ctx->tsdf,
                                 ctx->tsdf_scratch[u.buf], ctx->d_counters, ctx->count_records, ctx->free_cnt != nullptr);
         if (rc == TL3D_OK) { ctx->stats.tsdf_launches++; ++launched; }
@@ -1668,6 +1691,13 @@ int tl3d_set_profile(tl3d_ctx *ctx, int count_records, int time_kernels) {
     FLUSH_UPDATES(ctx);
     ctx->count_records = count_records != 0;
     ctx->time_kernels = time_kernels != 0;
+    return TL3D_OK;
+}
+
+int tl3d_set_tsdf_pairing(tl3d_ctx *ctx, int on) {
+    REQUIRE(ctx != nullptr, TL3D_E_INVALID, "null ctx");
+    FLUSH_UPDATES(ctx);
+    ctx->tsdf_pairing = on != 0;
     return TL3D_OK;
 }
 

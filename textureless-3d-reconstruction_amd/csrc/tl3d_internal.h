@@ -138,6 +138,7 @@ struct tl3d_ctx {
     int n_prep_streams;
     void *tsdf_scratch[TL3D_TSDF_NBUF];   // depth tiles + compact brick list, one per frame of the two batches in flight
     void *tsdf_scratch_slab;              // the one allocation they are carved from
+    bool tsdf_pairing;                    // two overlapping consecutive frames share one visit of their common bricks (TL3D_TSDF_PAIR=0: off)
     hipEvent_t ev_prep[TL3D_TSDF_NBUF];   // prep of the frame using scratch b is done (recorded on its prep stream)
     hipEvent_t ev_upd[2];                 // all updates of the last batch that used half h are done (main stream)
     bool upd_recorded[2];
@@ -259,6 +260,10 @@ int launch_centroid_points(hipStream_t s, const Grid &g, const float *xyz, const
 int launch_bounds(hipStream_t s, const float *xyz, long long n, float *slab, int nblocks);
 // tsdf
 size_t tsdf_scratch_bytes(const Cam &cam, const Grid &g);
+int tsdf_lane_map(const PoseF &p);
+int launch_tsdf_update_pair(hipStream_t s, const Cam &cam, const Grid &g, const PoseF &pA, const PoseF &pB, const void *depthA, const void *depthB,
+                            bool depth_u16, float scaleA, float scaleB, float mind, float maxd, int2 *grid, void *scratchA, void *scratchB,
+                            unsigned long long *counters, bool count);
 int launch_tsdf_prepare(hipStream_t s, const Cam &cam, const Grid &g, const PoseF &p, const Frustum &fr, const void *depth, bool depth_u16,
                         float scale, float mind, float maxd, void *scratch, unsigned *free_cnt);
 int launch_tsdf_update(hipStream_t s, const Cam &cam, const Grid &g, const PoseF &p, const void *depth, bool depth_u16, float scale, float mind,

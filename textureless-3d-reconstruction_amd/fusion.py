@@ -404,6 +404,10 @@ class FusionContext:
     def set_profile(self, count_records=False, time_kernels=False):
         abi.check(self._lib.tl3d_set_profile(self._h, int(count_records), int(time_kernels)))
 
+    def set_tsdf_pairing(self, on: bool):
+        """integrate() may update two consecutive overlapping frames per launch (default); off: one frame per launch."""
+        abi.check(self._lib.tl3d_set_tsdf_pairing(self._h, 1 if on else 0))
+
     def stats(self) -> dict:
         s = abi.Stats()
         abi.check(self._lib.tl3d_get_stats(self._h, C.byref(s)))

@@ -3,7 +3,7 @@
 # 1. rocprofv3 --kernel-trace --stats of the default bench command (the roofline numbers must agree with its
 #    average duration for tsdf_integrate_kernel);
 # 2. separate --pmc passes (never combined with tracing; FETCH_SIZE and WRITE_SIZE cannot share a pass on gfx950)
-#    on the same workload with one step of 32 frames, for the default build (free-space bricks counted) and for
+#    on the same workload with one step of 64 frames (the first 64 of the 512-frame orbit), for the default build (free-space bricks counted) and for
 #    TL3D_FREE_COUNTERS=0 (free-space bricks streamed, the round-1 formulation);
 # 3. calibration passes: FETCH_SIZE on access patterns with a KNOWN byte count (TL3D_TSDF_VARIANT=2 reads every record of
 #    every listed brick with 8 B per lane; TL3D_DEBUG_ONLY=2 streams the free-space bricks alone with 16 B per lane);
@@ -19,7 +19,7 @@ echo "rc=$?"
 echo "[prof] kernel trace of the per-row measurements: python3 bench.py --no-cpu-baseline --steps 1 --warmup 1 (rows on)"
 timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_rows" -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 1 > "$OUT/bench_trace_rows.log" 2>&1
 echo "rc=$?"
-PMC=(--no-cpu-baseline --no-rows --steps 1 --warmup 0 --frames-per-step 32 --resident-frames 32)
+PMC=(--no-cpu-baseline --no-rows --steps 1 --warmup 0 --frames-per-step 64 --resident-frames 512)      # 64 frames, 0.7 degrees apart
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM SQ_WAVES" "GRBM_GUI_ACTIVE TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TA_TOTAL_WAVEFRONTS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"; do
   i=$((i+1))

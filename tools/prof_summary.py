@@ -76,7 +76,9 @@ def bench_json(name):
     return None
 
 
-key = [k for k in agg if "tsdf_integrate_kernel<false, 0" in k and k.rstrip(">").endswith("false")]      # production variant: free space counted (any lane map)
+key = [k for k in agg if "tsdf_pair_kernel<false" in k]                                                   # production: two overlapping frames per launch
+if not key:
+    key = [k for k in agg if "tsdf_integrate_kernel<false, 0" in k and k.rstrip(">").endswith("false")]  # one frame per launch, free space counted (any lane map)
 if key and "FETCH_SIZE" in agg[key[0]] and "WRITE_SIZE" in agg[key[0]]:
     k = key[0]
     fetch_kb = agg[k]["FETCH_SIZE"] / cnt[k]["FETCH_SIZE"]
@@ -98,7 +100,7 @@ if key and "FETCH_SIZE" in agg[key[0]] and "WRITE_SIZE" in agg[key[0]]:
                "factor_8B_per_lane_reads": round(f_v2 * 1024.0 / known, 3)}
     traffic = (fetch_kb + write_kb) * 1024.0                      # 8-B-per-lane loads, 4-B gathers and stores at face value (factor above ~1.0)
     j = {"grid": 512, "width": 1080, "height": 1920, "depth_format": "f32", "free_space_counters": counted,
-         "kernel": "tsdf_integrate_kernel", "fetch_size_kb": round(fetch_kb, 1), "write_size_kb": round(write_kb, 1),
+         "kernel": k.split("<")[0].replace("tl3d::", ""), "frames_per_sweep": int(round(b1["roofline"].get("frames_per_sweep", 1))) if b1 else 1, "fetch_size_kb": round(fetch_kb, 1), "write_size_kb": round(write_kb, 1),
          "hbm_bytes_per_launch": int(traffic), "algorithmic_bytes_per_launch": alg, "calibration": cal,
          "note": "traffic = (FETCH_SIZE + WRITE_SIZE) * 1024 from separate --pmc passes.  The guide's gfx950 correction (FETCH_SIZE "
                  "reports half the bytes of 16-B-per-lane streaming reads) does not apply to this kernel since free-space bricks are "
