@@ -557,12 +557,7 @@ __global__ __launch_bounds__(256) void tsdf_pair_kernel(Cam cam, Grid g, PoseF p
     const unsigned lstep = (gridDim.x / ngrp) * 4u;
     const int la = lane & 7, lb = lane >> 3;
     (void)ntask;
-    for (unsigned t = bi * 4u + wid; t < a_len + b_len; t += lstep) {
-        const bool fromA = t < a_len;
-        const unsigned brick = (unsigned)__builtin_amdgcn_readfirstlane((int)(fromA ? listA[a_beg + t] : listB[b_beg + (t - a_len)]));
-        const int other = __builtin_amdgcn_readfirstlane((int)(fromA ? clsB[brick] : clsA[brick]));
-        if (!fromA && other == 1) continue;                          // handled from A's list
-        const bool both = fromA && other == 1;
+    auto process = [&](unsigned brick, bool useA, bool useB) {        // useA / useB wave-uniform
         const int bx = (int)(brick % (unsigned)g.nbx), by = (int)((brick / (unsigned)g.nbx) % (unsigned)g.nby), bz = (int)(brick / (unsigned)(g.nbx * g.nby));
         int2 *__restrict__ recs2 = grid + ((size_t)brick << 9);
         const int i = bx * 8 + la;
@@ -571,7 +566,6 @@ __global__ __launch_bounds__(256) void tsdf_pair_kernel(Cam cam, Grid g, PoseF p
 #pragma unroll
         for (int k = 0; k < 8; ++k) { qs[k] = 0; ws[k] = 0; }
         // both frames' gathers are issued before either frame's values are needed (one wait for 16 instead of two for 8)
-        const bool useA = fromA, useB = fromA ? both : true;         // wave-uniform
         float zcA[8], dvA[8], zcB[8], dvB[8];
         bool okA[8], okB[8];
 #pragma unroll
@@ -613,6 +607,28 @@ __global__ __launch_bounds__(256) void tsdf_pair_kernel(Cam cam, Grid g, PoseF p
                 recs2[MAP == 1 ? (k * 64 + lane) : (lb * 64 + k * 8 + la)] = rec[k];
                 if (COUNT) { nread += 1; nwritten += 1; }
             }
+    };
+    // one list entry per wave and trip, A's list then B's; the entry of the NEXT trip (and its class in the other frame) is
+    // fetched before this trip's brick is processed.  Most of B's entries are on A's list too and are skipped.
+    {
+        const unsigned ntot = a_len + b_len;
+        auto fetch = [&](unsigned t, unsigned &brick, int &other) {
+            const bool fromA = t < a_len;
+            brick = (unsigned)__builtin_amdgcn_readfirstlane((int)(fromA ? listA[a_beg + t] : listB[b_beg + (t - a_len)]));
+            other = __builtin_amdgcn_readfirstlane((int)(fromA ? clsB[brick] : clsA[brick]));
+        };
+        unsigned t = bi * 4u + wid;
+        unsigned brick_n = 0;
+        int other_n = 0;
+        if (t < ntot) fetch(t, brick_n, other_n);
+        for (; t < ntot; t += lstep) {
+            const unsigned brick = brick_n;
+            const int other = other_n;
+            if (t + lstep < ntot) fetch(t + lstep, brick_n, other_n);
+            const bool fromA = t < a_len;
+            if (!fromA && other == 1) continue;                      // handled from A's list
+            process(brick, fromA, fromA ? other == 1 : true);
+        }
     }
     if (COUNT) {
 #pragma unroll

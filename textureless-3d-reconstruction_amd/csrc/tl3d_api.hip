@@ -212,14 +212,16 @@ static int alloc_grid(tl3d_ctx *ctx, const tl3d_config *cfg) {
             ctx->own_tsdf = true;
             if (hipMemsetAsync(ctx->tsdf, 0, ctx->nvox * sizeof(int2), ctx->stream) != hipSuccess) return set_err(TL3D_E_HIP, "memset failed");
         }
-        {   // two side streams for the per-frame prep chains (tiles, pyramid, classification).  Default priority: a priority
+        {   // three side streams for the per-frame prep chains (tiles, pyramid, classification): a chain is three small dependent
+            // kernels that crawl beside the update kernels (~45 us), so three in flight keep ahead of a 31 us update; two fall
+            // behind it (26.4k vs 28.9k frames/s), four take too much of the chip from it (18.4k).  Default priority: a priority
             // stream gets a hardware queue outside the GPU_MAX_HW_QUEUES pool, and hardware queues are the scarce resource
             // (24 live queues per process over-subscribe the GPU's slots: 10 ms scheduler quanta);
             // highest / lowest / default priority measured the same frame rate.
             const char *ns = getenv("TL3D_PREP_STREAMS");
-            ctx->n_prep_streams = ns ? atoi(ns) : 2;
+            ctx->n_prep_streams = ns ? atoi(ns) : 3;
             if (ctx->n_prep_streams < 1) ctx->n_prep_streams = 1;
-            if (ctx->n_prep_streams > 2) ctx->n_prep_streams = 2;
+            if (ctx->n_prep_streams > 4) ctx->n_prep_streams = 4;
             for (int q = 0; q < ctx->n_prep_streams; ++q)
                 if (!ctx->prep_stream[q] && hipStreamCreateWithFlags(&ctx->prep_stream[q], hipStreamNonBlocking) != hipSuccess)
                     return set_err(TL3D_E_HIP, "stream create failed");
@@ -430,12 +432,12 @@ int tl3d_destroy(tl3d_ctx *ctx) {
     pool_release(ctx->pool_nmap);
     if (ctx->own_tsdf && ctx->tsdf) (void)hipFree(ctx->tsdf);
     if (ctx->own_centroid && ctx->centroid) (void)hipFree(ctx->centroid);
-    for (int q = 0; q < 2; ++q)
+    for (int q = 0; q < 4; ++q)
         if (ctx->prep_stream[q]) (void)hipStreamSynchronize(ctx->prep_stream[q]);
     if (ctx->tsdf_scratch_slab) (void)hipFree(ctx->tsdf_scratch_slab);
     for (int b = 0; b < TL3D_TSDF_NBUF; ++b)
         if (ctx->ev_prep[b]) (void)hipEventDestroy(ctx->ev_prep[b]);
-    for (int q = 0; q < 2; ++q)
+    for (int q = 0; q < 4; ++q)
         if (ctx->prep_stream[q]) (void)hipStreamDestroy(ctx->prep_stream[q]);
     if (ctx->block_counts) (void)hipFree(ctx->block_counts);
     if (ctx->block_offsets) (void)hipFree(ctx->block_offsets);
@@ -474,7 +476,7 @@ int tl3d_sync(tl3d_ctx *ctx) {
     REQUIRE(ctx != nullptr, TL3D_E_INVALID, "null ctx");
     FLUSH_AND_FOLD(ctx);
     TL3D_HIP(hipSetDevice(ctx->device));
-    for (int q = 0; q < 2; ++q)
+    for (int q = 0; q < 4; ++q)
         if (ctx->prep_stream[q]) TL3D_HIP(hipStreamSynchronize(ctx->prep_stream[q]));
     for (int l = 0; l < TL3D_ICP_LANES; ++l)
         if (ctx->icp_lanes[l].stream) TL3D_HIP(hipStreamSynchronize(ctx->icp_lanes[l].stream));

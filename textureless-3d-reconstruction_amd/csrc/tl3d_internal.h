@@ -134,7 +134,7 @@ struct tl3d_ctx {
     // scratch
     // TSDF integration is double-buffered over two streams: the tile/pyramid/cull kernels of frame i+1 run on
     // prep_stream while the update kernel of frame i streams the grid on the main stream.
-    hipStream_t prep_stream[2];  // consecutive frames alternate, so two prep chains are in flight
+    hipStream_t prep_stream[4];  // consecutive frames take them in turn, so that many prep chains are in flight
     int n_prep_streams;
     void *tsdf_scratch[TL3D_TSDF_NBUF];   // depth tiles + compact brick list, one per frame of the two batches in flight
     void *tsdf_scratch_slab;              // the one allocation they are carved from
