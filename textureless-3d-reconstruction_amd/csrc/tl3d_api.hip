@@ -212,14 +212,15 @@ static int alloc_grid(tl3d_ctx *ctx, const tl3d_config *cfg) {
             ctx->own_tsdf = true;
             if (hipMemsetAsync(ctx->tsdf, 0, ctx->nvox * sizeof(int2), ctx->stream) != hipSuccess) return set_err(TL3D_E_HIP, "memset failed");
         }
-        {   // three side streams for the per-frame prep chains (tiles, pyramid, classification): a chain is three small dependent
-            // kernels that crawl beside the update kernels (~45 us), so three in flight keep ahead of a 31 us update; two fall
-            // behind it (26.4k vs 28.9k frames/s), four take too much of the chip from it (18.4k).  Default priority: a priority
-            // stream gets a hardware queue outside the GPU_MAX_HW_QUEUES pool, and hardware queues are the scarce resource
-            // (24 live queues per process over-subscribe the GPU's slots: 10 ms scheduler quanta);
-            // highest / lowest / default priority measured the same frame rate.
+        {   // side streams for the per-frame prep chains (tiles, pyramid, classification): a chain is three small dependent
+            // kernels that crawl beside the update kernels (~45-75 us).  TWO by default.  Measured: on the 1080p bench three
+            // chains in flight keep ahead of the 31 us two-frame update (28.9-29.3k frames/s against 26.4k with two, 18.4k with
+            // four), but the pipeline's fusion stage on 720p frames (TSDF + centroid kernels interleaved on the main stream) takes
+            // 63-82 ms per 1000 frames with three against 30 with two; TL3D_PREP_STREAMS=1..4 overrides.  Folding the pyramid into
+            // the tiles kernel (last workgroup by ticket) was tried to shorten the chain: its 1024 release fences per frame write
+            // the update kernel's dirty lines back under it (53 us per frame) -- reverted.  Default priority: a priority
             const char *ns = getenv("TL3D_PREP_STREAMS");
-            ctx->n_prep_streams = ns ? atoi(ns) : 3;
+            ctx->n_prep_streams = ns ? atoi(ns) : 2;
             if (ctx->n_prep_streams < 1) ctx->n_prep_streams = 1;
             if (ctx->n_prep_streams > 4) ctx->n_prep_streams = 4;
             for (int q = 0; q < ctx->n_prep_streams; ++q)
