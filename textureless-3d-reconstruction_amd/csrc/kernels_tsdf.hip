@@ -756,7 +756,10 @@ int launch_tsdf_update_pair(hipStream_t s, const Cam &cam, const Grid &g, const 
     const TsdfConst cA = make_const(cam, scaleA, mind, maxd, true), cB = make_const(cam, scaleB, mind, maxd, true);
     const TsdfScratch tA = carve(cam, g, scratchA), tB = carve(cam, g, scratchB);
     const int nbricks = g.nbx * g.nby * g.nbz;
-    static const int max_blk = getenv("TL3D_UPDATE_BLOCKS") ? atoi(getenv("TL3D_UPDATE_BLOCKS")) : 1536;
+    // 4 workgroups per CU: the two-frame update is fast enough that the prep chains of the next batch, which crawl beside it,
+    // decide the frame rate; 1024 / 1280 / 1536 / 2048 workgroups: 29.2k / 27.8k / 26.6k / 27.9k frames/s (update 33.4 / 33.3 /
+    // 31.1 / 32.3 us per frame: it is a little slower with fewer, the whole is faster)
+    static const int max_blk = getenv("TL3D_UPDATE_BLOCKS") ? atoi(getenv("TL3D_UPDATE_BLOCKS")) : 1024;
     int nblk = (nbricks + 3) / 4;
     if (nblk > max_blk) nblk = max_blk;
     const int map = tsdf_lane_map(pA);
