@@ -3,7 +3,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch, tl3d
 from tl3d import synth
-W, H, n = 1080, 1920, 32
+W, H, n = 1080, 1920, int(os.environ.get("NF", "32"))
 fx = fy = 1719.0; cx, cy = 540.0, 960.0
 dev = torch.device("cuda", 0)
 scene, poses = synth.object_scene(with_room=True), synth.orbit_poses(n, 1.0, 360.0 / 512)
