@@ -46,6 +46,18 @@ struct Pyramid {
     int ntx[MAX_LEVELS], nty[MAX_LEVELS], off[MAX_LEVELS];     // per level: tiles in x / y, offset into the float4 array
 };
 
+// per-frame arguments of the prep kernels: one launch prepares one frame or two (blockIdx.y picks the frame), since the
+// prep chains of later frames crawl beside the update kernels and their launches, not their work, are what costs
+struct PrepFrame {
+    const void *depth;
+    float4 *tiles;
+    unsigned *list, *list_counts;
+    unsigned char *cls;
+    TsdfConst c;
+    PoseF pose;
+};
+struct PrepFrames { PrepFrame f[2]; };
+
 // tile = (dmin, dmax, allvalid ? 1 : 0, unused)
 
 // Depth source of the TSDF kernels: the f32 frame, or the 16-bit millimetre image it was converted from (uploads of kind
@@ -64,8 +76,12 @@ __device__ __forceinline__ void ld_depth4(const uint16_t *__restrict__ p, size_t
 
 // ---- 1. depth tiles --------------------------------------------------------------------------------------
 template <typename DT>
-__global__ __launch_bounds__(256) void depth_tiles_kernel(Cam cam, TsdfConst c, const DT *__restrict__ depth, int ntx, int nty,
-                                                          float4 *__restrict__ tiles, unsigned *__restrict__ list_counts) {
+__global__ __launch_bounds__(256) void depth_tiles_kernel(Cam cam, PrepFrames P, int ntx, int nty) {
+    const PrepFrame &F = P.f[blockIdx.y];
+    const TsdfConst c = F.c;
+    const DT *__restrict__ depth = static_cast<const DT *>(F.depth);
+    float4 *__restrict__ tiles = F.tiles;
+    unsigned *__restrict__ list_counts = F.list_counts;
     __shared__ float smin[4], smax[4];
     __shared__ int sbad[4];
     if (blockIdx.x == 0 && threadIdx.x < 2) list_counts[threadIdx.x] = 0u;      // reset the brick-list cursors
@@ -114,7 +130,8 @@ __global__ __launch_bounds__(256) void depth_tiles_kernel(Cam cam, TsdfConst c, 
 }
 
 // ---- 2. pyramid ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void tile_pyramid_kernel(Pyramid py, float4 *__restrict__ tiles) {
+__global__ __launch_bounds__(256) void tile_pyramid_kernel(Pyramid py, PrepFrames P) {
+    float4 *__restrict__ tiles = P.f[blockIdx.x].tiles;
     for (int L = 1; L < py.nlev; ++L) {
         const int n = py.ntx[L] * py.nty[L];
         const float4 *__restrict__ src = tiles + py.off[L - 1];
@@ -150,10 +167,14 @@ __device__ __forceinline__ bool sphere_in_view(const Frustum &fr, float x, float
            (fr.ty * y + fr.tz * z >= -rad) && (fr.by * y + fr.bz * z >= -rad);
 }
 
-__global__ __launch_bounds__(256) void brick_cull_kernel(Cam cam, Grid g, PoseF pose, Frustum fr, Pyramid py,
-                                                         const float4 *__restrict__ tiles, unsigned *__restrict__ list,
-                                                         unsigned *__restrict__ list_counts, unsigned *__restrict__ free_cnt,
-                                                         unsigned char *__restrict__ cls_map) {
+__global__ __launch_bounds__(256) void brick_cull_kernel(Cam cam, Grid g, PrepFrames P, Frustum fr, Pyramid py,
+                                                         unsigned *__restrict__ free_cnt) {
+    const PrepFrame &F = P.f[blockIdx.y];
+    const PoseF pose = F.pose;
+    const float4 *__restrict__ tiles = F.tiles;
+    unsigned *__restrict__ list = F.list;
+    unsigned *__restrict__ list_counts = F.list_counts;
+    unsigned char *__restrict__ cls_map = F.cls;
     __shared__ unsigned s_cnt[4][2];
     __shared__ unsigned s_base[2];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -705,26 +726,35 @@ static TsdfConst make_const(const Cam &cam, float scale, float mind, float maxd,
     return c;
 }
 
-// depth tiles + pyramid + brick classification -> compact brick list in scratch
-int launch_tsdf_prepare(hipStream_t s, const Cam &cam, const Grid &g, const PoseF &p, const Frustum &fr, const void *depth, bool depth_u16,
-                        float scale, float mind, float maxd, void *scratch, unsigned *free_cnt) {
-    const TsdfConst c = make_const(cam, scale, mind, maxd);
-    const TsdfScratch t = carve(cam, g, scratch);
-    const int ntiles = t.py.ntx[0] * t.py.nty[0];
+// depth tiles + pyramid + brick classification -> compact brick list in scratch, for one frame or for two in the same
+// three launches (n = 2: both depth images of one kind)
+int launch_tsdf_prepare(hipStream_t s, const Cam &cam, const Grid &g, int n, const PoseF *p, const Frustum &fr, const void *const *depth,
+                        bool depth_u16, const float *scale, float mind, float maxd, void *const *scratch, unsigned *free_cnt) {
+    PrepFrames P;
+    memset(&P, 0, sizeof(P));
+    Pyramid py = make_pyramid(cam);
+    for (int i = 0; i < n; ++i) {
+        const TsdfScratch t = carve(cam, g, scratch[i]);
+        P.f[i].depth = depth[i];
+        P.f[i].tiles = t.tiles;
+        P.f[i].list = t.list;
+        P.f[i].list_counts = t.list_counts;
+        P.f[i].cls = t.cls;
+        P.f[i].c = make_const(cam, scale[i], mind, maxd);
+        P.f[i].pose = p[i];
+    }
+    const int ntiles = py.ntx[0] * py.nty[0];
     if (depth_u16)
-        hipLaunchKernelGGL(depth_tiles_kernel<uint16_t>, dim3(ntiles < 1024 ? ntiles : 1024), dim3(256), 0, s, cam, c,
-                           static_cast<const uint16_t *>(depth), t.py.ntx[0], t.py.nty[0], t.tiles, t.list_counts);
+        hipLaunchKernelGGL(depth_tiles_kernel<uint16_t>, dim3(ntiles < 1024 ? ntiles : 1024, n), dim3(256), 0, s, cam, P, py.ntx[0], py.nty[0]);
     else
-        hipLaunchKernelGGL(depth_tiles_kernel<float>, dim3(ntiles < 1024 ? ntiles : 1024), dim3(256), 0, s, cam, c,
-                           static_cast<const float *>(depth), t.py.ntx[0], t.py.nty[0], t.tiles, t.list_counts);
+        hipLaunchKernelGGL(depth_tiles_kernel<float>, dim3(ntiles < 1024 ? ntiles : 1024, n), dim3(256), 0, s, cam, P, py.ntx[0], py.nty[0]);
     TL3D_HIP(hipGetLastError());
-    if (t.py.nlev > 1) {
-        hipLaunchKernelGGL(tile_pyramid_kernel, dim3(1), dim3(256), 0, s, t.py, t.tiles);
+    if (py.nlev > 1) {
+        hipLaunchKernelGGL(tile_pyramid_kernel, dim3(n), dim3(256), 0, s, py, P);
         TL3D_HIP(hipGetLastError());
     }
     const int ncells = ((g.nbx + 3) / 4) * ((g.nby + 3) / 4) * ((g.nbz + 3) / 4);
-    hipLaunchKernelGGL(brick_cull_kernel, dim3((ncells + 3) / 4), dim3(256), 0, s, cam, g, p, fr, t.py, t.tiles, t.list,
-                       t.list_counts, free_cnt, t.cls);
+    hipLaunchKernelGGL(brick_cull_kernel, dim3((ncells + 3) / 4, n), dim3(256), 0, s, cam, g, P, fr, py, free_cnt);
     TL3D_HIP(hipGetLastError());
     return TL3D_OK;
 }
@@ -756,10 +786,10 @@ int launch_tsdf_update_pair(hipStream_t s, const Cam &cam, const Grid &g, const 
     const TsdfConst cA = make_const(cam, scaleA, mind, maxd, true), cB = make_const(cam, scaleB, mind, maxd, true);
     const TsdfScratch tA = carve(cam, g, scratchA), tB = carve(cam, g, scratchB);
     const int nbricks = g.nbx * g.nby * g.nbz;
-    // 4 workgroups per CU: the two-frame update is fast enough that the prep chains of the next batch, which crawl beside it,
-    // decide the frame rate; 1024 / 1280 / 1536 / 2048 workgroups: 29.2k / 27.8k / 26.6k / 27.9k frames/s (update 33.4 / 33.3 /
-    // 31.1 / 32.3 us per frame: it is a little slower with fewer, the whole is faster)
-    static const int max_blk = getenv("TL3D_UPDATE_BLOCKS") ? atoi(getenv("TL3D_UPDATE_BLOCKS")) : 1024;
+    // 6 workgroups per CU, as the one-frame kernel.  (While every frame had a prep chain of its own those chains, which crawl
+    // beside this kernel, decided the frame rate and 4 per CU was the better trade: 29.2k against 26.6k frames/s; with one chain
+    // per two frames it is 28.5k at 4 per CU, 30.7k at 6.)
+    static const int max_blk = getenv("TL3D_UPDATE_BLOCKS") ? atoi(getenv("TL3D_UPDATE_BLOCKS")) : 1536;
     int nblk = (nbricks + 3) / 4;
     if (nblk > max_blk) nblk = max_blk;
     const int map = tsdf_lane_map(pA);

@@ -873,6 +873,48 @@ static int ktimer_begin(tl3d_ctx *ctx) {
     return id;
 }
 
+// Prep chains of the pending frames that have none yet (the last one or two), together when their depth images are of one kind.
+static int launch_pending_preps(tl3d_ctx *ctx) {
+    int first = ctx->n_pend;
+    while (first > 0 && !ctx->pend[first - 1].prepped) --first;
+    const float mind = (float)ctx->cfg.min_depth, maxd = (float)ctx->cfg.max_depth;
+    const Frustum fr = make_frustum(ctx->cam);
+    const int half = (int)(ctx->tsdf_batch_no & 1u);
+    for (int k = first; k < ctx->n_pend;) {
+        tl3d_ctx::PendingUpdate &u = ctx->pend[k];
+        const Slot &us = ctx->slots[u.slot];
+        const bool u16 = us.has_u16 && ctx->tsdf_use_u16;
+        int n = 1;
+        if (k + 1 < ctx->n_pend) {
+            const Slot &vs = ctx->slots[ctx->pend[k + 1].slot];
+            if ((vs.has_u16 && ctx->tsdf_use_u16) == u16) n = 2;
+        }
+        hipStream_t ps = ctx->prep_stream[ctx->tsdf_seq++ % (unsigned)ctx->n_prep_streams];
+        PoseF poses[2];
+        const void *depths[2];
+        float scales[2];
+        void *scratch[2];
+        for (int i = 0; i < n; ++i) {
+            const tl3d_ctx::PendingUpdate &w = ctx->pend[k + i];
+            const Slot &ws = ctx->slots[w.slot];
+            if (ws.ev_upload) TL3D_HIP(hipStreamWaitEvent(ps, ws.ev_upload, 0));
+            poses[i] = w.pose;
+            depths[i] = u16 ? (const void *)ws.depth_u16 : (const void *)ws.depth;
+            scales[i] = w.scale;
+            scratch[i] = ctx->tsdf_scratch[w.buf];
+        }
+        if (ctx->upd_recorded[half]) TL3D_HIP(hipStreamWaitEvent(ps, ctx->ev_upd[half], 0));
+        int rc = launch_tsdf_prepare(ps, ctx->cam, ctx->grid, n, poses, fr, depths, u16, scales, mind, maxd, scratch, ctx->free_cnt);
+        if (rc) return rc;
+        for (int i = 0; i < n; ++i) {
+            TL3D_HIP(hipEventRecord(ctx->ev_prep[ctx->pend[k + i].buf], ps));
+            ctx->pend[k + i].prepped = true;
+        }
+        k += n;
+    }
+    return TL3D_OK;
+}
+
 // Launches the update kernels of the prepared frames, in call order: one wait per prep stream, the updates back to back,
 // one completion event for the half of the scratch buffers the batch used.
 static int flush_updates(tl3d_ctx *ctx) {
@@ -880,12 +922,14 @@ static int flush_updates(tl3d_ctx *ctx) {
     ctx->grid_epoch++;
     TL3D_HIP(hipSetDevice(ctx->device));
     const float mind = (float)ctx->cfg.min_depth, maxd = (float)ctx->cfg.max_depth;
+    int rc = launch_pending_preps(ctx);                 // (a first frame of a pair still waiting for its partner)
     const int n = ctx->n_pend;
     ctx->n_pend = 0;                                    // whatever happens below, the batch is consumed
-    // each prep stream is in order: waiting for the newest event of every stream covers the whole batch
-    for (int k = n - 1; k >= 0 && k >= n - ctx->n_prep_streams; --k)
+    if (rc) return rc;
+    // each prep stream is in order: waiting for the newest event of every stream covers the whole batch (a chain serves up
+    // to two frames, so the newest events of all streams are among the last 2 x streams frames)
+    for (int k = n - 1; k >= 0 && k >= n - 2 * ctx->n_prep_streams; --k)
         TL3D_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_prep[ctx->pend[k].buf], 0));
-    int rc = TL3D_OK;
     // profiling mode: one event pair around the batch's back-to-back update kernels (nothing else runs on this stream in
     // between), so the two marker packets are shared by n launches instead of being charged to each
     const int kt = ktimer_begin(ctx);
@@ -958,7 +1002,9 @@ int tl3d_integrate(tl3d_ctx *ctx, int slot, const double R[9], const double t[3]
     const void *dptr = u16 ? (const void *)sl.depth_u16 : (const void *)sl.depth;
     static const bool single = getenv("TL3D_SINGLE_STREAM") && atoi(getenv("TL3D_SINGLE_STREAM")) != 0;
     if (single) {                                       // everything in order on the caller's stream
-        rc = launch_tsdf_prepare(ctx->stream, ctx->cam, ctx->grid, p, fr, dptr, u16, (float)scale, mind, maxd, ctx->tsdf_scratch[0], ctx->free_cnt);
+        const float sc1 = (float)scale;
+        void *const sb1 = ctx->tsdf_scratch[0];
+        rc = launch_tsdf_prepare(ctx->stream, ctx->cam, ctx->grid, 1, &p, fr, &dptr, u16, &sc1, mind, maxd, &sb1, ctx->free_cnt);
         if (rc) return rc;
         const int kt = ktimer_begin(ctx);
         rc = launch_tsdf_update(ctx->stream, ctx->cam, ctx->grid, p, dptr, u16, (float)scale, mind, maxd, ctx->tsdf,
@@ -971,18 +1017,19 @@ int tl3d_integrate(tl3d_ctx *ctx, int slot, const double R[9], const double t[3]
         ctx->stats.tsdf_launches++;
         return TL3D_OK;
     }
-    // prep (tiles, pyramid, classification) now, on a side stream: needs the slot's upload and a scratch buffer whose
-    // previous user (two batches ago) has been updated; the update launch itself waits for the batch to fill
+    // prep (tiles, pyramid, classification) on a side stream: needs the slot's upload and a scratch buffer whose previous user
+    // (two batches ago) has been updated; the update launch itself waits for the batch to fill.  Two consecutive frames are
+    // prepared by ONE chain of three launches: the first frame of a pair waits (un-prepared) for the second call, or for
+    // whatever flushes the batch.
     const int half = (int)(ctx->tsdf_batch_no & 1u);
     const int b = half * ctx->tsdf_batch + ctx->n_pend;
-    hipStream_t ps = ctx->prep_stream[ctx->tsdf_seq++ % (unsigned)ctx->n_prep_streams];
-    if (sl.ev_upload) TL3D_HIP(hipStreamWaitEvent(ps, sl.ev_upload, 0));
-    if (ctx->upd_recorded[half]) TL3D_HIP(hipStreamWaitEvent(ps, ctx->ev_upd[half], 0));
-    rc = launch_tsdf_prepare(ps, ctx->cam, ctx->grid, p, fr, dptr, u16, (float)scale, mind, maxd, ctx->tsdf_scratch[b], ctx->free_cnt);
-    if (rc) return rc;
-    TL3D_HIP(hipEventRecord(ctx->ev_prep[b], ps));
     tl3d_ctx::PendingUpdate &u = ctx->pend[ctx->n_pend++];
-    u.slot = slot; u.buf = b; u.pose = p; u.scale = (float)scale;
+    u.slot = slot; u.buf = b; u.pose = p; u.scale = (float)scale; u.prepped = false;
+    const bool second = ctx->n_pend >= 2 && !ctx->pend[ctx->n_pend - 2].prepped;
+    if (second || !ctx->tsdf_pairing) {
+        rc = launch_pending_preps(ctx);
+        if (rc) return rc;
+    }
     if (ctx->n_pend >= ctx->tsdf_batch) return flush_updates(ctx);
     return TL3D_OK;
 }

@@ -145,7 +145,7 @@ struct tl3d_ctx {
     bool tsdf_use_u16;                    // gather from the millimetre image when the slot has one (env TL3D_U16_GATHER=0: never)
     int tsdf_batch;                       // frames per batch (env TL3D_TSDF_BATCH, default 32; 1 = no deferral)
     unsigned tsdf_seq, tsdf_batch_no;
-    struct PendingUpdate { int slot, buf; tl3d::PoseF pose; float scale; } pend[TL3D_TSDF_MAXBATCH];
+    struct PendingUpdate { int slot, buf; tl3d::PoseF pose; float scale; bool prepped; } pend[TL3D_TSDF_MAXBATCH];
     int n_pend;                           // prepared frames whose update launch is deferred to the batch boundary
     // extraction is called twice (size query, then with buffers): the block counts of the query are kept while nothing
     // has touched the grids in between (every grid-modifying or pointer-exposing call bumps grid_epoch)
@@ -264,8 +264,8 @@ int tsdf_lane_map(const PoseF &p);
 int launch_tsdf_update_pair(hipStream_t s, const Cam &cam, const Grid &g, const PoseF &pA, const PoseF &pB, const void *depthA, const void *depthB,
                             bool depth_u16, float scaleA, float scaleB, float mind, float maxd, int2 *grid, void *scratchA, void *scratchB,
                             unsigned long long *counters, bool count);
-int launch_tsdf_prepare(hipStream_t s, const Cam &cam, const Grid &g, const PoseF &p, const Frustum &fr, const void *depth, bool depth_u16,
-                        float scale, float mind, float maxd, void *scratch, unsigned *free_cnt);
+int launch_tsdf_prepare(hipStream_t s, const Cam &cam, const Grid &g, int n, const PoseF *p, const Frustum &fr, const void *const *depth,
+                        bool depth_u16, const float *scale, float mind, float maxd, void *const *scratch, unsigned *free_cnt);
 int launch_tsdf_update(hipStream_t s, const Cam &cam, const Grid &g, const PoseF &p, const void *depth, bool depth_u16, float scale, float mind,
                        float maxd, int2 *grid, void *scratch, unsigned long long *counters, bool count, bool free_counted);
 int launch_fold_free(hipStream_t s, const Grid &g, int2 *grid, unsigned *free_cnt);
