@@ -276,9 +276,9 @@ int tl3d_statistical_outlier(tl3d_ctx *ctx, const float *xyz_hd, int64_t n, int 
 
 /* measurement */
 int tl3d_set_profile(tl3d_ctx *ctx, int count_records, int time_kernels);
-/* tl3d_integrate updates two consecutive frames in one launch when their views overlap (the bricks both see near a surface
- * are read and written once for both; the grid is the same bit for bit).  on = 0: one frame per launch.  Default: on
- * (environment TL3D_TSDF_PAIR=0: off). */
+/* tl3d_integrate updates two consecutive frames in one launch (the bricks both see near a surface are read and written
+ * once for both; the grid is the same bit for bit).  on = 0: one frame per launch.  Default: on (environment
+ * TL3D_TSDF_PAIR=0: off). */
 int tl3d_set_tsdf_pairing(tl3d_ctx *ctx, int on);
 int tl3d_get_stats(tl3d_ctx *ctx, tl3d_stats *out);
 int tl3d_reset_stats(tl3d_ctx *ctx);

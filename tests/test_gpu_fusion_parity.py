@@ -609,9 +609,9 @@ def test_centroid_runs_of_every_length_and_the_point_list_path():
 
 
 def test_two_frames_per_launch_give_the_oracle_grid_bit_for_bit():
-    """tl3d_integrate updates two consecutive overlapping frames in one launch (records of the bricks both see are read and
-    written once): 7 frames 1 degree apart -> 3 pair launches + 1 single, grid == oracle == one frame per launch; a jump of 20
-    degrees in the sequence falls back to single launches; 16-bit frames take the same path."""
+    """tl3d_integrate updates two consecutive frames in one launch (records of the bricks both see are read and written once):
+    9 frames (7 of them 1 degree apart, then a jump back and one of 20 degrees) -> 4 pair launches + 1 single, grid == oracle
+    == one frame per launch; 16-bit frames take the same path."""
     poses, frames = small_scene_frames(n=7, deg=1.0)
     far_poses, far_frames = small_scene_frames(n=2, deg=20.0)
     for as_u16 in (False, True):
@@ -636,6 +636,5 @@ def test_two_frames_per_launch_give_the_oracle_grid_bit_for_bit():
                 launches.append(ctx.stats()["tsdf_launches"])
             for (d, _), pose in seq:
                 orc.tsdf_integrate(d, pose[0], pose[1])
-        # (0,1) (2,3) (4,5) pair up; frame 6 and the two far frames are more than 5 degrees from their neighbours
-        assert launches[1] == 9 and launches[0] == 6, launches
+        assert launches[1] == 9 and launches[0] == 5, launches       # (0,1) (2,3) (4,5) (6,7) and 8 alone
         assert np.array_equal(grids[0], orc.tsdf) and np.array_equal(grids[1], orc.tsdf), as_u16
