@@ -5,14 +5,16 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
-A step = one pass of the hot path over one batch of --frames-per-step synthetic frames per GPU: each frame
-(already resident in HBM) is integrated into that GPU's 512^3 TSDF grid with one tsdf_integrate launch
-(F = 1 frame per sweep).  With N > 1 the frames shard across ranks (weak scaling: per-GPU batch fixed) and the
-per-GPU grids are summed once with an RCCL all-reduce inside the timed region.  Rank 0 prints ONE JSON line.
+A step = one pass of the hot path over one batch of --frames-per-step synthetic frames per GPU (512 = one turn of a
+512-frame orbit, frames 0.7 degrees apart): each frame, already resident in HBM, is integrated into that GPU's 512^3 TSDF
+grid with tl3d_integrate; the library updates two consecutive frames per launch (roofline.frames_per_sweep = 2; the
+same frames at one per launch are measured beside it: roofline.single_frame_per_sweep).  With N > 1 the frames shard
+across ranks (weak scaling: per-GPU batch fixed) and the per-GPU grids are summed once with an RCCL all-reduce inside
+the timed region.  Rank 0 prints ONE JSON line.
 
 roofline: algorithmic bytes per launch are COUNTED by the kernel (8 B x (records read + records written),
-SURVEY.md section 8d) plus the frame's depth bytes; time is hipEvent time on the launching stream over the
-timed region.  cpu_baseline: the C oracle (oracle/tl3d_oracle.c, OpenMP) on the host cores, bounded sample.
+SURVEY.md section 8d) plus the depth bytes of the launch's frames; time is hipEvent time on the launching stream over
+the timed region.  cpu_baseline: the C oracle (oracle/tl3d_oracle.c, OpenMP) on the host cores, bounded sample.
 """
 import argparse
 import json
