@@ -397,7 +397,8 @@ def main():
             "config": {"workload": f"{W}x{H} ray-cast orbit (sphere-union object in a closed room: every pixel valid, the heavier "
                                    f"case -- ray-miss pixels only remove bricks; camera radius 1 m) "
                                    f"integrated into a {n}^3 TSDF @ {args.voxel * 1e3:g} mm, 8 B/voxel, "
-                                   f"1 frame per sweep; frames resident in HBM as "
+                                   f"{args.resident_frames} frames per turn of the orbit ({360.0 / max(1, world * args.resident_frames):.2f} degrees apart), "
+                                   f"{roof['frames_per_sweep'] if roof else 2:g} frames per update launch; frames resident in HBM as "
                                    + ("16-bit millimetres (PNG depth)" if args.depth_format == "u16" else "float32 metres"),
                        "depth_format": args.depth_format,
                        "frames_per_step_per_gpu": F, "resident_frames_per_gpu": n_res, "grid": n,
