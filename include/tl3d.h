@@ -200,10 +200,18 @@ int tl3d_points_bounds(tl3d_ctx *ctx, const float *xyz_hd, int64_t n, double out
  * tl3d_grid_device_ptr issue the outstanding updates first, so results never depend on the batching; a caller that
  * works on a grid pointer obtained EARLIER must call tl3d_grid_device_ptr (or tl3d_sync) again before using it. */
 int tl3d_integrate(tl3d_ctx *ctx, int slot, const double R[9], const double t[3], double scale);
+/* The fusion loop of a sequence in one call (replaces D2R:625-659 per view): for i in 0..n-1, tl3d_integrate (when the TSDF
+ * channel exists) and, when centroid_subsample >= 1 and the centroid channel exists, tl3d_accumulate_centroid of slots[i] with
+ * pose (R + 9 i, t + 3 i) and scales[i] (NULL = 1.0).  Same results as the per-frame calls in that order. */
+int tl3d_fuse_frames(tl3d_ctx *ctx, int n, const int32_t *slots, const double *R, const double *t, const double *scales,
+                     uint32_t flags, int centroid_subsample, double min_depth, double max_depth);
 
 /* a10: vertex/normal map + point-to-plane ICP (no reference code; replaces the SIFT/essential-matrix
  * pose front end D2R:144-215 as the pose source, output in the convention of D2R:618-620). */
 int tl3d_build_normals(tl3d_ctx *ctx, int slot, double scale, double depth_jump);
+/* the same for n slots in one call (scales: n entries or NULL = 1.0): what a host loop over the frames of a sequence does
+ * before registering them (D2R:573 per frame), without a foreign call per frame */
+int tl3d_build_normals_many(tl3d_ctx *ctx, int n, const int32_t *slots, const double *scales, double depth_jump);
 int tl3d_download_normals(tl3d_ctx *ctx, int slot, float *nmap_out_hd /* [H][W][4] */);
 int tl3d_icp_p2plane(tl3d_ctx *ctx, int slot_src, double scale_src, int slot_tgt, const double T_init[16],
                      const tl3d_icp_params *prm, tl3d_icp_result *out);

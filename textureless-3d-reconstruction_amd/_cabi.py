@@ -25,7 +25,7 @@ SYMBOLS = [
     "tl3d_upload_frame", "tl3d_download_depth", "tl3d_pinned_alloc", "tl3d_pinned_free", "tl3d_upload_frame_async",
     "tl3d_slot_wait", "tl3d_attach_grid", "tl3d_backproject", "tl3d_backproject_device", "tl3d_frame_bounds", "tl3d_frames_bounds", "tl3d_accumulate_centroid",
     "tl3d_accumulate_points", "tl3d_points_bounds", "tl3d_integrate", "tl3d_build_normals",
-    "tl3d_download_normals", "tl3d_icp_p2plane", "tl3d_icp_enqueue", "tl3d_icp_collect", "tl3d_icp_batch_enqueue", "tl3d_icp_batch_collect", "tl3d_host_pack_bgr_rows", "tl3d_host_copy_rows", "tl3d_grid_reset", "tl3d_grid_device_ptr",
+    "tl3d_download_normals", "tl3d_icp_p2plane", "tl3d_icp_enqueue", "tl3d_icp_collect", "tl3d_icp_batch_enqueue", "tl3d_icp_batch_collect", "tl3d_host_pack_bgr_rows", "tl3d_host_copy_rows", "tl3d_build_normals_many", "tl3d_fuse_frames", "tl3d_grid_reset", "tl3d_grid_device_ptr",
     "tl3d_grid_download", "tl3d_grid_upload", "tl3d_grid_add", "tl3d_rccl_unique_id", "tl3d_rccl_init", "tl3d_allreduce_grid", "tl3d_extract", "tl3d_statistical_outlier",
     "tl3d_set_profile", "tl3d_set_tsdf_pairing", "tl3d_get_stats", "tl3d_reset_stats", "tl3d_event_record", "tl3d_event_elapsed_ms",
 ]
@@ -177,6 +177,8 @@ def load():
         "tl3d_icp_collect": [vp, i32, C.POINTER(IcpResult)],
         "tl3d_icp_batch_enqueue": [vp, C.POINTER(IcpPair), i32, C.POINTER(IcpParams), i32],
         "tl3d_icp_batch_collect": [vp, C.POINTER(IcpResult), i32],
+        "tl3d_build_normals_many": [vp, i32, vp, vp, dbl],
+        "tl3d_fuse_frames": [vp, i32, vp, vp, vp, vp, u32, i32, dbl, dbl],
         "tl3d_host_pack_bgr_rows": [vp, vp, i32, i32],
         "tl3d_host_copy_rows": [vp, vp, i32, C.c_size_t],
         "tl3d_grid_reset": [vp],

@@ -1032,6 +1032,24 @@ int tl3d_integrate(tl3d_ctx *ctx, int slot, const double R[9], const double t[3]
     return TL3D_OK;
 }
 
+int tl3d_fuse_frames(tl3d_ctx *ctx, int n, const int32_t *slots, const double *R, const double *t, const double *scales,
+                     uint32_t flags, int centroid_subsample, double min_depth, double max_depth) {
+    REQUIRE(ctx && slots && R && t, TL3D_E_INVALID, "null argument");
+    REQUIRE(n >= 0, TL3D_E_INVALID, "n must not be negative");
+    for (int i = 0; i < n; ++i) {
+        const double sc = scales ? scales[i] : 1.0;
+        if (ctx->tsdf) {
+            const int rc = tl3d_integrate(ctx, slots[i], R + (size_t)9 * i, t + (size_t)3 * i, sc);
+            if (rc) return rc;
+        }
+        if (ctx->centroid && centroid_subsample >= 1) {
+            const int rc = tl3d_accumulate_centroid(ctx, slots[i], R + (size_t)9 * i, t + (size_t)3 * i, sc, flags, centroid_subsample, min_depth, max_depth);
+            if (rc) return rc;
+        }
+    }
+    return TL3D_OK;
+}
+
 // ------------------------------------------------------------------------------------------- normals + ICP
 int tl3d_build_normals(tl3d_ctx *ctx, int slot, double scale, double depth_jump) {
     int rc = check_slot(ctx, slot, true);
@@ -1058,6 +1076,15 @@ int tl3d_download_normals(tl3d_ctx *ctx, int slot, float *out) {
     TL3D_HIP(hipSetDevice(ctx->device));
     TL3D_HIP(hipMemcpyAsync(out, ctx->slots[slot].nmap, (size_t)ctx->cam.W * ctx->cam.H * sizeof(float4), hipMemcpyDefault, ctx->stream));
     TL3D_HIP(hipStreamSynchronize(ctx->stream));
+    return TL3D_OK;
+}
+
+int tl3d_build_normals_many(tl3d_ctx *ctx, int n, const int32_t *slots, const double *scales, double depth_jump) {
+    REQUIRE(ctx && slots, TL3D_E_INVALID, "null argument");
+    for (int i = 0; i < n; ++i) {
+        const int rc = tl3d_build_normals(ctx, slots[i], scales ? scales[i] : 1.0, depth_jump);
+        if (rc) return rc;
+    }
     return TL3D_OK;
 }
 

@@ -247,7 +247,28 @@ class FusionContext:
         r, t = pose
         abi.check(self._lib.tl3d_integrate(self._h, int(slot), abi.ptr(abi.d9(r)), abi.ptr(abi.d3(t)), float(scale)))
 
+    def fuse_frames(self, slots, poses, scales=None, centroid_subsample: int = 0, min_depth=None, max_depth=None):
+        """integrate() (and accumulate_centroid() when centroid_subsample >= 1) of many frames in one call, in order."""
+        n = len(slots)
+        if n == 0:
+            return
+        sl = np.ascontiguousarray(slots, np.int32)
+        R = np.ascontiguousarray(np.stack([np.asarray(p[0], np.float64).reshape(3, 3) for p in poses]))
+        t = np.ascontiguousarray(np.stack([np.asarray(p[1], np.float64).reshape(3) for p in poses]))
+        sc = np.ascontiguousarray(np.ones(n) if scales is None else np.asarray(scales, np.float64))
+        mn_d = self.min_depth if min_depth is None else float(min_depth)
+        mx_d = self.max_depth if max_depth is None else float(max_depth)
+        abi.check(self._lib.tl3d_fuse_frames(self._h, n, abi.ptr(sl), abi.ptr(R), abi.ptr(t), abi.ptr(sc), 0, int(centroid_subsample), mn_d, mx_d))
+
     # ---- ICP -------------------------------------------------------------------------------
+    def build_normals_many(self, slots, scales=None, depth_jump=0.05):
+        n = len(slots)
+        if n == 0:
+            return
+        sl = np.ascontiguousarray(slots, np.int32)
+        sc = None if scales is None else np.ascontiguousarray(np.asarray(scales, np.float64))
+        abi.check(self._lib.tl3d_build_normals_many(self._h, n, abi.ptr(sl), None if sc is None else abi.ptr(sc), float(depth_jump)))
+
     def build_normals(self, slot: int, scale=1.0, depth_jump=0.05):
         abi.check(self._lib.tl3d_build_normals(self._h, int(slot), float(scale), float(depth_jump)))
 

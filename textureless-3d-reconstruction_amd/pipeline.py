@@ -205,8 +205,7 @@ class DepthToReconstructionPipeline:
         poses = [(np.eye(3), np.zeros((3, 1)))]
         index = [0]
         prev = 0
-        for i in range(n):
-            ctx.build_normals(i, scale=scales[i])
+        ctx.build_normals_many(list(range(n)), scales)
         T_guess = np.eye(4)
 
         def prior(a, b_):
@@ -318,10 +317,9 @@ class DepthToReconstructionPipeline:
             ctx.attach_grid(grid)
             marks.append(("bound_and_allocate", clock()))
             print("\n--- Step 3: Fuse depth frames (TSDF + voxel centroids) ---")
-            for pose, fi in zip(self.camera_poses, self.frame_index):
-                if grid.channels & abi.CH_TSDF:
-                    ctx.integrate(fi, pose, scale=self.scales[fi])
-                ctx.accumulate_centroid(fi, pose, scale=self.scales[fi], subsample=cfg.subsample_factor)
+            ctx.fuse_frames(self.frame_index, self.camera_poses, [self.scales[fi] for fi in self.frame_index],
+                            centroid_subsample=cfg.subsample_factor)           # TSDF + centroids of every kept frame, in order
+            for fi in self.frame_index:
                 print(f"Camera {fi}: fused")
             st = ctx.stats()
             marks.append(("fuse", clock()))
