@@ -638,3 +638,29 @@ def test_two_frames_per_launch_give_the_oracle_grid_bit_for_bit():
                 orc.tsdf_integrate(d, pose[0], pose[1])
         assert launches[1] == 9 and launches[0] == 5, launches       # (0,1) (2,3) (4,5) (6,7) and 8 alone
         assert np.array_equal(grids[0], orc.tsdf) and np.array_equal(grids[1], orc.tsdf), as_u16
+
+
+def test_fuse_frames_and_normals_many_equal_the_per_frame_calls():
+    """tl3d_fuse_frames / tl3d_build_normals_many (one foreign call for a whole sequence) == the per-frame calls in order."""
+    poses, frames = small_scene_frames(n=5, deg=2.0)
+    grids, nmaps = [], []
+    for batched in (False, True):
+        ctx, _ = make_pair(dims=(96, 96, 96), voxel=0.025, centre=(0.0, -0.2, 0.0), n_slots=5)
+        with ctx:
+            for i, (d, c) in enumerate(frames):
+                ctx.upload(i, d, c)
+            scales = [1.0, 1.0, 0.98, 1.0, 1.02]
+            if batched:
+                ctx.build_normals_many(list(range(5)), scales)
+                ctx.fuse_frames(list(range(5)), poses, scales, centroid_subsample=2)
+            else:
+                for i in range(5):
+                    ctx.build_normals(i, scale=scales[i])
+                for i in range(5):
+                    ctx.integrate(i, poses[i], scale=scales[i])
+                    ctx.accumulate_centroid(i, poses[i], scale=scales[i], subsample=2)
+            grids.append((ctx.download_grid(tl3d.CH_TSDF), ctx.download_grid(tl3d.CH_CENTROID)))
+            nmaps.append([ctx.download_normals(i) for i in range(5)])
+    assert np.array_equal(grids[0][0], grids[1][0]) and np.array_equal(grids[0][1], grids[1][1])
+    assert all(np.array_equal(a, b) for a, b in zip(nmaps[0], nmaps[1]))
+    assert int((grids[0][0][:, 1] > 0).sum()) > 1000
