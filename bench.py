@@ -54,8 +54,26 @@ def parse():
     return ap.parse_args()
 
 
+def spawn_ranks(n):
+    """--gpus N outside torchrun: start N fresh copies of this command line, one per GPU, BEFORE this process has made any GPU
+    call (the parent only waits and passes rank 0's line through).  Rendezvous on 127.0.0.1."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    return max(p.wait() for p in procs)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
     # stdout carries exactly one line, the JSON; libraries that print banners with printf (RCCL at communicator creation)
     # are sent to stderr at the file-descriptor level for the whole run
     sys.stdout.flush()
@@ -73,14 +91,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # TL3D_SHARE_DEVICE=1 + TL3D_DIST_BACKEND=gloo: several ranks on ONE GPU (rehearsal of the N > 1 path on a one-GPU box)
+    if os.environ.get("TL3D_SHARE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
+    backend = os.environ.get("TL3D_DIST_BACKEND", "nccl")
     if world > 1 or args.force_dist:
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:                      # single-process rehearsal of the merge path
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29533"), RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     H, W = args.height, args.width
     sx = W / 1080.0
@@ -89,10 +114,12 @@ def main():
     F = args.frames_per_step
     n_res = min(args.resident_frames, F * max(1, args.steps))
     total_frames_rank = F * args.steps
-    # the orbit is divided by the frames a full run keeps resident (a shorter run renders the first n_res of them)
-    deg = 360.0 / max(1, world * args.resident_frames)
+    # every rank flies the SAME kind of turn: resident_frames frames, 360 / resident_frames degrees apart (0.70 at 512), so the
+    # per-GPU step at N = 8 is the step the N = 1 line times; rank r's turn is shifted by r / N of one frame spacing, i.e. the
+    # ranks hold frames r, r + N, r + 2N, ... of one N x finer sequence
+    deg = 360.0 / max(1, args.resident_frames)
     scene = synth.object_scene(with_room=True)
-    poses = synth.orbit_poses(n_res, 1.0, deg, start_deg=rank * args.resident_frames * deg)
+    poses = synth.orbit_poses(n_res, 1.0, deg, start_deg=rank * deg / world)
     want_rows = world == 1 and not args.no_rows
     channels = tl3d.CH_TSDF | (tl3d.CH_CENTROID if (args.centroid or want_rows) else 0)
     spec = tl3d.GridSpec.cube(n, args.voxel, centre=(0.0, -0.1, 0.0), channels=channels)
@@ -166,11 +193,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    merge_ms = []
+
     def merge():
         # the product's merge: int32-headroom check + RCCL sum all-reduce on the library's own grid memory (zero-copy)
         if dist is not None:
-            from tl3d.distributed import allreduce_context_grids
-            allreduce_context_grids(ctx, dist)
+            from tl3d.distributed import allreduce_context_grids, merge_context_grids
+            ctx.sync()
+            tm = time.perf_counter()
+            if world == 1:                                      # --force-dist: the RCCL path with one rank
+                allreduce_context_grids(ctx, dist)
+            else:
+                merge_context_grids(ctx, dist)
+            ctx.sync()
+            merge_ms.append(1e3 * (time.perf_counter() - tm))
 
     # int32 headroom of the TSDF sums: a voxel may hold TL3D_TSDF_MAX_WEIGHT (65 536) observations, the merged grid included.
     # A job longer than that is a sequence of scans: merge, hand the grid on (here: drop it), start the next scan.  All of it
@@ -180,6 +216,7 @@ def main():
         step(s)
     if dist is not None and args.warmup > 0:
         merge()                                                 # warm the communicator
+        merge_ms.clear()
     ctx.reset()
     barrier()
     ctx.event_record(0)
@@ -397,7 +434,7 @@ def main():
             "config": {"workload": f"{W}x{H} ray-cast orbit (sphere-union object in a closed room: every pixel valid, the heavier "
                                    f"case -- ray-miss pixels only remove bricks; camera radius 1 m) "
                                    f"integrated into a {n}^3 TSDF @ {args.voxel * 1e3:g} mm, 8 B/voxel, "
-                                   f"{args.resident_frames} frames per turn of the orbit ({360.0 / max(1, world * args.resident_frames):.2f} degrees apart), "
+                                   f"{args.resident_frames} frames per turn of the orbit ({360.0 / max(1, args.resident_frames):.2f} degrees apart on every rank), "
                                    f"{roof['frames_per_sweep'] if roof else 2:g} frames per update launch; frames resident in HBM as "
                                    + ("16-bit millimetres (PNG depth)" if args.depth_format == "u16" else "float32 metres"),
                        "depth_format": args.depth_format,
@@ -405,6 +442,9 @@ def main():
                        "voxel_m": args.voxel, "centroid_channel": bool(args.centroid), "icp_in_loop": bool(args.icp),
                        "parallelism": f"frame-shard x{world}" + (f" + {n_merges} RCCL all-reduce(s) of the grid" if world > 1 else ""),
                        "grid_merges_in_timed_region": n_merges if dist is not None else 0,
+                       "merge_ms": [round(x, 2) for x in merge_ms],
+                       "dist_backend": (backend if dist is not None else None),
+                       "dist_ranks": (dist.get_world_size() if dist is not None else 1),
                        "invalid_pixel_fraction": round(invalid_frac, 4),
                        "hw_queues": hwq, "hip": dict(abi.RUNTIME),
                        "setup_s": round(t_gen, 1)},

@@ -73,10 +73,11 @@ void orc_set_threads(int n) {
 #endif
 }
 
-/* brick-major record index: 8x8x8 voxels per brick, x fastest inside a brick and across bricks */
+/* brick-major record index: 8x8x8 voxels per brick, bricks x fastest; inside a brick eight 4x4x4 sub-bricks
+ * (x >> 2 | (y >> 2) << 1 | (z >> 2) << 2) of 64 contiguous records each, x fastest inside a sub-brick */
 static inline size_t vox_index(int i, int j, int k, int nbx, int nby) {
     size_t b = ((size_t)(k >> 3) * (size_t)nby + (size_t)(j >> 3)) * (size_t)nbx + (size_t)(i >> 3);
-    return (b << 9) + (size_t)(((k & 7) << 6) | ((j & 7) << 3) | (i & 7));
+    return (b << 9) + (size_t)(((k & 4) << 6) | ((j & 4) << 5) | ((i & 4) << 4) | ((k & 3) << 4) | ((j & 3) << 2) | (i & 3));
 }
 
 size_t orc_vox_index(const orc_cfg *c, int i, int j, int k) { return vox_index(i, j, k, c->nx >> 3, c->ny >> 3); }
@@ -248,9 +249,9 @@ static inline void rec_coords(size_t idx, int nbx, int nby, int *i, int *j, int 
     const size_t b = idx >> 9;
     const int l = (int)(idx & 511);
     const int bx = (int)(b % (size_t)nbx), by = (int)((b / (size_t)nbx) % (size_t)nby), bz = (int)(b / ((size_t)nbx * (size_t)nby));
-    *i = (bx << 3) | (l & 7);
-    *j = (by << 3) | ((l >> 3) & 7);
-    *k = (bz << 3) | (l >> 6);
+    *i = (bx << 3) | ((l >> 4) & 4) | (l & 3);
+    *j = (by << 3) | ((l >> 5) & 4) | ((l >> 2) & 3);
+    *k = (bz << 3) | ((l >> 6) & 4) | ((l >> 4) & 3);
 }
 
 int64_t orc_extract(const orc_cfg *c, int mode, int min_count, int min_weight, double max_abs_tsdf,

@@ -51,8 +51,8 @@ def test_tsdf_counting_mode_matches_and_counts():
     assert np.array_equal(g, orc.tsdf)
     updates = int(orc.tsdf[:, 1].sum())
     assert st["tsdf_launches"] == 2 and st["tsdf_kernel_timed"] == 2 and st["tsdf_kernel_ms"] > 0
-    # records move in 16-byte pairs: between 1x and 2x the number of updated voxels
-    assert updates <= st["tsdf_records_written"] <= 2 * updates
+    # every voxel update is one 8-byte record read + written by the update kernel, or 1/512 of a counted free-space brick
+    assert st["tsdf_records_written"] + 512 * st["tsdf_bricks_free_counted"] == updates
     assert st["tsdf_records_read"] == st["tsdf_records_written"]
     assert 0 < st["tsdf_bricks_visited"] <= 2 * 512
 

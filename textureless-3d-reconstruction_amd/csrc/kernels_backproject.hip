@@ -365,8 +365,12 @@ int launch_bp_fused(hipStream_t s, const Cam &cam, const BpArgs &a, const PoseD 
     // Static tile order while every tile of the launch can be resident at once (>= 4 workgroups of this kernel fit a CU by
     // registers and LDS; 256 CUs): no tile can then be kept off the chip by tiles that wait for it.  If other work holds
     // slots AND workgroups were dispatched out of order, a wait could starve: it is bounded, ends in the error word, and
-    // the blocking entry point then repeats the call in dynamic order (force_dynamic).  TL3D_BP_ORDER=dynamic|static pins it.
+    // the blocking entry point then repeats the call in dynamic order (force_dynamic).  (Experiments flavour: TL3D_BP_ORDER=dynamic|static pins it.)
+#ifdef TL3D_EXPERIMENTS
     static const int pin = getenv("TL3D_BP_ORDER") ? (getenv("TL3D_BP_ORDER")[0] == 'd' ? 1 : 2) : 0;
+#else
+    constexpr int pin = 0;
+#endif
     BpArgs ad = a;
     const bool stat = pin == 2 || (pin == 0 && !force_dynamic && nt <= 1024);
     if (stat) ad.flags |= BP_F_STATIC_ORDER;

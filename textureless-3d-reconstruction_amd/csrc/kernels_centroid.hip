@@ -311,15 +311,20 @@ int launch_centroid_frame(hipStream_t s, const Cam &cam, const Grid &g, const Bp
         const long long ns = (long long)a.Ws * a.Hs;
         hipLaunchKernelGGL(centroid_direct_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, s, cam, g, a, p, depth, bgr, xf, yf, grid, counters);
     } else {
-        // TL3D_CEN_VARIANT: timing ablations only (2: no grid atomics, 3: samples only, 4: no colour loads); DESIGN.md 7.5
+        // experiments flavour only -- TL3D_CEN_VARIANT: timing ablations (2: no grid atomics, 3: samples only, 4: no colour loads); DESIGN.md 7.5
+#ifdef TL3D_EXPERIMENTS
         static const int var = getenv("TL3D_CEN_VARIANT") ? atoi(getenv("TL3D_CEN_VARIANT")) : 0;
+#endif
         const int tiles_x = (a.Ws + CEN_TW - 1) / CEN_TW, tiles_y = (a.Hs + CEN_TH - 1) / CEN_TH;
         const dim3 gr((unsigned)tiles_x * (unsigned)tiles_y);
 #define CEN_LAUNCH(V_) hipLaunchKernelGGL((centroid_frame_kernel<V_>), gr, dim3(256), 0, s, cam, g, a, p, depth, bgr, xf, yf, grid, counters, tiles_x)
+#ifdef TL3D_EXPERIMENTS
         if (var == 2) CEN_LAUNCH(2);
         else if (var == 3) CEN_LAUNCH(3);
         else if (var == 4) CEN_LAUNCH(4);
-        else CEN_LAUNCH(0);
+        else
+#endif
+            CEN_LAUNCH(0);
 #undef CEN_LAUNCH
     }
     TL3D_HIP(hipGetLastError());

@@ -19,9 +19,10 @@ __device__ __forceinline__ void rec_coords(size_t idx, int nbx, int nby, int &i,
     const int l = (int)(idx & 511);
     const int bx = (int)(b % (size_t)nbx), by = (int)((b / (size_t)nbx) % (size_t)nby);
     const int bz = (int)(b / ((size_t)nbx * (size_t)nby));
-    i = (bx << 3) | (l & 7);
-    j = (by << 3) | ((l >> 3) & 7);
-    k = (bz << 3) | (l >> 6);
+    in_brick_coords(l, i, j, k);
+    i |= bx << 3;
+    j |= by << 3;
+    k |= bz << 3;
 }
 
 __device__ __forceinline__ void mean_colour(const unsigned long long *__restrict__ rec, unsigned long long n, uint8_t c[3]) {

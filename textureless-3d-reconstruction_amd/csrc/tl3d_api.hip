@@ -23,6 +23,18 @@ int set_err(int code, const char *fmt, ...) {
 }
 }  // namespace tl3d
 
+// Tuning knobs (TL3D_PREP_STREAMS, TL3D_TSDF_BATCH, ...) are read from the environment only by the experiments flavour of the
+// library (csrc/build.sh with TL3D_FLAVOUR=experiments -> libtl3d_exp.so); the shipped library ignores them.
+static int env_int(const char *name, int dflt) {
+#ifdef TL3D_EXPERIMENTS
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
+}
+
 #define REQUIRE(cond, code, ...)                           \
     do {                                                   \
         if (!(cond)) return set_err((code), __VA_ARGS__);  \
@@ -166,12 +178,24 @@ static int measure_max_weight(tl3d_ctx *ctx, const int2 *grid, long long *out) {
     return TL3D_OK;
 }
 
+// The free-space counters are incremented by the classification kernels on the prep streams and cleared / folded on the main
+// stream.  Every main-stream write to them is followed by this marker; the next prep chains wait for it (launch_pending_preps),
+// so a count can never land in front of a clear that was issued before it (a reset followed at once by integrate calls).
+static int mark_free_cnt_write(tl3d_ctx *ctx) {
+    if (!ctx->ev_free && hipEventCreateWithFlags(&ctx->ev_free, hipEventDisableTiming) != hipSuccess) return set_err(TL3D_E_HIP, "event create failed");
+    TL3D_HIP(hipEventRecord(ctx->ev_free, ctx->stream));
+    ctx->ev_free_recorded = true;
+    return TL3D_OK;
+}
+
 // pending free-space counts -> records (main stream; the deferred updates must have been issued: their classification
 // kernels, which increment the counters on the side streams, are ordered before the main stream by flush_updates)
 static int fold_free(tl3d_ctx *ctx) {
     if (!ctx->free_cnt || !ctx->free_dirty) return TL3D_OK;
     ctx->free_dirty = false;
-    return launch_fold_free(ctx->stream, ctx->grid, ctx->tsdf, ctx->free_cnt);
+    const int rc = launch_fold_free(ctx->stream, ctx->grid, ctx->tsdf, ctx->free_cnt);
+    if (rc) return rc;
+    return mark_free_cnt_write(ctx);
 }
 #define FLUSH_AND_FOLD(ctx_)                     \
     do {                                         \
@@ -219,27 +243,30 @@ static int alloc_grid(tl3d_ctx *ctx, const tl3d_config *cfg) {
             // 63-82 ms per 1000 frames with three against 30 with two; TL3D_PREP_STREAMS=1..4 overrides.  Folding the pyramid into
             // the tiles kernel (last workgroup by ticket) was tried to shorten the chain: its 1024 release fences per frame write
             // the update kernel's dirty lines back under it (53 us per frame) -- reverted.  Default priority: a priority
-            const char *ns = getenv("TL3D_PREP_STREAMS");
-            ctx->n_prep_streams = ns ? atoi(ns) : 2;
+            ctx->n_prep_streams = env_int("TL3D_PREP_STREAMS", 2);
             if (ctx->n_prep_streams < 1) ctx->n_prep_streams = 1;
             if (ctx->n_prep_streams > 4) ctx->n_prep_streams = 4;
             for (int q = 0; q < ctx->n_prep_streams; ++q)
                 if (!ctx->prep_stream[q] && hipStreamCreateWithFlags(&ctx->prep_stream[q], hipStreamNonBlocking) != hipSuccess)
                     return set_err(TL3D_E_HIP, "stream create failed");
         }
-        ctx->free_cnt = nullptr;
-        ctx->free_dirty = false;
-        if (!(getenv("TL3D_FREE_COUNTERS") && atoi(getenv("TL3D_FREE_COUNTERS")) == 0)) {
+        {
             const size_t nbr = (size_t)g.nbx * g.nby * g.nbz;
+            ctx->free_dirty = false;
             if (hipMalloc(&ctx->free_cnt, nbr * sizeof(unsigned)) != hipSuccess) return set_err(TL3D_E_NOMEM, "free-space counter alloc failed");
             if (hipMemsetAsync(ctx->free_cnt, 0, nbr * sizeof(unsigned), ctx->stream) != hipSuccess) return set_err(TL3D_E_HIP, "memset failed");
+            const int mrc = mark_free_cnt_write(ctx);
+            if (mrc) return mrc;
         }
-        ctx->tsdf_use_u16 = !(getenv("TL3D_U16_GATHER") && atoi(getenv("TL3D_U16_GATHER")) == 0);
-        ctx->tsdf_pairing = !(getenv("TL3D_TSDF_PAIR") && atoi(getenv("TL3D_TSDF_PAIR")) == 0);      // read when the grid is attached
-        const char *nb = getenv("TL3D_TSDF_BATCH");
-        ctx->tsdf_batch = nb ? atoi(nb) : 32;
+        ctx->tsdf_use_u16 = env_int("TL3D_U16_GATHER", 1) != 0;
+        ctx->tsdf_pairing = env_int("TL3D_TSDF_PAIR", 1) != 0;
+        ctx->tsdf_batch = env_int("TL3D_TSDF_BATCH", 32);
         if (ctx->tsdf_batch < 1) ctx->tsdf_batch = 1;
         if (ctx->tsdf_batch > TL3D_TSDF_MAXBATCH) ctx->tsdf_batch = TL3D_TSDF_MAXBATCH;
+        ctx->tsdf_max_blocks = env_int("TL3D_UPDATE_BLOCKS", 1536);
+        if (ctx->tsdf_max_blocks < 8) ctx->tsdf_max_blocks = 8;
+        ctx->tsdf_xcd_group = env_int("TL3D_XCD_GROUP", 1);
+        ctx->tsdf_single_stream = env_int("TL3D_SINGLE_STREAM", 0) != 0;
         {   // the per-frame scratch of both batches: one allocation (64 of them cost ~6 ms to make and as long to free)
             const size_t each = (tsdf_scratch_bytes(ctx->cam, g) + 255) & ~(size_t)255;
             void *slab = nullptr;
@@ -451,6 +478,7 @@ int tl3d_destroy(tl3d_ctx *ctx) {
     if (ctx->rccl_comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(ctx->rccl_comm);
     if (ctx->d_maxw) (void)hipFree(ctx->d_maxw);
     if (ctx->free_cnt) (void)hipFree(ctx->free_cnt);
+    if (ctx->ev_free) (void)hipEventDestroy(ctx->ev_free);
     for (int l = 0; l < TL3D_ICP_LANES; ++l) {
         tl3d_ctx::IcpLane &ln = ctx->icp_lanes[l];
         if (ln.stream) (void)hipStreamSynchronize(ln.stream);
@@ -904,11 +932,13 @@ static int launch_pending_preps(tl3d_ctx *ctx) {
             scratch[i] = ctx->tsdf_scratch[w.buf];
         }
         if (ctx->upd_recorded[half]) TL3D_HIP(hipStreamWaitEvent(ps, ctx->ev_upd[half], 0));
+        if (ctx->ev_free_recorded) TL3D_HIP(hipStreamWaitEvent(ps, ctx->ev_free, 0));      // clears / folds of the free-space counters
         int rc = launch_tsdf_prepare(ps, ctx->cam, ctx->grid, n, poses, fr, depths, u16, scales, mind, maxd, scratch, ctx->free_cnt);
         if (rc) return rc;
         for (int i = 0; i < n; ++i) {
             TL3D_HIP(hipEventRecord(ctx->ev_prep[ctx->pend[k + i].buf], ps));
             ctx->pend[k + i].prepped = true;
+            ctx->pend[k + i].prep_pair = n == 2 ? i + 1 : 0;       // the second frame of a jointly prepared pair has its solo list
         }
         k += n;
     }
@@ -935,32 +965,28 @@ static int flush_updates(tl3d_ctx *ctx) {
     const int kt = ktimer_begin(ctx);
     int launched = 0;
     // two consecutive frames share one visit of the bricks both see near a surface (records read and written once for both)
-    // when they use the same lane map and depth kind; TL3D_TSDF_PAIR=0: one frame per sweep
-    const bool pairing = ctx->tsdf_pairing;
-    static const bool plain = !getenv("TL3D_DEBUG_ONLY") && !getenv("TL3D_TSDF_VARIANT");
-    for (int k = 0; k < n && rc == TL3D_OK; ++k) {
-        const tl3d_ctx::PendingUpdate &u = ctx->pend[k];
-        const Slot &us = ctx->slots[u.slot];
+    // when their depth images are of one kind; tl3d_set_tsdf_pairing(ctx, 0): one frame per launch
+    for (int k = 0; k < n && rc == TL3D_OK;) {
+        const Slot &us = ctx->slots[ctx->pend[k].slot];
         const bool u16 = us.has_u16 && ctx->tsdf_use_u16;
-        if (pairing && plain && ctx->free_cnt != nullptr && k + 1 < n) {
-            const tl3d_ctx::PendingUpdate &v = ctx->pend[k + 1];
-            const Slot &vs = ctx->slots[v.slot];
-            const bool v16 = vs.has_u16 && ctx->tsdf_use_u16;
-            const int map = tsdf_lane_map(u.pose);
-            // (no gate on how far apart the views are: 0.7 / 2.8 / 7.2 / 11 / 22 degrees between the two frames gave +22 / +19 / +13 /
-            // +15 / +15 % frames/s over two single launches -- fewer common bricks, but one launch, one tail)
-            if (v16 == u16 && map != 0 && map == tsdf_lane_map(v.pose)) {
-                rc = launch_tsdf_update_pair(ctx->stream, ctx->cam, ctx->grid, u.pose, v.pose, u16 ? (const void *)us.depth_u16 : (const void *)us.depth,
-                                             v16 ? (const void *)vs.depth_u16 : (const void *)vs.depth, u16, u.scale, v.scale, mind, maxd, ctx->tsdf,
-                                             ctx->tsdf_scratch[u.buf], ctx->tsdf_scratch[v.buf], ctx->d_counters, ctx->count_records);
-                if (rc == TL3D_OK) { ctx->stats.tsdf_launches++; ++launched; }
-                ++k;
-                continue;
-            }
+        // (two frames that one prep chain prepared together: same depth kind, and the second one's solo list exists)
+        const int m = (ctx->tsdf_pairing && k + 1 < n && ctx->pend[k].prep_pair == 1 && ctx->pend[k + 1].prep_pair == 2) ? 2 : 1;
+        PoseF poses[2];
+        const void *depths[2];
+        float scales[2];
+        void *scratch[2];
+        for (int i = 0; i < m; ++i) {
+            const tl3d_ctx::PendingUpdate &w = ctx->pend[k + i];
+            const Slot &ws = ctx->slots[w.slot];
+            poses[i] = w.pose;
+            depths[i] = u16 ? (const void *)ws.depth_u16 : (const void *)ws.depth;
+            scales[i] = w.scale;
+            scratch[i] = ctx->tsdf_scratch[w.buf];
         }
-        rc = launch_tsdf_update(ctx->stream, ctx->cam, ctx->grid, u.pose, u16 ? (const void *)us.depth_u16 : (const void *)us.depth, u16, u.scale, mind, maxd, ctx->tsdf,
-                                ctx->tsdf_scratch[u.buf], ctx->d_counters, ctx->count_records, ctx->free_cnt != nullptr);
+        rc = launch_tsdf_update(ctx->stream, ctx->cam, ctx->grid, m, poses, depths, u16, scales, mind, maxd, ctx->tsdf, scratch, ctx->d_counters,
+                                ctx->count_records, ctx->tsdf_max_blocks, ctx->tsdf_xcd_group);
         if (rc == TL3D_OK) { ctx->stats.tsdf_launches++; ++launched; }
+        k += m;
     }
     if (kt >= 0) {
         ctx->ktimers[kt].launches = launched;
@@ -998,15 +1024,14 @@ int tl3d_integrate(tl3d_ctx *ctx, int slot, const double R[9], const double t[3]
     Slot &sl = ctx->slots[slot];
     const bool u16 = sl.has_u16 && ctx->tsdf_use_u16;
     const void *dptr = u16 ? (const void *)sl.depth_u16 : (const void *)sl.depth;
-    static const bool single = getenv("TL3D_SINGLE_STREAM") && atoi(getenv("TL3D_SINGLE_STREAM")) != 0;
-    if (single) {                                       // everything in order on the caller's stream
+    if (ctx->tsdf_single_stream) {                      // everything in order on the caller's stream
         const float sc1 = (float)scale;
         void *const sb1 = ctx->tsdf_scratch[0];
         rc = launch_tsdf_prepare(ctx->stream, ctx->cam, ctx->grid, 1, &p, fr, &dptr, u16, &sc1, mind, maxd, &sb1, ctx->free_cnt);
         if (rc) return rc;
         const int kt = ktimer_begin(ctx);
-        rc = launch_tsdf_update(ctx->stream, ctx->cam, ctx->grid, p, dptr, u16, (float)scale, mind, maxd, ctx->tsdf,
-                                ctx->tsdf_scratch[0], ctx->d_counters, ctx->count_records, ctx->free_cnt != nullptr);
+        rc = launch_tsdf_update(ctx->stream, ctx->cam, ctx->grid, 1, &p, &dptr, u16, &sc1, mind, maxd, ctx->tsdf, &sb1, ctx->d_counters,
+                                ctx->count_records, ctx->tsdf_max_blocks, ctx->tsdf_xcd_group);
         if (kt >= 0) {
             ctx->ktimers[kt].launches = 1;
             (void)hipEventRecord(ctx->ktimers[kt].b, ctx->stream);
@@ -1022,7 +1047,7 @@ int tl3d_integrate(tl3d_ctx *ctx, int slot, const double R[9], const double t[3]
     const int half = (int)(ctx->tsdf_batch_no & 1u);
     const int b = half * ctx->tsdf_batch + ctx->n_pend;
     tl3d_ctx::PendingUpdate &u = ctx->pend[ctx->n_pend++];
-    u.slot = slot; u.buf = b; u.pose = p; u.scale = (float)scale; u.prepped = false;
+    u.slot = slot; u.buf = b; u.pose = p; u.scale = (float)scale; u.prepped = false; u.prep_pair = 0;
     const bool second = ctx->n_pend >= 2 && !ctx->pend[ctx->n_pend - 2].prepped;
     if (second || !ctx->tsdf_pairing) {
         rc = launch_pending_preps(ctx);
@@ -1354,10 +1379,12 @@ int tl3d_icp_batch_enqueue(tl3d_ctx *ctx, const tl3d_icp_pair *pairs, int n_pair
     // workgroups per pair: a function of the level geometry only, so a pair's sums (and pose) do not depend on the batch it is in
     long long members = (ns_max + ICP_BATCH_SAMPLES_PER_MEMBER - 1) / ICP_BATCH_SAMPLES_PER_MEMBER;
     if (members > ICP_BATCH_MAX_MEMBERS) members = ICP_BATCH_MAX_MEMBERS;
-    if (const char *e = getenv("TL3D_ICP_MEMBERS")) {       // experiments only
+#ifdef TL3D_EXPERIMENTS
+    if (const char *e = getenv("TL3D_ICP_MEMBERS")) {
         const long long m = atoll(e);
         if (m >= 1 && m <= ICP_BATCH_MAX_MEMBERS) members = m;
     }
+#endif
     TL3D_HIP(hipSetDevice(ctx->device));
     int rc = icp_batch_reserve(ctx, n_pairs, (size_t)n_pairs * (size_t)members * ICP_SLAB);
     if (rc) return rc;
@@ -1390,7 +1417,8 @@ int tl3d_icp_batch_enqueue(tl3d_ctx *ctx, const tl3d_icp_pair *pairs, int n_pair
     a.sync_rows = b.sync_rows;
     a.mind = (float)ctx->cfg.min_depth;
     a.maxd = (float)ctx->cfg.max_depth;
-    if (getenv("TL3D_ICP_TRACE")) {                        // experiments: per-pass timestamps of pair 0
+#ifdef TL3D_EXPERIMENTS
+    if (getenv("TL3D_ICP_TRACE")) {                        // per-pass timestamps of pair 0
         if (b.dbg) (void)hipFree(b.dbg);
         b.dbg = nullptr;
         TL3D_HIP(hipMalloc(&b.dbg, (size_t)members * 16 * 8 * sizeof(unsigned long long)));
@@ -1406,6 +1434,7 @@ int tl3d_icp_batch_enqueue(tl3d_ctx *ctx, const tl3d_icp_pair *pairs, int n_pair
         TL3D_HIP(hipMemsetAsync(b.stage, 0, b.stage_n * 16, b.stream));
         a.stage = b.stage;
     }
+#endif
     rc = launch_icp_batch(b.stream, ctx->cam, a);
     if (rc) return rc;
     TL3D_HIP(hipMemcpyAsync(b.states_host, b.states, (size_t)n_pairs * sizeof(IcpState), hipMemcpyDeviceToHost, b.stream));
@@ -1424,6 +1453,7 @@ int tl3d_icp_batch_collect(tl3d_ctx *ctx, tl3d_icp_result *out, int n_out) {
     TL3D_HIP(hipSetDevice(ctx->device));
     TL3D_HIP(hipStreamSynchronize(b.stream));
     b.busy = false;
+#ifdef TL3D_EXPERIMENTS
     if (b.dbg && getenv("TL3D_ICP_TRACE")) {
         std::vector<unsigned long long> h((size_t)b.dbg_members * 16 * 8);
         TL3D_HIP(hipMemcpy(h.data(), b.dbg, h.size() * 8, hipMemcpyDeviceToHost));
@@ -1456,6 +1486,7 @@ int tl3d_icp_batch_collect(tl3d_ctx *ctx, tl3d_icp_result *out, int n_out) {
             fprintf(stderr, "  pair %zu ticket-member %zu: stage %u pass %u block %u arrived-as %u hwid %08x\n", p0, m, r[0] & 15u, r[0] >> 4, r[1], r[2], r[3]);
         }
     }
+#endif
     REQUIRE(b.ctl_host[1] == 0, TL3D_E_HIP, "ICP batch: a workgroup timed out waiting for its pair (pair %u member %u pass %u level %u iteration %u: "
             "%u of its workgroups had arrived, generation word %u; %u workgroups started, %u polls)", b.ctl_host[4], b.ctl_host[5], b.ctl_host[6],
             b.ctl_host[10], b.ctl_host[11], b.ctl_host[8], b.ctl_host[9], b.ctl_host[0], b.ctl_host[7]);
@@ -1496,7 +1527,11 @@ int tl3d_grid_reset(tl3d_ctx *ctx) {
     TL3D_HIP(hipSetDevice(ctx->device));
     if (ctx->tsdf) TL3D_HIP(hipMemsetAsync(ctx->tsdf, 0, ctx->nvox * sizeof(int2), ctx->stream));
     if (ctx->centroid) TL3D_HIP(hipMemsetAsync(ctx->centroid, 0, ctx->nvox * 32, ctx->stream));
-    if (ctx->free_cnt) TL3D_HIP(hipMemsetAsync(ctx->free_cnt, 0, (ctx->nvox >> 9) * sizeof(unsigned), ctx->stream));
+    if (ctx->free_cnt) {
+        TL3D_HIP(hipMemsetAsync(ctx->free_cnt, 0, (ctx->nvox >> 9) * sizeof(unsigned), ctx->stream));
+        const int mrc = mark_free_cnt_write(ctx);
+        if (mrc) return mrc;
+    }
     ctx->free_dirty = false;
     ctx->tsdf_w_upper = 0;
     ctx->tsdf_w_unknown = false;
@@ -1537,7 +1572,11 @@ int tl3d_grid_upload(tl3d_ctx *ctx, uint32_t channel, const void *in, size_t byt
     TL3D_HIP(hipSetDevice(ctx->device));
     if (channel == TL3D_CH_TSDF) {
         ctx->tsdf_w_unknown = true;
-        if (ctx->free_cnt) TL3D_HIP(hipMemsetAsync(ctx->free_cnt, 0, (ctx->nvox >> 9) * sizeof(unsigned), ctx->stream));   // the upload replaces the channel
+        if (ctx->free_cnt) {                                  // the upload replaces the channel
+            TL3D_HIP(hipMemsetAsync(ctx->free_cnt, 0, (ctx->nvox >> 9) * sizeof(unsigned), ctx->stream));
+            const int mrc = mark_free_cnt_write(ctx);
+            if (mrc) return mrc;
+        }
         ctx->free_dirty = false;
     }
     TL3D_HIP(hipMemcpyAsync(p, in, nb, hipMemcpyDefault, ctx->stream));

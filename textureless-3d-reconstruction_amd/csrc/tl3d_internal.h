@@ -145,7 +145,7 @@ struct tl3d_ctx {
     bool tsdf_use_u16;                    // gather from the millimetre image when the slot has one (env TL3D_U16_GATHER=0: never)
     int tsdf_batch;                       // frames per batch (env TL3D_TSDF_BATCH, default 32; 1 = no deferral)
     unsigned tsdf_seq, tsdf_batch_no;
-    struct PendingUpdate { int slot, buf; tl3d::PoseF pose; float scale; bool prepped; } pend[TL3D_TSDF_MAXBATCH];
+    struct PendingUpdate { int slot, buf; tl3d::PoseF pose; float scale; bool prepped; int prep_pair; } pend[TL3D_TSDF_MAXBATCH];
     int n_pend;                           // prepared frames whose update launch is deferred to the batch boundary
     // extraction is called twice (size query, then with buffers): the block counts of the query are kept while nothing
     // has touched the grids in between (every grid-modifying or pointer-exposing call bumps grid_epoch)
@@ -170,6 +170,10 @@ struct tl3d_ctx {
     // anything reads the TSDF channel.  TL3D_FREE_COUNTERS=0 keeps the round-1 behaviour (records streamed every frame).
     unsigned *free_cnt;
     bool free_dirty;
+    hipEvent_t ev_free;                   // recorded on the main stream behind its last write to free_cnt (clear, fold); prep chains wait for it
+    bool ev_free_recorded;
+    int tsdf_max_blocks, tsdf_xcd_group;  // launch geometry of the update kernel (1536 workgroups, XCD-grouped lists)
+    bool tsdf_single_stream;
     void *rccl_comm;             // ncclComm_t of tl3d_rccl_init (RCCL is dlopen'ed: tl3d_api.hip)
     int rccl_world;
     long long tsdf_w_upper;
@@ -236,8 +240,19 @@ int set_err(int code, const char *fmt, ...);
 __device__ __forceinline__ size_t brick_base(int bx, int by, int bz, int nbx, int nby) {
     return (((size_t)bz * (size_t)nby + (size_t)by) * (size_t)nbx + (size_t)bx) << 9;
 }
+// Record order inside a brick: eight 4x4x4 sub-bricks (sub-brick = x >> 2 | (y >> 2) << 1 | (z >> 2) << 2) of 64 contiguous records
+// each, x fastest inside a sub-brick.  A sub-brick is the unit the TSDF update classifies and touches: 64 records = one 8-B-per-lane
+// access of a wave = 512 contiguous bytes of the TSDF channel (2 KB of the centroid channel).
+__host__ __device__ __forceinline__ int in_brick_index(int i, int j, int k) {
+    return ((k & 4) << 6) | ((j & 4) << 5) | ((i & 4) << 4) | ((k & 3) << 4) | ((j & 3) << 2) | (i & 3);
+}
+__host__ __device__ __forceinline__ void in_brick_coords(int l, int &i, int &j, int &k) {
+    i = ((l >> 4) & 4) | (l & 3);
+    j = ((l >> 5) & 4) | ((l >> 2) & 3);
+    k = ((l >> 6) & 4) | ((l >> 4) & 3);
+}
 __device__ __forceinline__ size_t vox_index(int i, int j, int k, int nbx, int nby) {
-    return brick_base(i >> 3, j >> 3, k >> 3, nbx, nby) + (size_t)(((k & 7) << 6) | ((j & 7) << 3) | (i & 7));
+    return brick_base(i >> 3, j >> 3, k >> 3, nbx, nby) + (size_t)in_brick_index(i, j, k);
 }
 
 // ---- kernel launchers (one per .hip file) -----------------------------------------------------
@@ -260,14 +275,11 @@ int launch_centroid_points(hipStream_t s, const Grid &g, const float *xyz, const
 int launch_bounds(hipStream_t s, const float *xyz, long long n, float *slab, int nblocks);
 // tsdf
 size_t tsdf_scratch_bytes(const Cam &cam, const Grid &g);
-int tsdf_lane_map(const PoseF &p);
-int launch_tsdf_update_pair(hipStream_t s, const Cam &cam, const Grid &g, const PoseF &pA, const PoseF &pB, const void *depthA, const void *depthB,
-                            bool depth_u16, float scaleA, float scaleB, float mind, float maxd, int2 *grid, void *scratchA, void *scratchB,
-                            unsigned long long *counters, bool count);
 int launch_tsdf_prepare(hipStream_t s, const Cam &cam, const Grid &g, int n, const PoseF *p, const Frustum &fr, const void *const *depth,
                         bool depth_u16, const float *scale, float mind, float maxd, void *const *scratch, unsigned *free_cnt);
-int launch_tsdf_update(hipStream_t s, const Cam &cam, const Grid &g, const PoseF &p, const void *depth, bool depth_u16, float scale, float mind,
-                       float maxd, int2 *grid, void *scratch, unsigned long long *counters, bool count, bool free_counted);
+int launch_tsdf_update(hipStream_t s, const Cam &cam, const Grid &g, int n, const PoseF *p, const void *const *depth, bool depth_u16,
+                       const float *scale, float mind, float maxd, int2 *grid, void *const *scratch, unsigned long long *counters, bool count,
+                       int max_blocks, int xcd_group);
 int launch_fold_free(hipStream_t s, const Grid &g, int2 *grid, unsigned *free_cnt);
 // normals + icp
 int launch_normals(hipStream_t s, const Cam &cam, const float *depth, float scale, float mind, float maxd, float jump, float4 *nmap);
