@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--icp", action="store_true", help="also run frame-to-frame ICP each frame (poses still analytic)")
     ap.add_argument("--icp-iters", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single", action="store_true", help="skip the one-frame-per-launch measurement beside the roofline (profiling runs)")
     ap.add_argument("--no-rows", action="store_true", help="skip the per-row rates of the rest of the path (N = 1 only)")
     ap.add_argument("--cpu-merge-frames", type=int, default=6, help="frames of the numpy back-project -> vstack -> voxel centroid -> SOR sample")
     ap.add_argument("--force-dist", action="store_true", help="init torch.distributed (RCCL) even with one rank: exercises the merge path")
@@ -298,7 +299,7 @@ def main():
             except Exception:
                 traffic = None
         paired = m["frames_per_sweep"] > 1.01
-        roof = {"bound": "hbm", "kernel": "tsdf_pair_kernel" if paired else "tsdf_integrate_kernel", "achieved": m["achieved"], "peak": 8000.0,
+        roof = {"bound": "hbm", "kernel": "tsdf_update_kernel", "achieved": m["achieved"], "peak": 8000.0,
                 "unit": "GB/s", "frac": m["frac"], "traffic": traffic,
                 "bytes_per_launch": m["bytes_per_launch"], "records_per_launch": m["records_per_launch"],
                 "dense_sweep_bytes": int(16.0 * n ** 3 + 4.0 * H * W), "bricks_visited_per_launch": m["bricks_visited_per_launch"],
@@ -306,7 +307,7 @@ def main():
                 "free_space_bricks_counted_per_launch": m["free_space_bricks_counted_per_launch"],
                 "ms_per_launch": m["ms_per_launch"], "us_per_frame": m["us_per_frame"], "ms_per_frame_all_kernels": round(region_ms, 4),
                 "launches": int(round(launches / m["frames_per_sweep"])), "frames_per_sweep": m["frames_per_sweep"]}
-        if paired:
+        if paired and not args.no_single:
             # the same frames, one per launch (F = 1: what the fraction was quoted on before), same context, same buffers
             ctx.set_tsdf_pairing(False)
             roof["single_frame_per_sweep"] = measure_roofline(ctx, max(1, min(args.steps, 4)))

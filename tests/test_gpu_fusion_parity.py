@@ -608,16 +608,16 @@ def test_centroid_runs_of_every_length_and_the_point_list_path():
             assert np.array_equal(g_pts, ctx.download_grid(tl3d.CH_CENTROID)), voxel
 
 
-def test_two_frames_per_launch_give_the_oracle_grid_bit_for_bit():
-    """tl3d_integrate updates two consecutive frames in one launch (records of the bricks both see are read and written once):
-    9 frames (7 of them 1 degree apart, then a jump back and one of 20 degrees) -> 4 pair launches + 1 single, grid == oracle
-    == one frame per launch; 16-bit frames take the same path."""
-    poses, frames = small_scene_frames(n=7, deg=1.0)
+def test_a_batch_of_frames_per_launch_gives_the_oracle_grid_bit_for_bit():
+    """tl3d_integrate collects up to 32 frames per update launch (every touched record is read and written once per batch):
+    41 frames (a slow orbit, a jump back and two frames 20 degrees apart, then the start again) -> 2 launches, grid == oracle
+    == one frame per launch; 16-bit frames take the same path; a batch holds one depth kind."""
+    poses, frames = small_scene_frames(n=30, deg=1.0)
     far_poses, far_frames = small_scene_frames(n=2, deg=20.0)
     for as_u16 in (False, True):
-        ctx, orc = make_pair(dims=(96, 96, 96), voxel=0.025, centre=(0.0, -0.2, 0.0), n_slots=9, channels=tl3d.CH_TSDF)
+        ctx, orc = make_pair(dims=(96, 96, 96), voxel=0.025, centre=(0.0, -0.2, 0.0), n_slots=41, channels=tl3d.CH_TSDF)
         with ctx:
-            seq = list(zip(frames, poses)) + list(zip(far_frames, far_poses))
+            seq = list(zip(frames, poses)) + list(zip(far_frames, far_poses)) + list(zip(frames[:9], poses[:9]))
             for i, ((d, c), _) in enumerate(seq):
                 if as_u16:
                     mm = np.clip(np.round(d * 1000.0), 0, 65535).astype(np.uint16)
@@ -626,18 +626,38 @@ def test_two_frames_per_launch_give_the_oracle_grid_bit_for_bit():
                 else:
                     ctx.upload(i, d, None)
             grids, launches = [], []
-            for pairing in (True, False):
+            for batching in (True, False):
                 ctx.reset()
                 ctx.reset_stats()
-                ctx.set_tsdf_pairing(pairing)
+                ctx.set_tsdf_pairing(batching)
                 for i, (_, pose) in enumerate(seq):
                     ctx.integrate(i, pose)
                 grids.append(ctx.download_grid(tl3d.CH_TSDF))
                 launches.append(ctx.stats()["tsdf_launches"])
             for (d, _), pose in seq:
                 orc.tsdf_integrate(d, pose[0], pose[1])
-        assert launches[1] == 9 and launches[0] == 5, launches       # (0,1) (2,3) (4,5) (6,7) and 8 alone
+        assert launches == [2, 41], launches                          # 32 + 9 frames; one frame per launch
         assert np.array_equal(grids[0], orc.tsdf) and np.array_equal(grids[1], orc.tsdf), as_u16
+    # float32 and 16-bit frames interleaved: the batch is cut at every change of kind, the grid does not care
+    ctx, orc = make_pair(dims=(96, 96, 96), voxel=0.025, centre=(0.0, -0.2, 0.0), n_slots=6, channels=tl3d.CH_TSDF)
+    with ctx:
+        ds = []
+        for i in range(6):
+            d = frames[i][0]
+            if i in (2, 3, 5):
+                mm = np.clip(np.round(d * 1000.0), 0, 65535).astype(np.uint16)
+                ctx.upload(i, mm, None)
+                d = mm.astype(np.float32) / np.float32(1000.0)
+            else:
+                ctx.upload(i, d, None)
+            ds.append(d)
+        ctx.reset_stats()
+        for i in range(6):
+            ctx.integrate(i, poses[i])
+            orc.tsdf_integrate(ds[i], poses[i][0], poses[i][1])
+        g = ctx.download_grid(tl3d.CH_TSDF)
+        assert ctx.stats()["tsdf_launches"] == 4                      # (0,1) (2,3) (4) (5)
+    assert np.array_equal(g, orc.tsdf)
 
 
 def test_fuse_frames_and_normals_many_equal_the_per_frame_calls():

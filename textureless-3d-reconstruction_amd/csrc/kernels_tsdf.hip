@@ -3,30 +3,33 @@
 // (oracle/tl3d_oracle.c: orc_tsdf_integrate) and both sides evaluate the same f32 sequence, so the integer
 // grid {sum of rint(tsdf*32767), weight} is bit-identical.
 //
-// Launches per frame (prep chain on a side stream, update on the main stream):
+// tl3d_integrate collects frames into BATCHES of up to 32 (TL3D_TSDF_MAXBATCH).  Per batch, five launches; the per-frame
+// arguments (pose, depth image, scratch pointers) of all its frames sit in one descriptor array in device memory and
+// blockIdx.y / a bit index picks the frame:
 //   1. depth_tiles_kernel     (min, max, all-valid) of the valid scaled depth over 8x8-, 16x16- and 32x32-pixel tiles
-//                             (pyramid levels 0-2), 4 B/pixel read
-//   2. tile_pyramid_kernel    1 workgroup: 2x2 reductions of level 2 up to a single tile
-//   3. brick_cull_kernel      one lane per 8^3 brick (one wave per 4x4x4-brick cell) classifies it from <= 16 pyramid
-//                             lookups:
+//                             (pyramid levels 0-2) of every frame, 4 B/pixel read
+//   2. tile_pyramid_kernel    1 workgroup per frame: 2x2 reductions of level 2 up to a single tile
+//   3. brick_cull_kernel      per frame, one lane per 8^3 brick (one wave per 4x4x4-brick cell) classifies it from <= 16
+//                             pyramid lookups:
 //        SKIP   outside the view, no valid depth under it, or more than trunc behind every surface it can see
 //        FREE   wholly inside the image, every pixel under it valid, and at least trunc in front of every
 //               surface: every voxel gets exactly tsdf = 1 (q = 32767): ONE add to the brick's free-space counter
-//        MIXED  everything else (near a surface, on the image border, straddling the camera plane): compact list
-//   4. subbrick_classify_kernel  one wave per LISTED brick: its eight 4x4x4 SUB-BRICKS by the same three rules (8 lanes per
-//        sub-brick: one extreme voxel centre each, <= 8 pyramid lookups) -> a (mixed, free) bit mask per brick.  On the
-//        headline sequence 3.4 of the 8 sub-bricks of a MIXED brick stay MIXED.  For the second frame of a prepared pair also
-//        the list of its bricks that are NOT on the first frame's list ("solo" list).
-//   5. tsdf_update_kernel     one 64-lane wave per listed brick and visit, for ONE frame or for TWO consecutive frames
-//        (a brick both frames see near a surface is read and written once for both): the voxels of MIXED sub-bricks are
-//        projected and gather a depth value; FREE sub-bricks stream (+32767, +1) into their 512 B of records; SKIP
-//        sub-bricks are not touched.  A sub-brick's 64 records are contiguous (the in-brick record order,
-//        tl3d_internal.h: in_brick_index), so every record access of a wave is one 512-B run.
+//        MIXED  everything else (near a surface, on the image border, straddling the camera plane): the frame's compact
+//               list, its bit in the brick's frame mask, and -- if it is the first frame of the batch to list the brick --
+//               the batch's brick list
+//   4. subbrick_classify_kernel  per frame, one wave per listed brick: its eight 4x4x4 SUB-BRICKS by the same three rules
+//        (8 lanes per sub-brick: one extreme voxel centre each, <= 8 pyramid lookups) -> a (mixed, free) bit mask.  On the
+//        headline sequence 3.4 of the 8 sub-bricks of a listed brick stay MIXED.
+//   5. tsdf_update_kernel     ONE launch per batch, one 64-lane wave per brick of the batch list: for every frame that lists
+//        the brick (frame mask), the voxels of its MIXED sub-bricks are projected and gather a depth value, FREE sub-bricks
+//        add (32767, 1); the increments of all frames are summed in registers and the brick's records are read and written
+//        ONCE per batch (integer sums commute: the grid is the one-frame-at-a-time grid bit for bit).  A sub-brick's 64
+//        records are contiguous (tl3d_internal.h: in_brick_index): every record access of a wave is one 512-B run.
 // Every classification is conservative with respect to the per-voxel rule, so the result is the oracle's bit
-// for bit whatever the view.  The list balances the work (a static brick->block map leaves most of the chip idle:
-// the frustum covers a fraction of the grid).
+// for bit whatever the view.
 // Algorithmic bytes per launch = 8 B x (records read + written), counted by the kernel in counting mode
-// ("counted, never estimated"), + 8 B per counted free-space brick + the depth frame(s).
+// ("counted, never estimated"; F = frames of the batch is reported), + 8 B per counted free-space
+// brick + the depth images of the batch's frames.
 #include <stdlib.h>
 
 #include "tl3d_internal.h"
@@ -42,37 +45,65 @@ constexpr int TILE0 = 8;                 // level-0 tiles are 8x8 pixels
 constexpr int TILE0_SHIFT = 3;
 constexpr int REGION = 32;               // one workgroup pass of the tiles kernel: 32x32 pixels = levels 0, 1, 2 of that region
 constexpr int MAX_LEVELS = 14;           // 8 px << 13 = 65 536 px
-constexpr unsigned XCD_GROUPS = 8;
+constexpr int TICKET_GROUPS = 64;        // ticket counters of the update kernel (one per group of workgroups)
+constexpr unsigned HDR_TICKETS = 64;     // batch header (unsigned words): [0] batch list length, [64 + 16 g] ticket counter of group g
+constexpr unsigned HDR_WORDS = HDR_TICKETS + 16 * TICKET_GROUPS;
 
 struct Pyramid {
     int nlev;
     int ntx[MAX_LEVELS], nty[MAX_LEVELS], off[MAX_LEVELS];     // per level: tiles in x / y, offset into the float4 array
 };
 
-// per-frame arguments of the prep kernels: one launch prepares one frame or two (blockIdx.y picks the frame), since the
-// prep chains of later frames crawl beside the update kernels and their launches, not their work, are what costs
-struct PrepFrame {
-    const void *depth;
-    float4 *tiles;
-    unsigned *list, *list_counts;        // list_counts: [0] listed (MIXED) bricks, [1] free-space bricks (counted), [2] solo list
-    unsigned char *cls;
-    unsigned short *sub;                 // [nbricks] sub-brick masks of the LISTED bricks: bits 0-7 mixed, bits 8-15 free
-    unsigned *solo;                      // second frame of a prepared pair: its listed bricks that the first frame does not list
-    TsdfConst c;
+// One frame of a batch.  The array of a batch's descriptors is written by the host and copied to the device in front of the
+// batch's first kernel; every kernel indexes it with a wave-uniform frame number (scalar loads).
+struct FrameDesc {
     PoseF pose;
+    TsdfConst c;
+    int pad;
+    const void *depth;                   // f32 metres, or the 16-bit millimetre image (one kind per batch)
+    float4 *tiles;                       // the frame's tile pyramid
+    unsigned *list;                      // its listed (MIXED) bricks, for the sub-brick classification
+    unsigned *counts;                    // [0] listed bricks, [1] free-space bricks (counted)
+    unsigned short *sub;                 // [nbricks] sub-brick masks of its listed bricks: bits 0-7 mixed, bits 8-15 free
 };
-struct PrepFrames { PrepFrame f[2]; };
 
-// one frame of an update launch
-struct UpdFrame {
-    PoseF pose;
-    TsdfConst c;
-    const void *depth;
-    const unsigned *list, *counts;       // compact list of the frame's MIXED bricks, counts[0] = its length (as frame B of a pair:
-                                         // the solo list, counts[2])
-    const unsigned char *cls;            // class of every brick of the grid in this frame (0 skip, 1 mixed, 2 free)
-    const unsigned short *sub;           // sub-brick masks of its listed bricks
+// what all frames of a batch share
+struct BatchBufs {
+    const FrameDesc *frames;             // [n_frames]
+    unsigned *hdr;                       // [0] length of the batch list (reset by the tiles kernel)
+    unsigned *list;                      // bricks that at least one frame of the batch lists, in order of first listing
+    unsigned *framemask;                 // [nbricks] bit f: frame f lists the brick; all zero between batches (the update re-arms it)
+    int n_frames;
 };
+
+// The descriptors do not change while a kernel that reads them runs: read through the constant address space, a wave-uniform
+// index turns into scalar loads (pose and limits live in SGPRs) -- through a plain pointer the compiler must assume that the
+// kernel's own stores could alias them and uses vector loads, 17 VGPRs per frame in flight.
+typedef const FrameDesc __attribute__((address_space(4))) *DescPtr;
+__device__ __forceinline__ DescPtr const_descs(const BatchBufs &B) { return (DescPtr)(B.frames); }
+__device__ __forceinline__ PoseF desc_pose(DescPtr d) {
+    PoseF p;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) p.r[i] = d->pose.r[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) p.t[i] = d->pose.t[i];
+    return p;
+}
+__device__ __forceinline__ TsdfConst desc_const(DescPtr d) {
+    TsdfConst c;
+    c.mind = d->c.mind; c.maxd = d->c.maxd; c.sc = d->c.sc; c.wlim = d->c.wlim; c.hlim = d->c.hlim;
+    return c;
+}
+
+// The descriptors travel to the device as the ARGUMENTS of a tiny kernel (captured at launch: no staging buffer whose lifetime
+// the host would have to track), 16 per launch (kernel arguments are limited to 4 KB).
+struct DescChunk { FrameDesc d[16]; };
+__global__ __launch_bounds__(256) void desc_upload_kernel(DescChunk c, FrameDesc *__restrict__ dst, int n) {
+    const unsigned *src = reinterpret_cast<const unsigned *>(&c);
+    unsigned *out = reinterpret_cast<unsigned *>(dst);
+    const int words = n * (int)(sizeof(FrameDesc) / 4);
+    for (int i = threadIdx.x; i < words; i += 256) out[i] = src[i];
+}
 
 // tile = (dmin, dmax, allvalid ? 1 : 0, unused)
 
@@ -95,15 +126,18 @@ __device__ __forceinline__ void ld_depth4(const uint16_t *__restrict__ p, size_t
 // 8w .. 8w+7 = one row of four level-0 tiles (lanes with equal q4 >> 1); the region's level-1 and level-2 tiles are combined
 // through LDS.
 template <typename DT>
-__global__ __launch_bounds__(256) void depth_tiles_kernel(Cam cam, PrepFrames P, Pyramid py, int nrx, int nry) {
-    const PrepFrame &F = P.f[blockIdx.y];
-    const TsdfConst c = F.c;
-    const DT *__restrict__ depth = static_cast<const DT *>(F.depth);
-    float4 *__restrict__ tiles = F.tiles;
-    unsigned *__restrict__ list_counts = F.list_counts;
+__global__ __launch_bounds__(256) void depth_tiles_kernel(Cam cam, BatchBufs B, Pyramid py, int nrx, int nry) {
+    const DescPtr F = const_descs(B) + blockIdx.y;
+    const TsdfConst c = desc_const(F);
+    const DT *__restrict__ depth = static_cast<const DT *>(F->depth);
+    float4 *__restrict__ tiles = F->tiles;
     __shared__ float s_mn[4][4], s_mx[4][4];
     __shared__ int s_bad[4][4];
-    if (blockIdx.x == 0 && threadIdx.x < 3) list_counts[threadIdx.x] = 0u;      // reset the brick-list cursors
+    if (blockIdx.x == 0 && threadIdx.x < 2) F->counts[threadIdx.x] = 0u;        // reset the frame's list cursors
+    if (blockIdx.x == 0 && blockIdx.y == 0) {                                    // and the batch list's, and the update's ticket counters
+        if (threadIdx.x == 2) B.hdr[0] = 0u;
+        if (threadIdx.x >= 64 && threadIdx.x < 64 + TICKET_GROUPS) B.hdr[HDR_TICKETS + 16u * (threadIdx.x - 64)] = 0u;
+    }
     const int q4 = threadIdx.x & 7, row = threadIdx.x >> 3, wid = threadIdx.x >> 6;
     const bool vec = (cam.W & 3) == 0;                              // rows are 16-B aligned
     for (int region = blockIdx.x; region < nrx * nry; region += gridDim.x) {
@@ -167,8 +201,8 @@ __global__ __launch_bounds__(256) void depth_tiles_kernel(Cam cam, PrepFrames P,
 }
 
 // ---- 2. pyramid: levels 3 .. from level 2 ------------------------------------------------------------------
-__global__ __launch_bounds__(256) void tile_pyramid_kernel(Pyramid py, PrepFrames P) {
-    float4 *__restrict__ tiles = P.f[blockIdx.x].tiles;
+__global__ __launch_bounds__(256) void tile_pyramid_kernel(Pyramid py, BatchBufs B) {
+    float4 *__restrict__ tiles = const_descs(B)[blockIdx.x].tiles;
     for (int L = 3; L < py.nlev; ++L) {
         const int n = py.ntx[L] * py.nty[L];
         const float4 *__restrict__ src = tiles + py.off[L - 1];
@@ -197,7 +231,7 @@ __global__ __launch_bounds__(256) void tile_pyramid_kernel(Pyramid py, PrepFrame
 // ---- 3. brick classification ------------------------------------------------------------------------------
 // One wave per cell of 4x4x4 bricks, one lane per brick.  A cell whose bounding sphere misses the view exits after
 // a handful of instructions (most of the grid); the four waves of a workgroup pool their survivors so the list
-// cursor sees one atomic per workgroup, not per wave (same-address returning atomics retire at ~90 per microsecond).
+// cursors see one atomic per workgroup, not per wave (same-address returning atomics retire at ~90 per microsecond).
 // Margins: 1.5 px on projected bounds, 1 % of a voxel on depths, 0.1 % on the truncation distance.
 __device__ __forceinline__ bool sphere_in_view(const Frustum &fr, float x, float y, float z, float rad) {
     return (z + rad > 0.0f) && (fr.lx * x + fr.lz * z >= -rad) && (fr.rx * x + fr.rz * z >= -rad) &&
@@ -214,36 +248,30 @@ __device__ __forceinline__ int classify_box(const Grid &g, float4 a, float zmin,
     return 1;
 }
 
-__global__ __launch_bounds__(256) void brick_cull_kernel(Cam cam, Grid g, PrepFrames P, Frustum fr, Pyramid py,
+__global__ __launch_bounds__(256) void brick_cull_kernel(Cam cam, Grid g, BatchBufs B, Frustum fr, Pyramid py,
                                                          unsigned *__restrict__ free_cnt) {
-    const PrepFrame &F = P.f[blockIdx.y];
-    const PoseF pose = F.pose;
-    const float4 *__restrict__ tiles = F.tiles;
-    unsigned *__restrict__ list = F.list;
-    unsigned *__restrict__ list_counts = F.list_counts;
-    unsigned char *__restrict__ cls_map = F.cls;
-    __shared__ unsigned s_cnt[4][2];
-    __shared__ unsigned s_base[2];
+    const DescPtr F = const_descs(B) + blockIdx.y;
+    const PoseF pose = desc_pose(F);
+    const float4 *__restrict__ tiles = F->tiles;
+    unsigned *__restrict__ list = F->list;
+    __shared__ unsigned s_cnt[4][3];
+    __shared__ unsigned s_base[3];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int ncx = (g.nbx + 3) >> 2, ncy = (g.nby + 3) >> 2, ncz = (g.nbz + 3) >> 2;
     const int cell = blockIdx.x * 4 + wid;
     int cls = 0;                                                  // 0 skip, 1 mixed, 2 free
     int brick = 0;
-    bool in_grid = false;
     if (cell < ncx * ncy * ncz) {
         const int ccx = cell % ncx, ccy = (cell / ncx) % ncy, ccz = cell / (ncx * ncy);
-        {
-            const int bx0 = ccx * 4 + (lane & 3), by0 = ccy * 4 + ((lane >> 2) & 3), bz0 = ccz * 4 + (lane >> 4);
-            in_grid = bx0 < g.nbx && by0 < g.nby && bz0 < g.nbz;
-            brick = (bz0 * g.nby + by0) * g.nbx + bx0;
-        }
+        const int bx = ccx * 4 + (lane & 3), by = ccy * 4 + ((lane >> 2) & 3), bz = ccz * 4 + (lane >> 4);
+        const bool in_grid = bx < g.nbx && by < g.nby && bz < g.nbz;
+        brick = (bz * g.nby + by) * g.nbx + bx;
         const float crad = 27.712812f * g.vs * 1.01f;               // half diagonal of a 32^3-voxel cell, +1 %
         const float qx = fmaf((float)(ccx * 32 + 16), g.vs, g.ox), qy = fmaf((float)(ccy * 32 + 16), g.vs, g.oy);
         const float qz = fmaf((float)(ccz * 32 + 16), g.vs, g.oz);
         const float ex = pose.r[0] * qx + pose.r[1] * qy + pose.r[2] * qz + pose.t[0];
         const float ey = pose.r[3] * qx + pose.r[4] * qy + pose.r[5] * qz + pose.t[1];
         const float ez = pose.r[6] * qx + pose.r[7] * qy + pose.r[8] * qz + pose.t[2];
-        const int bx = ccx * 4 + (lane & 3), by = ccy * 4 + ((lane >> 2) & 3), bz = ccz * 4 + (lane >> 4);
         if (sphere_in_view(fr, ex, ey, ez, crad) && in_grid) {
             const float rad = 6.9282032f * g.vs * 1.01f;             // half diagonal of a brick, +1 %
             const float wx = fmaf((float)(bx * 8 + 4), g.vs, g.ox);
@@ -302,24 +330,26 @@ __global__ __launch_bounds__(256) void brick_cull_kernel(Cam cam, Grid g, PrepFr
             }
         }
     }
-    // the class of EVERY brick of the grid, for the kernel that updates two frames per visit (it asks whether a brick on one
-    // frame's list is on the other's too)
-    if (in_grid) cls_map[brick] = (unsigned char)cls;
-    const unsigned long long mm = __ballot(cls == 1), mf = __ballot(cls == 2);
-    if (lane == 0) { s_cnt[wid][0] = (unsigned)__popcll(mm); s_cnt[wid][1] = (unsigned)__popcll(mf); }
-    __syncthreads();
-    if (threadIdx.x < 2) {
-        const unsigned tot = s_cnt[0][threadIdx.x] + s_cnt[1][threadIdx.x] + s_cnt[2][threadIdx.x] + s_cnt[3][threadIdx.x];
-        s_base[threadIdx.x] = tot ? atomicAdd(list_counts + threadIdx.x, tot) : 0u;      // [1]: free-space bricks, counted only
-    }
-    __syncthreads();
-    unsigned bm = s_base[0];
-    for (int w = 0; w < wid; ++w) bm += s_cnt[w][0];
-    const unsigned long long below = (1ull << lane) - 1ull;
-    if (cls == 1) list[bm + __popcll(mm & below)] = (unsigned)brick;
+    // MIXED: the brick's bit in the frame mask; the first frame of the batch to set a bit also puts the brick on the batch list
+    bool first = false;
+    if (cls == 1) first = atomicOr(B.framemask + brick, 1u << blockIdx.y) == 0u;
     // Free space: every voxel of the brick gets exactly (+32767, +1).  That is ONE integer add here instead of a 4 KB read +
     // 4 KB write by the update kernel; the counters are folded into the records before anything reads them (fold_free_kernel).
     if (cls == 2) atomicAdd(free_cnt + brick, 1u);
+    const unsigned long long mm = __ballot(cls == 1), mf = __ballot(cls == 2), m1 = __ballot(first);
+    if (lane == 0) { s_cnt[wid][0] = (unsigned)__popcll(mm); s_cnt[wid][1] = (unsigned)__popcll(mf); s_cnt[wid][2] = (unsigned)__popcll(m1); }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const unsigned tot = s_cnt[0][threadIdx.x] + s_cnt[1][threadIdx.x] + s_cnt[2][threadIdx.x] + s_cnt[3][threadIdx.x];
+        unsigned *cur = threadIdx.x < 2 ? F->counts + threadIdx.x : B.hdr;      // [1]: free-space bricks, counted only
+        s_base[threadIdx.x] = tot ? atomicAdd(cur, tot) : 0u;
+    }
+    __syncthreads();
+    unsigned bm = s_base[0], b1 = s_base[2];
+    for (int w = 0; w < wid; ++w) { bm += s_cnt[w][0]; b1 += s_cnt[w][2]; }
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (cls == 1) list[bm + __popcll(mm & below)] = (unsigned)brick;
+    if (first) B.list[b1 + __popcll(m1 & below)] = (unsigned)brick;
 }
 
 // records += count x (32767, 1) for every brick with a pending free-space count; the count returns to zero (exchanged, so a
@@ -350,7 +380,12 @@ __global__ __launch_bounds__(256) void fold_free_kernel(int2 *__restrict__ grid,
 // finish():  depth value -> quantised tsdf + final flag.  Together they are exactly orc_tsdf_integrate's sequence.
 __device__ __forceinline__ bool tsdf_project(const Cam &cam, const TsdfConst &c, float xc, float yc, float zc, int &pix) {
     bool ok = zc > 0.0f;
-    const float inv = 1.0f / zc;
+    // 1 / zc.  v_rcp_f32 + one Newton step equals the IEEE quotient for EVERY float with 2^-126 <= zc < 2^126 (exhaustive:
+    // tools/ubench_rcp.hip, profiles/r03_ubench_rcp.txt); the division proper (~10 instructions) runs only for lanes outside
+    // that range (a voxel centre within 1e-38 m of the camera plane, or absurdly far) -- the value is the oracle's either way.
+    float inv = __builtin_amdgcn_rcpf(zc);
+    inv = fmaf(fmaf(-zc, inv, 1.0f), inv, inv);
+    if (__builtin_expect(!(zc >= 1.17549435e-38f && zc < 8.5e37f), 0)) inv = 1.0f / zc;
     const float uf = fmaf(cam.fx * xc, inv, cam.cx);
     const float vf = fmaf(cam.fy * yc, inv, cam.cy);
     ok = ok && (uf >= -0.5f && uf < c.wlim && vf >= -0.5f && vf < c.hlim);
@@ -371,163 +406,180 @@ __device__ __forceinline__ bool tsdf_finish(const Grid &g, const TsdfConst &c, b
     return ok;
 }
 
-// min / max over the 8 lanes of a group (lane bits 0-2) in three DPP steps, no LDS traffic: quad_perm [1,0,3,2], quad_perm
-// [2,3,0,1], then row_half_mirror (lane i <- lane 7 - i of its 8-lane half: the other quad, which is uniform by then)
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float group8_min(float v) {
-    v = fminf(v, dpp_mov<0xB1>(v));
-    v = fminf(v, dpp_mov<0x4E>(v));
-    return fminf(v, dpp_mov<0x141>(v));
-}
-__device__ __forceinline__ float group8_max(float v) {
-    v = fmaxf(v, dpp_mov<0xB1>(v));
-    v = fmaxf(v, dpp_mov<0x4E>(v));
-    return fmaxf(v, dpp_mov<0x141>(v));
-}
-
-// bits 8 s of a ballot (one per 8-lane group) -> bits s
-__device__ __forceinline__ unsigned group_bits(unsigned long long b) {
-    unsigned m = 0;
+// Class of ONE 4x4x4 sub-brick (the lane's): its 8 extreme voxel centres by the per-voxel position sequence (they span the box
+// of all 64: a projective map keeps convexity while every depth is positive, so all 64 project inside the 8 projections' pixel
+// box), then <= 8 pyramid tiles that cover the box (finest level at which it spans <= 8 tiles).  0 skip, 1 mixed, 2 free.
+__device__ __forceinline__ int classify_subbrick(const Cam &cam, const Grid &g, const Pyramid &py, const PoseF &pose,
+                                                 const float4 *__restrict__ tiles, int i0, int j0, int k0) {
+    float wx[2], wy[2], wz[2];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) m |= (unsigned)((b >> (8 * s)) & 1ull) << s;
-    return m;
-}
-
-// Classes of the eight 4x4x4 sub-bricks of brick (bx, by, bz) in one frame: bit s of `mixed` / `free_` (sub-brick s =
-// (x >> 2) | (y >> 2) << 1 | (z >> 2) << 2; neither bit: skip).  Lane l handles extreme voxel centre l & 7 of sub-brick l >> 3
-// with the per-voxel position sequence (the 8 extreme centres span the box of all 64: a projective map keeps convexity while
-// every depth is positive, so all 64 project inside the 8 projections' pixel box), then the 8 lanes of a sub-brick share
-// <= 8 pyramid tiles that cover the box (finest level at which it spans <= 8 tiles).
-__device__ __forceinline__ void classify_subbricks(const Cam &cam, const Grid &g, const Pyramid &py, const PoseF &pose,
-                                                   const float4 *__restrict__ tiles, int bx, int by, int bz, int lane, unsigned &mixed,
-                                                   unsigned &free_) {
-    const int s = lane >> 3, cn = lane & 7;
-    const int i = bx * 8 + (s & 1) * 4 + ((cn & 1) ? 3 : 0);
-    const int j = by * 8 + ((s >> 1) & 1) * 4 + ((cn & 2) ? 3 : 0);
-    const int k = bz * 8 + (s >> 2) * 4 + ((cn & 4) ? 3 : 0);
-    const float px = fmaf((float)i + 0.5f, g.vs, g.ox), py_ = fmaf((float)j + 0.5f, g.vs, g.oy), pz = fmaf((float)k + 0.5f, g.vs, g.oz);
-    const float x = fmaf(pose.r[0], px, fmaf(pose.r[1], py_, fmaf(pose.r[2], pz, pose.t[0])));
-    const float y = fmaf(pose.r[3], px, fmaf(pose.r[4], py_, fmaf(pose.r[5], pz, pose.t[1])));
-    const float z = fmaf(pose.r[6], px, fmaf(pose.r[7], py_, fmaf(pose.r[8], pz, pose.t[2])));
-    const float zmin = group8_min(z), zmax = group8_max(z);
-    int cls = 1;
-    if (zmin > 1e-3f) {
-        const float iz = __builtin_amdgcn_rcpf(z);                 // 1 ulp; the 1.5 px margin absorbs it
-        const float u = cam.fx * x * iz + cam.cx, v = cam.fy * y * iz + cam.cy;
-        const float umin = group8_min(u) - 1.5f, umax = group8_max(u) + 1.5f;
-        const float vmin = group8_min(v) - 1.5f, vmax = group8_max(v) + 1.5f;
-        if (umax < 0.0f || vmax < 0.0f || umin > (float)(cam.W - 1) || vmin > (float)(cam.H - 1)) {
-            cls = 0;
-        } else {
-            const bool inside = umin >= 0.0f && vmin >= 0.0f && umax <= (float)(cam.W - 1) && vmax <= (float)(cam.H - 1);
-            const int pu0 = max(0, (int)floorf(umin)), pu1 = min(cam.W - 1, (int)ceilf(umax));
-            const int pv0 = max(0, (int)floorf(vmin)), pv1 = min(cam.H - 1, (int)ceilf(vmax));
-            // finest level at which the box spans at most 8 tiles; level geometry by arithmetic (no table lookups per lane)
-            int L = 0, off = 0, ntx = py.ntx[0], nty = py.nty[0];
-            int tu0, tv0, nu, nv;
-            for (;;) {
-                tu0 = pu0 >> (TILE0_SHIFT + L); tv0 = pv0 >> (TILE0_SHIFT + L);
-                nu = (pu1 >> (TILE0_SHIFT + L)) - tu0 + 1; nv = (pv1 >> (TILE0_SHIFT + L)) - tv0 + 1;
-                if (nu * nv <= 8 || L >= py.nlev - 1) break;
-                off += ntx * nty;
-                ntx = (ntx + 1) >> 1; nty = (nty + 1) >> 1;
-                ++L;
+    for (int h = 0; h < 2; ++h) {
+        wx[h] = fmaf((float)(i0 + 3 * h) + 0.5f, g.vs, g.ox);
+        wy[h] = fmaf((float)(j0 + 3 * h) + 0.5f, g.vs, g.oy);
+        wz[h] = fmaf((float)(k0 + 3 * h) + 0.5f, g.vs, g.oz);
+    }
+    float x[8], y[8], z[8];
+    float zmin = INFINITY, zmax = -INFINITY;
+#pragma unroll
+    for (int hz = 0; hz < 2; ++hz) {
+        const float ax0 = fmaf(pose.r[2], wz[hz], pose.t[0]), ay0 = fmaf(pose.r[5], wz[hz], pose.t[1]), az0 = fmaf(pose.r[8], wz[hz], pose.t[2]);
+#pragma unroll
+        for (int hy = 0; hy < 2; ++hy) {
+            const float ax = fmaf(pose.r[1], wy[hy], ax0), ay = fmaf(pose.r[4], wy[hy], ay0), az = fmaf(pose.r[7], wy[hy], az0);
+#pragma unroll
+            for (int hx = 0; hx < 2; ++hx) {
+                const int c = hz * 4 + hy * 2 + hx;
+                x[c] = fmaf(pose.r[0], wx[hx], ax);
+                y[c] = fmaf(pose.r[3], wx[hx], ay);
+                z[c] = fmaf(pose.r[6], wx[hx], az);
+                zmin = fminf(zmin, z[c]);
+                zmax = fmaxf(zmax, z[c]);
             }
-            const int q = cn < nu * nv ? cn : 0;
-            const int qr = (int)(((float)q + 0.5f) * __builtin_amdgcn_rcpf((float)nu));      // q / nu for 0 <= q < 8, 1 <= nu <= 8
-            const float4 b = tiles[off + (tv0 + qr) * ntx + (tu0 + (q - qr * nu))];
-            const float4 a = make_float4(group8_min(b.x), group8_max(b.y), group8_min(b.z), 0.0f);
-            cls = classify_box(g, a, zmin, zmax, inside);
         }
     }
-    mixed = group_bits(__ballot(cls == 1));
-    free_ = group_bits(__ballot(cls == 2));
+    if (!(zmin > 1e-3f)) return 1;                                  // touches the camera plane: per-voxel rule decides
+    float umin = INFINITY, umax = -INFINITY, vmin = INFINITY, vmax = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float iz = __builtin_amdgcn_rcpf(z[c]);                // 1 ulp; the 1.5 px margin absorbs it
+        const float u = cam.fx * x[c] * iz + cam.cx, v = cam.fy * y[c] * iz + cam.cy;
+        umin = fminf(umin, u); umax = fmaxf(umax, u);
+        vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
+    }
+    umin -= 1.5f; umax += 1.5f; vmin -= 1.5f; vmax += 1.5f;
+    if (umax < 0.0f || vmax < 0.0f || umin > (float)(cam.W - 1) || vmin > (float)(cam.H - 1)) return 0;
+    const bool inside = umin >= 0.0f && vmin >= 0.0f && umax <= (float)(cam.W - 1) && vmax <= (float)(cam.H - 1);
+    const int pu0 = max(0, (int)floorf(umin)), pu1 = min(cam.W - 1, (int)ceilf(umax));
+    const int pv0 = max(0, (int)floorf(vmin)), pv1 = min(cam.H - 1, (int)ceilf(vmax));
+    // finest level at which the box spans at most 8 tiles; level geometry by arithmetic (no table lookups per lane)
+    int L = 0, off = 0, ntx = py.ntx[0], nty = py.nty[0];
+    int tu0, tv0, nu, nv;
+    for (;;) {
+        tu0 = pu0 >> (TILE0_SHIFT + L); tv0 = pv0 >> (TILE0_SHIFT + L);
+        nu = (pu1 >> (TILE0_SHIFT + L)) - tu0 + 1; nv = (pv1 >> (TILE0_SHIFT + L)) - tv0 + 1;
+        if (nu * nv <= 8 || L >= py.nlev - 1) break;
+        off += ntx * nty;
+        ntx = (ntx + 1) >> 1; nty = (nty + 1) >> 1;
+        ++L;
+    }
+    const float4 *__restrict__ lv = tiles + off;
+    float4 a = make_float4(INFINITY, -INFINITY, 1.0f, 0.0f);
+    int du = 0, dv = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {                                   // tiles (du, dv) row by row; beyond the box: the last one again (harmless)
+        const float4 b = lv[(tv0 + dv) * ntx + (tu0 + du)];
+        a.x = fminf(a.x, b.x);
+        a.y = fmaxf(a.y, b.y);
+        a.z = fminf(a.z, b.z);
+        if (du + 1 < nu) ++du;
+        else if (dv + 1 < nv) { du = 0; ++dv; }
+    }
+    return classify_box(g, a, zmin, zmax, inside);
 }
 
-// Prep kernel 4: sub-brick masks of the listed bricks, one wave per brick; and, for the second frame of a prepared pair
-// (blockIdx.y == 1, pair != 0), the compact list of its bricks that the first frame does not list (lane-parallel scan of the
-// list, one atomic per workgroup).  Runs behind brick_cull_kernel of BOTH frames on the same stream.
-__global__ __launch_bounds__(256) void subbrick_classify_kernel(Cam cam, Grid g, Pyramid py, PrepFrames P, int pair) {
-    const PrepFrame &F = P.f[blockIdx.y];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+// Prep kernel 4: sub-brick masks of the listed bricks of every frame; one lane per sub-brick, 8 bricks per wave.
+__global__ __launch_bounds__(256) void subbrick_classify_kernel(Cam cam, Grid g, Pyramid py, BatchBufs B) {
+    const DescPtr F = const_descs(B) + blockIdx.y;
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const unsigned nbricks = (unsigned)(g.nbx * g.nby * g.nbz);
-    const unsigned n = min(F.list_counts[0], nbricks);
-    if (pair && blockIdx.y == 1) {
-        __shared__ unsigned s_cnt[4], s_base;
-        const unsigned char *__restrict__ cls_prev = P.f[0].cls;
-        for (unsigned t0 = blockIdx.x * 256u; t0 < n; t0 += gridDim.x * 256u) {
-            const unsigned t = t0 + threadIdx.x;
-            unsigned brick = 0;
-            bool solo = false;
-            if (t < n) {
-                brick = min(F.list[t], nbricks - 1u);
-                solo = cls_prev[brick] != 1;
-            }
-            const unsigned long long m = __ballot(solo);
-            if (lane == 0) s_cnt[wid] = (unsigned)__popcll(m);
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                const unsigned tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-                s_base = tot ? atomicAdd(F.list_counts + 2, tot) : 0u;
-            }
-            __syncthreads();
-            unsigned base = s_base;
-            for (int w = 0; w < wid; ++w) base += s_cnt[w];
-            if (solo) F.solo[base + __popcll(m & ((1ull << lane) - 1ull))] = brick;
-            __syncthreads();
+    const unsigned n = min(F->counts[0], nbricks);
+    const PoseF pose = desc_pose(F);
+    const float4 *__restrict__ tiles = F->tiles;
+    const unsigned *__restrict__ list = F->list;
+    unsigned short *__restrict__ sub = F->sub;
+    const int j = lane >> 3, sb = lane & 7;
+    for (unsigned base = (blockIdx.x * 4u + (unsigned)wid) * 8u; base < n; base += gridDim.x * 32u) {
+        const unsigned t = base + (unsigned)j;
+        int cls = 0;
+        unsigned brick = 0;
+        if (t < n) {
+            brick = min(list[t], nbricks - 1u);
+            const int bx = (int)(brick % (unsigned)g.nbx), by = (int)((brick / (unsigned)g.nbx) % (unsigned)g.nby), bz = (int)(brick / (unsigned)(g.nbx * g.nby));
+            cls = classify_subbrick(cam, g, py, pose, tiles, bx * 8 + (sb & 1) * 4, by * 8 + ((sb >> 1) & 1) * 4, bz * 8 + (sb >> 2) * 4);
         }
-    }
-    for (unsigned t = blockIdx.x * 4u + wid; t < n; t += gridDim.x * 4u) {
-        const unsigned brick = min((unsigned)__builtin_amdgcn_readfirstlane((int)F.list[t]), nbricks - 1u);
-        const int bx = (int)(brick % (unsigned)g.nbx), by = (int)((brick / (unsigned)g.nbx) % (unsigned)g.nby), bz = (int)(brick / (unsigned)(g.nbx * g.nby));
-        unsigned mixed, free_;
-        classify_subbricks(cam, g, py, F.pose, F.tiles, bx, by, bz, lane, mixed, free_);
-        if (lane == 0) F.sub[brick] = (unsigned short)(mixed | (free_ << 8));
+        const unsigned long long mm = __ballot(cls == 1), mf = __ballot(cls == 2);
+        if (sb == 0 && t < n) sub[brick] = (unsigned short)(((mm >> (8 * j)) & 0xffull) | (((mf >> (8 * j)) & 0xffull) << 8));
     }
 }
 
-// One frame (NF = 1) or two consecutive frames (NF = 2) per visit of a brick.  The gathers are per frame; the records need
-// not be: a brick that both frames see near a surface is read and written ONCE for both (integer sums: the same grid bit for
-// bit).  Tasks = frame A's MIXED list, then frame B's; a brick of A's list that is MIXED in B too (B's class map) takes both
-// frames' gathers before its one read-modify-write; a brick of B's list that was on A's is skipped.
-// EXP (experiments flavour of the library only; results incomplete): bit 0 no depth gathers, bit 1 no record accesses, bit 2 no
-// sub-brick classification (every sub-brick of a listed brick is treated as MIXED)
-template <bool COUNT, int NF, typename DT, int EXP = 0>
-__global__ __launch_bounds__(256) void tsdf_update_kernel(Cam cam, Grid g, UpdFrame A, UpdFrame B, int xcd_group,
-                                                          int2 *__restrict__ grid, unsigned long long *__restrict__ counters) {
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+// ---- 5. the update: one launch per batch ---------------------------------------------------------------------------------
+// A wave takes one brick of the batch list per trip.  For every frame whose bit is set in the brick's frame mask it projects the
+// lane's voxel of each MIXED sub-brick, gathers the depth values (all gathers of a frame back to back) and adds the quantised
+// tsdf to the lane's eight running sums; FREE sub-bricks add (32767, 1).  The frame loop is software-pipelined two deep: the
+// gathers of the next frame are in flight while the current frame's values are turned into increments.  After the last frame
+// the records that changed are read, added to and written: once per batch, whatever the number of frames.
+// EXP (experiments flavour of the library only; results incomplete): bit 0 no depth gathers, bit 1 no record accesses.
+template <typename DT> struct RawDepth { typedef float type; };
+template <> struct RawDepth<uint16_t> { typedef unsigned short type; };
+__device__ __forceinline__ float depth_value(float raw) { return raw; }
+__device__ __forceinline__ float depth_value(unsigned short raw) { return mm_to_m(raw); }
+
+template <typename DT>
+struct GatherState {            // one frame's gathers of one brick, in flight
+    float zc[8];
+    typename RawDepth<DT>::type dv[8];   // as loaded: nothing touches a value before finish() (the gathers stay in flight)
+    unsigned okm, m, fr;        // lanes' "could update" bits per sub-brick; the frame's MIXED and FREE sub-brick masks (wave-uniform)
+    TsdfConst c;
+};
+
+template <bool COUNT, typename DT, int EXP = 0>
+__global__ __launch_bounds__(256) void tsdf_update_kernel(Cam cam, Grid g, BatchBufs B, int xcd_group, int2 *__restrict__ grid,
+                                                          unsigned long long *__restrict__ counters) {
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // wave-uniform, and known to be
     const unsigned nbricks = (unsigned)(g.nbx * g.nby * g.nbz);
-    // the trip counts come from device memory: clamp them to what a list can hold, so that no ordering mistake upstream can
+    // the trip count comes from device memory: clamp it to what the list can hold, so that no ordering mistake upstream can
     // ever turn into an unbounded loop or an out-of-range list read
-    const unsigned nA = min(A.counts[0], nbricks), nB = NF == 2 ? min(B.counts[2], nbricks) : 0u;      // B: its solo list
+    const unsigned ntask = min(B.hdr[0], nbricks);
     unsigned nread = 0, nwritten = 0;
-    // Blocks with the same blockIdx % 8 share an XCD and its L2 (a placement habit of the dispatcher: a speed choice, never
-    // a correctness one).  Each such group takes one contiguous eighth of BOTH lists -- the classification emits bricks in
-    // grid order, so an eighth is a slab of the volume and its depth lookups stay in one region of the image
-    const bool grouped = XCD_GROUPS > 1 && (gridDim.x % XCD_GROUPS) == 0 && xcd_group != 0;
-    const unsigned ngrp = grouped ? XCD_GROUPS : 1u;
-    const unsigned grp = grouped ? blockIdx.x % XCD_GROUPS : 0u, bi = grouped ? blockIdx.x / XCD_GROUPS : blockIdx.x;
-    const unsigned perA = (nA + ngrp - 1u) / ngrp, perB = (nB + ngrp - 1u) / ngrp;
-    const unsigned a_beg = min(nA, grp * perA), a_len = min(nA, a_beg + perA) - a_beg;
-    const unsigned b_beg = min(nB, grp * perB), b_len = min(nB, b_beg + perB) - b_beg;
-    const unsigned lstep = (gridDim.x / ngrp) * 4u;
-    const DT *__restrict__ depthA = static_cast<const DT *>(A.depth);
-    const DT *__restrict__ depthB = static_cast<const DT *>(B.depth);
+    // Work distribution.  A brick costs one trip of the frame loop per frame that lists it (1 .. 32), so a static share of the
+    // list leaves waves idle for a third of the launch.  Tasks are handed out by TICKET instead: the workgroups form up to 64
+    // groups (blockIdx % groups), group g owns list entries g, g + groups, g + 2 groups, ... (every group sees the same mix of
+    // cheap and dear bricks) and a ticket counter of its own (64-B apart; a few hundred returning atomics per counter and
+    // launch, handed out two tasks ahead of their use, so nobody waits for one).  A wave's first task needs no ticket.
+    const unsigned ngrp = min((unsigned)TICKET_GROUPS, gridDim.x);
+    const unsigned grp = blockIdx.x % ngrp, bi = blockIdx.x / ngrp;
+    const unsigned waves_in_group = ((gridDim.x - grp + ngrp - 1u) / ngrp) * 4u;
+    unsigned *__restrict__ ticket = B.hdr + HDR_TICKETS + 16u * grp;
+    // A group's sequence runs over chunks of `chunk` consecutive list entries (the bricks of one 4x4x4 cell are listed together
+    // and look at the same pixels): group g owns chunks g, g + groups, ...; its workgroups share an XCD (blockIdx % 8), so a
+    // chunk's depth lines meet in one L2
+    const unsigned chunk = xcd_group > 0 ? (unsigned)xcd_group : 1u;
+    auto entry_of = [&](unsigned k) -> unsigned {               // k-th task of this group -> list position (saturating)
+        if (k >= 0x2000000u) return 0xffffffffu;
+        return ((k / chunk) * ngrp + grp) * chunk + k % chunk;
+    };
+    const DescPtr frames = const_descs(B);
 
-    // mA / fA / mB / fB: the brick's MIXED and FREE sub-brick masks in frame A and B (wave-uniform; zero for a frame that does
-    // not list the brick)
-    auto process = [&](unsigned brick, unsigned mA, unsigned fA, unsigned mB, unsigned fB) {
-        const int bx = (int)(brick % (unsigned)g.nbx), by = (int)((brick / (unsigned)g.nbx) % (unsigned)g.nby), bz = (int)(brick / (unsigned)(g.nbx * g.nby));
-        if (EXP & 4) {
-            if (mA | fA) { mA = 0xffu; fA = 0u; }
-            if (mB | fB) { mB = 0xffu; fB = 0u; }
+    // the next brick of this wave, its frame mask and (lane f) its sub-brick masks in frame f: fetched one trip ahead
+    auto fetch = [&](unsigned t, unsigned &brick, unsigned &fm, unsigned &subv) {
+        brick = min((unsigned)__builtin_amdgcn_readfirstlane((int)B.list[t]), nbricks - 1u);
+        fm = (unsigned)__builtin_amdgcn_readfirstlane((int)B.framemask[brick]);
+        subv = 0u;
+        if (lane < B.n_frames && ((fm >> lane) & 1u)) subv = frames[lane].sub[brick];
+    };
+
+    auto take_ticket = [&]() -> unsigned {                      // position in the group's sequence of the task after next
+        unsigned k = 0;
+        if (lane == 0) k = atomicAdd(ticket, 1u);
+        return (unsigned)__builtin_amdgcn_readfirstlane((int)k) + waves_in_group;
+    };
+    unsigned t = entry_of(bi * 4u + (unsigned)wid);                // list entry of this trip
+    unsigned brick_n = 0, fm_n = 0, subv_n = 0;
+    if (t < ntask) fetch(t, brick_n, fm_n, subv_n);
+    unsigned k_next = t < ntask ? take_ticket() : 0u;             // the entry after this one: its ticket is drawn a trip ahead of its fetch
+    while (t < ntask) {
+        const unsigned brick = brick_n, subv = subv_n;
+        unsigned fm = fm_n;
+        if (lane == 0) B.framemask[brick] = 0u;                       // re-armed for the next batch that uses this buffer
+        // saturating: a ticket far beyond the list must not wrap into it
+        const unsigned t_next = entry_of(k_next);
+        if (t_next < ntask) {
+            fetch(t_next, brick_n, fm_n, subv_n);
+            k_next = take_ticket();
         }
-        const unsigned any = mA | fA | mB | fB;
-        if (any == 0u) return;
-        int2 *__restrict__ recs = grid + ((size_t)brick << 9);
+        t = t_next;
+        if (B.n_frames < 32) fm &= (1u << B.n_frames) - 1u;
+        const int bx = (int)(brick % (unsigned)g.nbx), by = (int)((brick / (unsigned)g.nbx) % (unsigned)g.nby), bz = (int)(brick / (unsigned)(g.nbx * g.nby));
         // the lane's voxel in sub-brick s: (x, y, z) = (4 (s & 1) + (lane & 3), 4 (s >> 1 & 1) + (lane >> 2 & 3), 4 (s >> 2) + (lane >> 4)),
         // record s * 64 + lane; world coordinates: two values per axis
         float wx[2], wy[2], wz[2];
@@ -537,17 +589,23 @@ __global__ __launch_bounds__(256) void tsdf_update_kernel(Cam cam, Grid g, UpdFr
             wy[h] = fmaf((float)(by * 8 + 4 * h + ((lane >> 2) & 3)) + 0.5f, g.vs, g.oy);
             wz[h] = fmaf((float)(bz * 8 + 4 * h + (lane >> 4)) + 0.5f, g.vs, g.oz);
         }
-        // phase 1: project the lane's voxel of every MIXED sub-brick of every frame, issue all depth gathers back to back
-        float zc[NF][8], dv[NF][8];
-        unsigned okm[NF];
+        // running sums of the lane's eight voxels, packed: bits 0-20 sum of (q + 32768) (<= 32 x 65535 < 2^21), bits 21-26 weight
+        unsigned acc[8];
 #pragma unroll
-        for (int f = 0; f < NF; ++f) {
-            okm[f] = 0u;
-            const unsigned m = f ? mB : mA;
-            if (m == 0u) continue;
-            const PoseF &pose = f ? B.pose : A.pose;
-            const TsdfConst &c = f ? B.c : A.c;
-            const DT *__restrict__ depth = f ? depthB : depthA;
+        for (int s = 0; s < 8; ++s) acc[s] = 0u;
+        unsigned touched = 0u;                                      // sub-bricks any frame adds to (wave-uniform)
+
+        // project the lane's voxel of every MIXED sub-brick of frame f and issue the depth gathers
+        // -- ALWAYS eight loads, so that the number of loads in flight is known where the previous frame's values are awaited
+        // (a count that depended on the masks would turn every wait into "all loads", the new gathers included); a sub-brick
+        // that is not MIXED loads pixel 0 in every lane: one cache line, one tag look-up per quad
+        auto issue = [&](int f, GatherState<DT> &S) {
+            const unsigned sm = (unsigned)__builtin_amdgcn_readlane((int)subv, f);
+            S.m = sm & 0xffu; S.fr = sm >> 8; S.okm = 0u;
+            touched |= S.m | S.fr;
+            const PoseF pose = desc_pose(frames + f);
+            S.c = desc_const(frames + f);
+            const DT *__restrict__ depth = static_cast<const DT *>(frames[f].depth);
             float ax[2][2], ay[2][2], az[2][2];                    // [z half][y half]: the two inner fma levels of the position chain
 #pragma unroll
             for (int hz = 0; hz < 2; ++hz)
@@ -559,81 +617,68 @@ __global__ __launch_bounds__(256) void tsdf_update_kernel(Cam cam, Grid g, UpdFr
                 }
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
-                if (!((m >> s) & 1u)) continue;
-                const float xc = fmaf(pose.r[0], wx[s & 1], ax[s >> 2][(s >> 1) & 1]);
-                const float yc = fmaf(pose.r[3], wx[s & 1], ay[s >> 2][(s >> 1) & 1]);
-                zc[f][s] = fmaf(pose.r[6], wx[s & 1], az[s >> 2][(s >> 1) & 1]);
-                int pix;
-                if (tsdf_project(cam, c, xc, yc, zc[f][s], pix)) okm[f] |= 1u << s;
-                dv[f][s] = (EXP & 1) ? 1.0f + 1e-6f * (float)(pix & 1023) : ld_depth(depth, (size_t)pix);
+                int pix = 0;
+                S.zc[s] = 0.0f;
+                if ((S.m >> s) & 1u) {
+                    const float xc = fmaf(pose.r[0], wx[s & 1], ax[s >> 2][(s >> 1) & 1]);
+                    const float yc = fmaf(pose.r[3], wx[s & 1], ay[s >> 2][(s >> 1) & 1]);
+                    S.zc[s] = fmaf(pose.r[6], wx[s & 1], az[s >> 2][(s >> 1) & 1]);
+                    if (tsdf_project(cam, S.c, xc, yc, S.zc[s], pix)) S.okm |= 1u << s;
+                }
+                if (EXP & 1) S.dv[s] = (typename RawDepth<DT>::type)(1 + (pix & 1023));
+                else S.dv[s] = depth[pix];
             }
-        }
-        // phase 2: decide; a FREE sub-brick adds (32767, 1) to every one of its voxels
-        int qs[8], ws[8];
+        };
+        // depth values -> increments
+        auto finish = [&](const GatherState<DT> &S) {
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            qs[s] = 0; ws[s] = 0;
-#pragma unroll
-            for (int f = 0; f < NF; ++f) {
-                const unsigned m = f ? mB : mA, fr = f ? fB : fA;
-                if ((m >> s) & 1u) {
+            for (int s = 0; s < 8; ++s) {
+                if ((S.m >> s) & 1u) {
                     int q;
-                    if (tsdf_finish(g, f ? B.c : A.c, (okm[f] >> s) & 1u, dv[f][s], zc[f][s], q)) { qs[s] += q; ws[s] += 1; }
-                } else if ((fr >> s) & 1u) {
-                    qs[s] += 32767; ws[s] += 1;
+                    if (tsdf_finish(g, S.c, (S.okm >> s) & 1u, depth_value(S.dv[s]), S.zc[s], q)) acc[s] += (unsigned)(q + 32768) + (1u << 21);
+                } else if ((S.fr >> s) & 1u) {
+                    acc[s] += 65535u + (1u << 21);
+                }
+            }
+        };
+        if (EXP & 4) {                                          // experiments: one frame at a time, no software pipeline
+            GatherState<DT> S0;
+            for (unsigned rest = fm; rest; rest &= rest - 1u) {
+                issue(__builtin_ctz(rest), S0);
+                finish(S0);
+            }
+        } else {
+            GatherState<DT> S0, S1;
+            unsigned rest = fm;
+            if (rest) {
+                int f = __builtin_ctz(rest);
+                rest &= rest - 1u;
+                issue(f, S0);
+                for (;;) {
+                    if (rest) { f = __builtin_ctz(rest); rest &= rest - 1u; issue(f, S1); } else { finish(S0); break; }
+                    finish(S0);
+                    if (rest) { f = __builtin_ctz(rest); rest &= rest - 1u; issue(f, S0); } else { finish(S1); break; }
+                    finish(S1);
                 }
             }
         }
-        // phase 3: load the records that change (8 B per lane, a sub-brick = one 512-B run); phase 4: add and store them
-        // (experiments, EXP bits 3-4: which lanes move a record -- 0: the lanes whose voxel changes; 8: all 64 lanes of a sub-brick in
-        //  which any voxel changes; 16: all 16 lanes of a 128-B line in which any voxel changes)
-        constexpr int RMW = (EXP >> 3) & 3;
+        if (touched == 0u) continue;
+        // load the records that change (8 B per lane, a sub-brick = one 512-B run), add, store
+        int2 *__restrict__ recs = grid + ((size_t)brick << 9);
         int2 rec[8];
-        bool mv[8];
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            mv[s] = false;
-            if (!((any >> s) & 1u)) continue;
-            if (RMW == 0) mv[s] = ws[s] != 0;
-            else {
-                const unsigned long long bal = __ballot(ws[s] != 0);
-                mv[s] = RMW == 1 ? bal != 0ull : ((bal >> (lane & 48)) & 0xffffull) != 0ull;
-            }
-            if (mv[s]) rec[s] = (EXP & 2) ? make_int2(qs[s] ^ lane, s) : recs[s * 64 + lane];
-        }
 #pragma unroll
         for (int s = 0; s < 8; ++s)
-            if (mv[s]) {
-                rec[s].x += qs[s];
-                rec[s].y += ws[s];
+            if (((touched >> s) & 1u) && (acc[s] >> 21)) rec[s] = (EXP & 2) ? make_int2((int)acc[s] ^ lane, s) : recs[s * 64 + lane];
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+            if (((touched >> s) & 1u) && (acc[s] >> 21)) {
+                const int w = (int)(acc[s] >> 21);
+                rec[s].x += (int)(acc[s] & 0x1fffffu) - 32768 * w;
+                rec[s].y += w;
                 if (EXP & 2) { if (rec[s].x == cam.W * 7919 + lane) recs[0] = rec[s]; }      // keep the values alive, (practically) never store
                 else recs[s * 64 + lane] = rec[s];
                 if (COUNT) { nread += 1; nwritten += 1; }
             }
-    };
-    // one list entry per wave and trip, A's list then B's solo list; the entry of the NEXT trip (brick, its sub-brick masks and,
-    // for A's entries, its class and masks in frame B) is fetched before this trip's brick is processed
-    {
-        const unsigned ntot = a_len + b_len;
-        auto fetch = [&](unsigned t, unsigned &brick, unsigned &sa, unsigned &sb) {
-            const bool fromA = t < a_len;
-            brick = min((unsigned)__builtin_amdgcn_readfirstlane((int)(fromA ? A.list[a_beg + t] : B.list[b_beg + (t - a_len)])), nbricks - 1u);
-            sa = fromA ? (unsigned)__builtin_amdgcn_readfirstlane((int)A.sub[brick]) : 0u;
-            sb = 0u;
-            if (NF == 2) {
-                const bool listedB = fromA ? __builtin_amdgcn_readfirstlane((int)B.cls[brick]) == 1 : true;
-                const unsigned v = (unsigned)__builtin_amdgcn_readfirstlane((int)B.sub[brick]);
-                sb = listedB ? v : 0u;
-            }
-        };
-        unsigned t = bi * 4u + wid;
-        unsigned brick_n = 0, sa_n = 0, sb_n = 0;
-        if (t < ntot) fetch(t, brick_n, sa_n, sb_n);
-        for (; t < ntot; t += lstep) {
-            const unsigned brick = brick_n, sa = sa_n, sb = sb_n;
-            if (t + lstep < ntot) fetch(t + lstep, brick_n, sa_n, sb_n);
-            process(brick, sa & 0xffu, sa >> 8, sb & 0xffu, sb >> 8);
-        }
     }
     if (COUNT) {
 #pragma unroll
@@ -647,17 +692,14 @@ __global__ __launch_bounds__(256) void tsdf_update_kernel(Cam cam, Grid g, UpdFr
         }
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             unsigned long long vis = 0, fre = 0;
-            {
-                const unsigned f = min(A.counts[1], nbricks - nA);
-                vis += nA + f; fre += f;
-            }
-            if (NF == 2) {
-                const unsigned lb = min(B.counts[0], nbricks), f = min(B.counts[1], nbricks - lb);
-                vis += lb + f; fre += f;
+            for (int f = 0; f < B.n_frames; ++f) {
+                const unsigned l = min(frames[f].counts[0], nbricks), fc = min(frames[f].counts[1], nbricks - l);
+                vis += l + fc; fre += fc;
             }
             atomicAdd(counters + 4, vis);
             atomicAdd(counters + 5, fre);
             atomicAdd(counters + 6, fre);
+            atomicAdd(counters + 7, (unsigned long long)ntask);
         }
     }
 }
@@ -680,34 +722,38 @@ static Pyramid make_pyramid(const Cam &cam) {
 
 static size_t pyramid_tiles(const Pyramid &p) { return (size_t)p.off[p.nlev - 1] + (size_t)p.ntx[p.nlev - 1] * p.nty[p.nlev - 1]; }
 
-size_t tsdf_scratch_bytes(const Cam &cam, const Grid &g) {
+static size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// Scratch of ONE batch in flight (the context keeps two and alternates):
+//   [descriptors (max_frames)] [header 256 B] [batch list] [frame masks] then per frame [counts 256 B] [tile pyramid] [list] [sub-brick masks]
+struct BatchLayout {
+    size_t off_desc, off_hdr, off_list, off_mask, off_frames, per_frame, f_counts, f_tiles, f_list, f_sub, total;
+};
+static BatchLayout batch_layout(const Cam &cam, const Grid &g, int max_frames) {
     const Pyramid p = make_pyramid(cam);
     const size_t nbricks = (size_t)g.nbx * g.nby * g.nbz;
-    return 256 + pyramid_tiles(p) * sizeof(float4) + 2 * (nbricks + 64) * sizeof(unsigned) + ((nbricks + 255) & ~(size_t)255) +
-           ((nbricks * sizeof(unsigned short) + 255) & ~(size_t)255);
+    BatchLayout L;
+    L.off_desc = 0;
+    L.off_hdr = up256((size_t)max_frames * sizeof(FrameDesc));
+    L.off_list = L.off_hdr + up256(HDR_WORDS * sizeof(unsigned));
+    L.off_mask = L.off_list + up256((nbricks + 64) * sizeof(unsigned));
+    L.off_frames = L.off_mask + up256(nbricks * sizeof(unsigned));
+    L.f_counts = 0;
+    L.f_tiles = 256;
+    L.f_list = L.f_tiles + up256(pyramid_tiles(p) * sizeof(float4));
+    L.f_sub = L.f_list + up256((nbricks + 64) * sizeof(unsigned));
+    L.per_frame = L.f_sub + up256(nbricks * sizeof(unsigned short));
+    L.total = L.off_frames + L.per_frame * (size_t)max_frames;
+    return L;
 }
 
-struct TsdfScratch {
-    unsigned *list_counts;       // [0] mixed (listed), [1] free (counted)
-    float4 *tiles;
-    unsigned *list, *solo;
-    unsigned char *cls;          // [nbricks] class of every brick (0 skip, 1 mixed, 2 free)
-    unsigned short *sub;         // [nbricks] sub-brick masks of the listed bricks
-    Pyramid py;
-};
+size_t tsdf_batch_scratch_bytes(const Cam &cam, const Grid &g, int max_frames) { return batch_layout(cam, g, max_frames).total; }
 
-static TsdfScratch carve(const Cam &cam, const Grid &g, void *scratch) {
-    TsdfScratch t;
-    t.py = make_pyramid(cam);
-    // scratch layout: [list_counts (256 B)] [tile pyramid] [brick list] [solo list] [brick classes] [sub-brick masks]
-    const size_t nbricks = (size_t)g.nbx * g.nby * g.nbz;
-    t.list_counts = reinterpret_cast<unsigned *>(scratch);
-    t.tiles = reinterpret_cast<float4 *>(reinterpret_cast<char *>(scratch) + 256);
-    t.list = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(scratch) + 256 + pyramid_tiles(t.py) * sizeof(float4));
-    t.solo = t.list + (nbricks + 64);
-    t.cls = reinterpret_cast<unsigned char *>(t.solo + (nbricks + 64));
-    t.sub = reinterpret_cast<unsigned short *>(t.cls + ((nbricks + 255) & ~(size_t)255));
-    return t;
+// bytes of a batch scratch that must be zero before its first use (the frame masks; the update kernel re-arms them)
+void tsdf_batch_scratch_zero_range(const Cam &cam, const Grid &g, int max_frames, size_t *off, size_t *bytes) {
+    const BatchLayout L = batch_layout(cam, g, max_frames);
+    *off = L.off_mask;
+    *bytes = L.off_frames - L.off_mask;
 }
 
 static TsdfConst make_const(const Cam &cam, float scale, float mind, float maxd) {
@@ -720,44 +766,66 @@ static TsdfConst make_const(const Cam &cam, float scale, float mind, float maxd)
     return c;
 }
 
-// depth tiles + pyramid + brick classification + sub-brick masks -> compact brick list in scratch, for one frame or for two
-// in the same four launches (n = 2: both depth images of one kind; the second frame then also gets its solo list and may be
-// updated together with the first)
-int launch_tsdf_prepare(hipStream_t s, const Cam &cam, const Grid &g, int n, const PoseF *p, const Frustum &fr, const void *const *depth,
-                        bool depth_u16, const float *scale, float mind, float maxd, void *const *scratch, unsigned *free_cnt) {
-    PrepFrames P;
-    memset(&P, 0, sizeof(P));
-    Pyramid py = make_pyramid(cam);
+static BatchBufs batch_bufs(const BatchLayout &L, void *scratch, int n) {
+    char *base = static_cast<char *>(scratch);
+    BatchBufs B;
+    B.frames = reinterpret_cast<const FrameDesc *>(base + L.off_desc);
+    B.hdr = reinterpret_cast<unsigned *>(base + L.off_hdr);
+    B.list = reinterpret_cast<unsigned *>(base + L.off_list);
+    B.framemask = reinterpret_cast<unsigned *>(base + L.off_mask);
+    B.n_frames = n;
+    return B;
+}
+
+// The whole prep of a batch of n frames (one depth kind) on stream s: descriptor upload, depth tiles, pyramid, brick
+// classification, sub-brick masks.  `scratch` is a batch scratch of at least n frames (tsdf_batch_scratch_bytes).
+int launch_tsdf_prepare(hipStream_t s, const Cam &cam, const Grid &g, int n, int max_frames, const PoseF *p, const Frustum &fr,
+                        const void *const *depth, bool depth_u16, const float *scale, float mind, float maxd, void *scratch, unsigned *free_cnt) {
+    if (n < 1 || n > max_frames || n > TL3D_TSDF_MAXBATCH) return set_err(TL3D_E_INVALID, "bad batch size %d", n);
+    const BatchLayout L = batch_layout(cam, g, max_frames);
+    const Pyramid py = make_pyramid(cam);
+    char *base = static_cast<char *>(scratch);
+    FrameDesc d[TL3D_TSDF_MAXBATCH];
+    memset(d, 0, sizeof(d));
     for (int i = 0; i < n; ++i) {
-        const TsdfScratch t = carve(cam, g, scratch[i]);
-        P.f[i].depth = depth[i];
-        P.f[i].tiles = t.tiles;
-        P.f[i].list = t.list;
-        P.f[i].list_counts = t.list_counts;
-        P.f[i].cls = t.cls;
-        P.f[i].sub = t.sub;
-        P.f[i].solo = t.solo;
-        P.f[i].c = make_const(cam, scale[i], mind, maxd);
-        P.f[i].pose = p[i];
+        char *fb = base + L.off_frames + L.per_frame * (size_t)i;
+        d[i].pose = p[i];
+        d[i].c = make_const(cam, scale[i], mind, maxd);
+        d[i].depth = depth[i];
+        d[i].counts = reinterpret_cast<unsigned *>(fb + L.f_counts);
+        d[i].tiles = reinterpret_cast<float4 *>(fb + L.f_tiles);
+        d[i].list = reinterpret_cast<unsigned *>(fb + L.f_list);
+        d[i].sub = reinterpret_cast<unsigned short *>(fb + L.f_sub);
     }
+    for (int i0 = 0; i0 < n; i0 += 16) {
+        DescChunk ch;
+        const int m = n - i0 < 16 ? n - i0 : 16;
+        memcpy(ch.d, d + i0, (size_t)m * sizeof(FrameDesc));
+        if (m < 16) memset(ch.d + m, 0, (size_t)(16 - m) * sizeof(FrameDesc));
+        hipLaunchKernelGGL(desc_upload_kernel, dim3(1), dim3(256), 0, s, ch, reinterpret_cast<FrameDesc *>(base + L.off_desc) + i0, m);
+        TL3D_HIP(hipGetLastError());
+    }
+    const BatchBufs B = batch_bufs(L, scratch, n);
     const int nrx = (cam.W + REGION - 1) / REGION, nry = (cam.H + REGION - 1) / REGION;
     const int nreg = nrx * nry;
     if (depth_u16)
-        hipLaunchKernelGGL(depth_tiles_kernel<uint16_t>, dim3(nreg < 1024 ? nreg : 1024, n), dim3(256), 0, s, cam, P, py, nrx, nry);
+        hipLaunchKernelGGL(depth_tiles_kernel<uint16_t>, dim3(nreg < 1024 ? nreg : 1024, n), dim3(256), 0, s, cam, B, py, nrx, nry);
     else
-        hipLaunchKernelGGL(depth_tiles_kernel<float>, dim3(nreg < 1024 ? nreg : 1024, n), dim3(256), 0, s, cam, P, py, nrx, nry);
+        hipLaunchKernelGGL(depth_tiles_kernel<float>, dim3(nreg < 1024 ? nreg : 1024, n), dim3(256), 0, s, cam, B, py, nrx, nry);
     TL3D_HIP(hipGetLastError());
     if (py.nlev > 3) {
-        hipLaunchKernelGGL(tile_pyramid_kernel, dim3(n), dim3(256), 0, s, py, P);
+        hipLaunchKernelGGL(tile_pyramid_kernel, dim3(n), dim3(256), 0, s, py, B);
         TL3D_HIP(hipGetLastError());
     }
     const int ncells = ((g.nbx + 3) / 4) * ((g.nby + 3) / 4) * ((g.nbz + 3) / 4);
-    hipLaunchKernelGGL(brick_cull_kernel, dim3((ncells + 3) / 4, n), dim3(256), 0, s, cam, g, P, fr, py, free_cnt);
+    hipLaunchKernelGGL(brick_cull_kernel, dim3((ncells + 3) / 4, n), dim3(256), 0, s, cam, g, B, fr, py, free_cnt);
     TL3D_HIP(hipGetLastError());
-    // sub-brick masks of the listed bricks (their number is known only on the device: a fixed grid strides over the list)
+    // sub-brick masks of the listed bricks (their number is known only on the device: a fixed grid strides over each list)
     const int nbricks = g.nbx * g.nby * g.nbz;
-    const int ncb = (nbricks + 3) / 4 < 1024 ? (nbricks + 3) / 4 : 1024;
-    hipLaunchKernelGGL(subbrick_classify_kernel, dim3(ncb, n), dim3(256), 0, s, cam, g, py, P, n == 2 ? 1 : 0);
+    int ncb = (nbricks + 31) / 32;                       // 8 bricks per wave, 4 waves per workgroup
+    const int cap = n >= 8 ? 128 : 512;
+    if (ncb > cap) ncb = cap;
+    hipLaunchKernelGGL(subbrick_classify_kernel, dim3(ncb, n), dim3(256), 0, s, cam, g, py, B);
     TL3D_HIP(hipGetLastError());
     return TL3D_OK;
 }
@@ -770,35 +838,20 @@ int launch_fold_free(hipStream_t s, const Grid &g, int2 *grid, unsigned *free_cn
     return TL3D_OK;
 }
 
-// the dominant kernel: read-modify-write of the listed bricks of one prepared frame (n = 1) or of two that were prepared
-// TOGETHER by one launch_tsdf_prepare call (n = 2: the second frame's solo list exists)
-int launch_tsdf_update(hipStream_t s, const Cam &cam, const Grid &g, int n, const PoseF *p, const void *const *depth, bool depth_u16,
-                       const float *scale, float mind, float maxd, int2 *grid, void *const *scratch, unsigned long long *counters, bool count,
-                       int max_blocks, int xcd_group) {
-    UpdFrame F[2];
-    memset(F, 0, sizeof(F));
-    for (int i = 0; i < n; ++i) {
-        const TsdfScratch t = carve(cam, g, scratch[i]);
-        F[i].pose = p[i];
-        F[i].c = make_const(cam, scale[i], mind, maxd);
-        F[i].depth = depth[i];
-        F[i].list = i == 0 ? t.list : t.solo;
-        F[i].counts = t.list_counts;
-        F[i].cls = t.cls;
-        F[i].sub = t.sub;
-    }
-    if (n == 1) F[1] = F[0];
+// the dominant kernel: ONE read-modify-write pass over the bricks the n prepared frames of the batch list
+int launch_tsdf_update(hipStream_t s, const Cam &cam, const Grid &g, int n, int max_frames, bool depth_u16, int2 *grid, void *scratch,
+                       unsigned long long *counters, bool count, int max_blocks, int xcd_group) {
+    const BatchLayout L = batch_layout(cam, g, max_frames);
+    const BatchBufs B = batch_bufs(L, scratch, n);
     const int nbricks = g.nbx * g.nby * g.nbz;
-    // 6 workgroups per CU by default: the update saturates from 4 per CU upwards, and the prep kernels of later frames,
-    // which run beside it, then get just the slots they need
+    // 6 workgroups per CU by default
     int nblk = (nbricks + 3) / 4;
     if (nblk > max_blocks) nblk = max_blocks;
-#define TL3D_LAUNCH_UPD(C_, N_, T_, E_) \
-    hipLaunchKernelGGL((tsdf_update_kernel<C_, N_, T_, E_>), dim3(nblk), dim3(256), 0, s, cam, g, F[0], F[1], xcd_group, grid, counters)
-#define TL3D_LAUNCH_UPD_E(E_)                                                                                   \
-    do {                                                                                                        \
-        if (n == 2) { if (depth_u16) TL3D_LAUNCH_UPD(false, 2, uint16_t, E_); else TL3D_LAUNCH_UPD(false, 2, float, E_); } \
-        else { if (depth_u16) TL3D_LAUNCH_UPD(false, 1, uint16_t, E_); else TL3D_LAUNCH_UPD(false, 1, float, E_); }        \
+#define TL3D_LAUNCH_UPD(C_, T_, E_) \
+    hipLaunchKernelGGL((tsdf_update_kernel<C_, T_, E_>), dim3(nblk), dim3(256), 0, s, cam, g, B, xcd_group, grid, counters)
+#define TL3D_LAUNCH_UPD_E(E_)                                                                          \
+    do {                                                                                               \
+        if (depth_u16) TL3D_LAUNCH_UPD(false, uint16_t, E_); else TL3D_LAUNCH_UPD(false, float, E_);   \
     } while (0)
 #ifdef TL3D_EXPERIMENTS
     static const int exp_mode = getenv("TL3D_TSDF_EXP") ? atoi(getenv("TL3D_TSDF_EXP")) : 0;     // timing ablations: results incomplete
@@ -806,8 +859,7 @@ int launch_tsdf_update(hipStream_t s, const Cam &cam, const Grid &g, int n, cons
     constexpr int exp_mode = 0;
 #endif
     if (count) {
-        if (n == 2) { if (depth_u16) TL3D_LAUNCH_UPD(true, 2, uint16_t, 0); else TL3D_LAUNCH_UPD(true, 2, float, 0); }
-        else { if (depth_u16) TL3D_LAUNCH_UPD(true, 1, uint16_t, 0); else TL3D_LAUNCH_UPD(true, 1, float, 0); }
+        if (depth_u16) TL3D_LAUNCH_UPD(true, uint16_t, 0); else TL3D_LAUNCH_UPD(true, float, 0);
     }
 #ifdef TL3D_EXPERIMENTS
     else if (exp_mode == 1) TL3D_LAUNCH_UPD_E(1);
@@ -815,11 +867,6 @@ int launch_tsdf_update(hipStream_t s, const Cam &cam, const Grid &g, int n, cons
     else if (exp_mode == 3) TL3D_LAUNCH_UPD_E(3);
     else if (exp_mode == 4) TL3D_LAUNCH_UPD_E(4);
     else if (exp_mode == 5) TL3D_LAUNCH_UPD_E(5);
-    else if (exp_mode == 6) TL3D_LAUNCH_UPD_E(6);
-    else if (exp_mode == 8) TL3D_LAUNCH_UPD_E(8);
-    else if (exp_mode == 9) TL3D_LAUNCH_UPD_E(9);
-    else if (exp_mode == 16) TL3D_LAUNCH_UPD_E(16);
-    else if (exp_mode == 17) TL3D_LAUNCH_UPD_E(17);
 #endif
     else TL3D_LAUNCH_UPD_E(0);
     (void)exp_mode;

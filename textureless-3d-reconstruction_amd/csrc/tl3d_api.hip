@@ -179,7 +179,7 @@ static int measure_max_weight(tl3d_ctx *ctx, const int2 *grid, long long *out) {
 }
 
 // The free-space counters are incremented by the classification kernels on the prep streams and cleared / folded on the main
-// stream.  Every main-stream write to them is followed by this marker; the next prep chains wait for it (launch_pending_preps),
+// stream.  Every main-stream write to them is followed by this marker; the next prep chains wait for it (flush_updates),
 // so a count can never land in front of a clear that was issued before it (a reset followed at once by integrate calls).
 static int mark_free_cnt_write(tl3d_ctx *ctx) {
     if (!ctx->ev_free && hipEventCreateWithFlags(&ctx->ev_free, hipEventDisableTiming) != hipSuccess) return set_err(TL3D_E_HIP, "event create failed");
@@ -265,17 +265,21 @@ static int alloc_grid(tl3d_ctx *ctx, const tl3d_config *cfg) {
         if (ctx->tsdf_batch > TL3D_TSDF_MAXBATCH) ctx->tsdf_batch = TL3D_TSDF_MAXBATCH;
         ctx->tsdf_max_blocks = env_int("TL3D_UPDATE_BLOCKS", 1536);
         if (ctx->tsdf_max_blocks < 8) ctx->tsdf_max_blocks = 8;
-        ctx->tsdf_xcd_group = env_int("TL3D_XCD_GROUP", 1);
+        ctx->tsdf_xcd_group = env_int("TL3D_XCD_GROUP", 16);      // consecutive list entries per ticket chunk
         ctx->tsdf_single_stream = env_int("TL3D_SINGLE_STREAM", 0) != 0;
-        {   // the per-frame scratch of both batches: one allocation (64 of them cost ~6 ms to make and as long to free)
-            const size_t each = (tsdf_scratch_bytes(ctx->cam, g) + 255) & ~(size_t)255;
+        {   // the scratch of the two batches in flight: one allocation; the frame masks start out zero (the update re-arms them)
+            const size_t each = (tsdf_batch_scratch_bytes(ctx->cam, g, ctx->tsdf_batch) + 255) & ~(size_t)255;
             void *slab = nullptr;
-            if (hipMalloc(&slab, each * (size_t)(2 * ctx->tsdf_batch)) != hipSuccess) return set_err(TL3D_E_NOMEM, "TSDF scratch alloc failed");
+            if (hipMalloc(&slab, each * 2) != hipSuccess) return set_err(TL3D_E_NOMEM, "TSDF scratch alloc (%zu B) failed", each * 2);
             ctx->tsdf_scratch_slab = slab;
-            for (int b = 0; b < 2 * ctx->tsdf_batch; ++b) {
-                ctx->tsdf_scratch[b] = (char *)slab + each * (size_t)b;
-                if (hipEventCreateWithFlags(&ctx->ev_prep[b], hipEventDisableTiming) != hipSuccess) return set_err(TL3D_E_HIP, "event create failed");
+            size_t zoff = 0, zbytes = 0;
+            tsdf_batch_scratch_zero_range(ctx->cam, g, ctx->tsdf_batch, &zoff, &zbytes);
+            for (int h = 0; h < 2; ++h) {
+                ctx->tsdf_scratch[h] = (char *)slab + each * (size_t)h;
+                if (hipMemsetAsync((char *)ctx->tsdf_scratch[h] + zoff, 0, zbytes, ctx->stream) != hipSuccess) return set_err(TL3D_E_HIP, "memset failed");
+                if (!ctx->ev_prep[h] && hipEventCreateWithFlags(&ctx->ev_prep[h], hipEventDisableTiming) != hipSuccess) return set_err(TL3D_E_HIP, "event create failed");
             }
+            if (hipStreamSynchronize(ctx->stream) != hipSuccess) return set_err(TL3D_E_HIP, "sync failed");     // the prep streams do not wait for this memset
         }
         for (int h = 0; h < 2; ++h)
             if (hipEventCreateWithFlags(&ctx->ev_upd[h], hipEventDisableTiming) != hipSuccess) return set_err(TL3D_E_HIP, "event create failed");
@@ -463,7 +467,7 @@ int tl3d_destroy(tl3d_ctx *ctx) {
     for (int q = 0; q < 4; ++q)
         if (ctx->prep_stream[q]) (void)hipStreamSynchronize(ctx->prep_stream[q]);
     if (ctx->tsdf_scratch_slab) (void)hipFree(ctx->tsdf_scratch_slab);
-    for (int b = 0; b < TL3D_TSDF_NBUF; ++b)
+    for (int b = 0; b < 2; ++b)
         if (ctx->ev_prep[b]) (void)hipEventDestroy(ctx->ev_prep[b]);
     for (int q = 0; q < 4; ++q)
         if (ctx->prep_stream[q]) (void)hipStreamDestroy(ctx->prep_stream[q]);
@@ -901,98 +905,51 @@ static int ktimer_begin(tl3d_ctx *ctx) {
     return id;
 }
 
-// Prep chains of the pending frames that have none yet (the last one or two), together when their depth images are of one kind.
-static int launch_pending_preps(tl3d_ctx *ctx) {
-    int first = ctx->n_pend;
-    while (first > 0 && !ctx->pend[first - 1].prepped) --first;
-    const float mind = (float)ctx->cfg.min_depth, maxd = (float)ctx->cfg.max_depth;
-    const Frustum fr = make_frustum(ctx->cam);
-    const int half = (int)(ctx->tsdf_batch_no & 1u);
-    for (int k = first; k < ctx->n_pend;) {
-        tl3d_ctx::PendingUpdate &u = ctx->pend[k];
-        const Slot &us = ctx->slots[u.slot];
-        const bool u16 = us.has_u16 && ctx->tsdf_use_u16;
-        int n = 1;
-        if (k + 1 < ctx->n_pend) {
-            const Slot &vs = ctx->slots[ctx->pend[k + 1].slot];
-            if ((vs.has_u16 && ctx->tsdf_use_u16) == u16) n = 2;
-        }
-        hipStream_t ps = ctx->prep_stream[ctx->tsdf_seq++ % (unsigned)ctx->n_prep_streams];
-        PoseF poses[2];
-        const void *depths[2];
-        float scales[2];
-        void *scratch[2];
-        for (int i = 0; i < n; ++i) {
-            const tl3d_ctx::PendingUpdate &w = ctx->pend[k + i];
-            const Slot &ws = ctx->slots[w.slot];
-            if (ws.ev_upload) TL3D_HIP(hipStreamWaitEvent(ps, ws.ev_upload, 0));
-            poses[i] = w.pose;
-            depths[i] = u16 ? (const void *)ws.depth_u16 : (const void *)ws.depth;
-            scales[i] = w.scale;
-            scratch[i] = ctx->tsdf_scratch[w.buf];
-        }
-        if (ctx->upd_recorded[half]) TL3D_HIP(hipStreamWaitEvent(ps, ctx->ev_upd[half], 0));
-        if (ctx->ev_free_recorded) TL3D_HIP(hipStreamWaitEvent(ps, ctx->ev_free, 0));      // clears / folds of the free-space counters
-        int rc = launch_tsdf_prepare(ps, ctx->cam, ctx->grid, n, poses, fr, depths, u16, scales, mind, maxd, scratch, ctx->free_cnt);
-        if (rc) return rc;
-        for (int i = 0; i < n; ++i) {
-            TL3D_HIP(hipEventRecord(ctx->ev_prep[ctx->pend[k + i].buf], ps));
-            ctx->pend[k + i].prepped = true;
-            ctx->pend[k + i].prep_pair = n == 2 ? i + 1 : 0;       // the second frame of a jointly prepared pair has its solo list
-        }
-        k += n;
-    }
-    return TL3D_OK;
-}
-
-// Launches the update kernels of the prepared frames, in call order: one wait per prep stream, the updates back to back,
-// one completion event for the half of the scratch buffers the batch used.
+// Issues the pending batch: its prep chain on a side stream (it needs the frames' uploads, the batch scratch whose previous
+// user -- two batches ago -- has been updated, and the last clear / fold of the free-space counters), then ONE update launch on
+// the main stream behind it.  Results never depend on where the batch boundaries fall (integer sums).
 static int flush_updates(tl3d_ctx *ctx) {
     if (ctx->n_pend == 0) return TL3D_OK;
     ctx->grid_epoch++;
     TL3D_HIP(hipSetDevice(ctx->device));
     const float mind = (float)ctx->cfg.min_depth, maxd = (float)ctx->cfg.max_depth;
-    int rc = launch_pending_preps(ctx);                 // (a first frame of a pair still waiting for its partner)
+    const Frustum fr = make_frustum(ctx->cam);
     const int n = ctx->n_pend;
     ctx->n_pend = 0;                                    // whatever happens below, the batch is consumed
-    if (rc) return rc;
-    // each prep stream is in order: waiting for the newest event of every stream covers the whole batch (a chain serves up
-    // to two frames, so the newest events of all streams are among the last 2 x streams frames)
-    for (int k = n - 1; k >= 0 && k >= n - 2 * ctx->n_prep_streams; --k)
-        TL3D_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_prep[ctx->pend[k].buf], 0));
-    // profiling mode: one event pair around the batch's back-to-back update kernels (nothing else runs on this stream in
-    // between), so the two marker packets are shared by n launches instead of being charged to each
-    const int kt = ktimer_begin(ctx);
-    int launched = 0;
-    // two consecutive frames share one visit of the bricks both see near a surface (records read and written once for both)
-    // when their depth images are of one kind; tl3d_set_tsdf_pairing(ctx, 0): one frame per launch
-    for (int k = 0; k < n && rc == TL3D_OK;) {
-        const Slot &us = ctx->slots[ctx->pend[k].slot];
-        const bool u16 = us.has_u16 && ctx->tsdf_use_u16;
-        // (two frames that one prep chain prepared together: same depth kind, and the second one's solo list exists)
-        const int m = (ctx->tsdf_pairing && k + 1 < n && ctx->pend[k].prep_pair == 1 && ctx->pend[k + 1].prep_pair == 2) ? 2 : 1;
-        PoseF poses[2];
-        const void *depths[2];
-        float scales[2];
-        void *scratch[2];
-        for (int i = 0; i < m; ++i) {
-            const tl3d_ctx::PendingUpdate &w = ctx->pend[k + i];
-            const Slot &ws = ctx->slots[w.slot];
-            poses[i] = w.pose;
-            depths[i] = u16 ? (const void *)ws.depth_u16 : (const void *)ws.depth;
-            scales[i] = w.scale;
-            scratch[i] = ctx->tsdf_scratch[w.buf];
-        }
-        rc = launch_tsdf_update(ctx->stream, ctx->cam, ctx->grid, m, poses, depths, u16, scales, mind, maxd, ctx->tsdf, scratch, ctx->d_counters,
-                                ctx->count_records, ctx->tsdf_max_blocks, ctx->tsdf_xcd_group);
-        if (rc == TL3D_OK) { ctx->stats.tsdf_launches++; ++launched; }
-        k += m;
+    const int half = (int)(ctx->tsdf_batch_no & 1u);
+    const bool u16 = ctx->pend_u16;
+    hipStream_t ps = ctx->tsdf_single_stream ? ctx->stream : ctx->prep_stream[ctx->tsdf_batch_no % (unsigned)ctx->n_prep_streams];
+    PoseF poses[TL3D_TSDF_MAXBATCH];
+    const void *depths[TL3D_TSDF_MAXBATCH];
+    float scales[TL3D_TSDF_MAXBATCH];
+    for (int i = 0; i < n; ++i) {
+        const tl3d_ctx::PendingUpdate &w = ctx->pend[i];
+        const Slot &ws = ctx->slots[w.slot];
+        if (ps != ctx->stream && ws.ev_upload) TL3D_HIP(hipStreamWaitEvent(ps, ws.ev_upload, 0));
+        poses[i] = w.pose;
+        depths[i] = u16 ? (const void *)ws.depth_u16 : (const void *)ws.depth;
+        scales[i] = w.scale;
     }
+    if (ps != ctx->stream) {
+        if (ctx->upd_recorded[half]) TL3D_HIP(hipStreamWaitEvent(ps, ctx->ev_upd[half], 0));
+        if (ctx->ev_free_recorded) TL3D_HIP(hipStreamWaitEvent(ps, ctx->ev_free, 0));      // clears / folds of the free-space counters
+    }
+    int rc = launch_tsdf_prepare(ps, ctx->cam, ctx->grid, n, ctx->tsdf_batch, poses, fr, depths, u16, scales, mind, maxd, ctx->tsdf_scratch[half], ctx->free_cnt);
+    if (rc) return rc;
+    if (ps != ctx->stream) {
+        TL3D_HIP(hipEventRecord(ctx->ev_prep[half], ps));
+        TL3D_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_prep[half], 0));
+    }
+    // profiling mode: one event pair around the update kernel
+    const int kt = ktimer_begin(ctx);
+    rc = launch_tsdf_update(ctx->stream, ctx->cam, ctx->grid, n, ctx->tsdf_batch, u16, ctx->tsdf, ctx->tsdf_scratch[half], ctx->d_counters,
+                            ctx->count_records, ctx->tsdf_max_blocks, ctx->tsdf_xcd_group);
+    if (rc == TL3D_OK) ctx->stats.tsdf_launches++;
     if (kt >= 0) {
-        ctx->ktimers[kt].launches = launched;
+        ctx->ktimers[kt].launches = rc == TL3D_OK ? 1 : 0;
         (void)hipEventRecord(ctx->ktimers[kt].b, ctx->stream);
     }
-    const int half = (int)(ctx->tsdf_batch_no++ & 1u);
+    ctx->tsdf_batch_no++;
     TL3D_HIP(hipEventRecord(ctx->ev_upd[half], ctx->stream));
     ctx->upd_recorded[half] = true;
     return rc;
@@ -1005,8 +962,6 @@ int tl3d_integrate(tl3d_ctx *ctx, int slot, const double R[9], const double t[3]
     REQUIRE(R && t, TL3D_E_INVALID, "null pose");
     TL3D_HIP(hipSetDevice(ctx->device));
     const PoseF p = make_pose_f(R, t);
-    const Frustum fr = make_frustum(ctx->cam);
-    const float mind = (float)ctx->cfg.min_depth, maxd = (float)ctx->cfg.max_depth;
     // int32 headroom: one more observation must keep every |sum_q| <= weight * 32767 below 2^31
     if (ctx->tsdf_w_unknown || ctx->tsdf_w_upper + 1 > TL3D_TSDF_MAX_WEIGHT) {
         FLUSH_AND_FOLD(ctx);
@@ -1021,39 +976,15 @@ int tl3d_integrate(tl3d_ctx *ctx, int slot, const double R[9], const double t[3]
     }
     ctx->tsdf_w_upper++;
     ctx->free_dirty = true;
-    Slot &sl = ctx->slots[slot];
+    const Slot &sl = ctx->slots[slot];
     const bool u16 = sl.has_u16 && ctx->tsdf_use_u16;
-    const void *dptr = u16 ? (const void *)sl.depth_u16 : (const void *)sl.depth;
-    if (ctx->tsdf_single_stream) {                      // everything in order on the caller's stream
-        const float sc1 = (float)scale;
-        void *const sb1 = ctx->tsdf_scratch[0];
-        rc = launch_tsdf_prepare(ctx->stream, ctx->cam, ctx->grid, 1, &p, fr, &dptr, u16, &sc1, mind, maxd, &sb1, ctx->free_cnt);
-        if (rc) return rc;
-        const int kt = ktimer_begin(ctx);
-        rc = launch_tsdf_update(ctx->stream, ctx->cam, ctx->grid, 1, &p, &dptr, u16, &sc1, mind, maxd, ctx->tsdf, &sb1, ctx->d_counters,
-                                ctx->count_records, ctx->tsdf_max_blocks, ctx->tsdf_xcd_group);
-        if (kt >= 0) {
-            ctx->ktimers[kt].launches = 1;
-            (void)hipEventRecord(ctx->ktimers[kt].b, ctx->stream);
-        }
-        if (rc) return rc;
-        ctx->stats.tsdf_launches++;
-        return TL3D_OK;
-    }
-    // prep (tiles, pyramid, classification) on a side stream: needs the slot's upload and a scratch buffer whose previous user
-    // (two batches ago) has been updated; the update launch itself waits for the batch to fill.  Two consecutive frames are
-    // prepared by ONE chain of three launches: the first frame of a pair waits (un-prepared) for the second call, or for
-    // whatever flushes the batch.
-    const int half = (int)(ctx->tsdf_batch_no & 1u);
-    const int b = half * ctx->tsdf_batch + ctx->n_pend;
+    // The frame joins the pending batch (one depth kind per batch); the batch goes out when it is full, or when any call needs
+    // the grid, a slot, a sync or a time stamp (flush_updates).
+    if (ctx->n_pend > 0 && ctx->pend_u16 != u16) FLUSH_UPDATES(ctx);
+    ctx->pend_u16 = u16;
     tl3d_ctx::PendingUpdate &u = ctx->pend[ctx->n_pend++];
-    u.slot = slot; u.buf = b; u.pose = p; u.scale = (float)scale; u.prepped = false; u.prep_pair = 0;
-    const bool second = ctx->n_pend >= 2 && !ctx->pend[ctx->n_pend - 2].prepped;
-    if (second || !ctx->tsdf_pairing) {
-        rc = launch_pending_preps(ctx);
-        if (rc) return rc;
-    }
-    if (ctx->n_pend >= ctx->tsdf_batch) return flush_updates(ctx);
+    u.slot = slot; u.pose = p; u.scale = (float)scale;
+    if (ctx->n_pend >= (ctx->tsdf_pairing ? ctx->tsdf_batch : 1)) return flush_updates(ctx);
     return TL3D_OK;
 }
 

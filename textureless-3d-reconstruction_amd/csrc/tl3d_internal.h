@@ -113,11 +113,11 @@ constexpr int ICP_SLAB = 32;     // doubles per block partial
 
 }  // namespace tl3d
 
-// TSDF updates are issued in batches of up to TL3D_TSDF_MAXBATCH frames: the prep chains run ahead on the side streams,
-// the main stream waits once per batch and then runs the updates back to back (a cross-stream hand-over costs ~10 us,
-// about a fifth of an update).  Two halves of scratch buffers alternate between consecutive batches.
+// TSDF updates are issued in batches of up to TL3D_TSDF_MAXBATCH frames (one bit per frame in a brick's frame mask): one prep
+// chain (5 launches) for the whole batch on the side stream, then ONE update launch on the main stream that reads and writes
+// every touched record once per batch.  Two batch scratch buffers alternate, so the prep of batch k+1 runs beside the update
+// of batch k.
 #define TL3D_TSDF_MAXBATCH 32
-#define TL3D_TSDF_NBUF (2 * TL3D_TSDF_MAXBATCH)
 struct tl3d_ctx {
     tl3d_config cfg;
     int device;
@@ -136,17 +136,18 @@ struct tl3d_ctx {
     // prep_stream while the update kernel of frame i streams the grid on the main stream.
     hipStream_t prep_stream[4];  // consecutive frames take them in turn, so that many prep chains are in flight
     int n_prep_streams;
-    void *tsdf_scratch[TL3D_TSDF_NBUF];   // depth tiles + compact brick list, one per frame of the two batches in flight
+    void *tsdf_scratch[2];                // batch scratch (descriptors, tile pyramids, brick lists, frame masks, sub-brick masks): two batches in flight
     void *tsdf_scratch_slab;              // the one allocation they are carved from
-    bool tsdf_pairing;                    // two overlapping consecutive frames share one visit of their common bricks (TL3D_TSDF_PAIR=0: off)
-    hipEvent_t ev_prep[TL3D_TSDF_NBUF];   // prep of the frame using scratch b is done (recorded on its prep stream)
-    hipEvent_t ev_upd[2];                 // all updates of the last batch that used half h are done (main stream)
+    bool tsdf_pairing;                    // frames of a batch share ONE update launch (tl3d_set_tsdf_pairing(ctx, 0): one frame per launch)
+    bool pend_u16;                        // depth kind of the pending batch (a batch holds one kind)
+    hipEvent_t ev_prep[2];                // prep of the batch using scratch h is done (recorded on its prep stream)
+    hipEvent_t ev_upd[2];                 // the update of the last batch that used scratch h is done (main stream)
     bool upd_recorded[2];
     bool tsdf_use_u16;                    // gather from the millimetre image when the slot has one (env TL3D_U16_GATHER=0: never)
     int tsdf_batch;                       // frames per batch (env TL3D_TSDF_BATCH, default 32; 1 = no deferral)
     unsigned tsdf_seq, tsdf_batch_no;
-    struct PendingUpdate { int slot, buf; tl3d::PoseF pose; float scale; bool prepped; int prep_pair; } pend[TL3D_TSDF_MAXBATCH];
-    int n_pend;                           // prepared frames whose update launch is deferred to the batch boundary
+    struct PendingUpdate { int slot; tl3d::PoseF pose; float scale; } pend[TL3D_TSDF_MAXBATCH];
+    int n_pend;                           // frames of the batch being collected
     // extraction is called twice (size query, then with buffers): the block counts of the query are kept while nothing
     // has touched the grids in between (every grid-modifying or pointer-exposing call bumps grid_epoch)
     unsigned long long grid_epoch, ext_epoch, ext_total;
@@ -274,12 +275,12 @@ int launch_centroid_points(hipStream_t s, const Grid &g, const float *xyz, const
                            unsigned long long *grid, unsigned long long *counters);
 int launch_bounds(hipStream_t s, const float *xyz, long long n, float *slab, int nblocks);
 // tsdf
-size_t tsdf_scratch_bytes(const Cam &cam, const Grid &g);
-int launch_tsdf_prepare(hipStream_t s, const Cam &cam, const Grid &g, int n, const PoseF *p, const Frustum &fr, const void *const *depth,
-                        bool depth_u16, const float *scale, float mind, float maxd, void *const *scratch, unsigned *free_cnt);
-int launch_tsdf_update(hipStream_t s, const Cam &cam, const Grid &g, int n, const PoseF *p, const void *const *depth, bool depth_u16,
-                       const float *scale, float mind, float maxd, int2 *grid, void *const *scratch, unsigned long long *counters, bool count,
-                       int max_blocks, int xcd_group);
+size_t tsdf_batch_scratch_bytes(const Cam &cam, const Grid &g, int max_frames);
+void tsdf_batch_scratch_zero_range(const Cam &cam, const Grid &g, int max_frames, size_t *off, size_t *bytes);
+int launch_tsdf_prepare(hipStream_t s, const Cam &cam, const Grid &g, int n, int max_frames, const PoseF *p, const Frustum &fr,
+                        const void *const *depth, bool depth_u16, const float *scale, float mind, float maxd, void *scratch, unsigned *free_cnt);
+int launch_tsdf_update(hipStream_t s, const Cam &cam, const Grid &g, int n, int max_frames, bool depth_u16, int2 *grid, void *scratch,
+                       unsigned long long *counters, bool count, int max_blocks, int xcd_group);
 int launch_fold_free(hipStream_t s, const Grid &g, int2 *grid, unsigned *free_cnt);
 // normals + icp
 int launch_normals(hipStream_t s, const Cam &cam, const float *depth, float scale, float mind, float maxd, float jump, float4 *nmap);
