@@ -167,6 +167,11 @@ def main():
 
     icp_level = [dict(iters=args.icp_iters, stride=4, max_dist=0.05)]
 
+    # the sequence as the arrays tl3d_fuse_frames takes (packed once: the timed loop makes one foreign call per 64 frames)
+    R_all = np.ascontiguousarray(np.stack([np.asarray(p[0], np.float64).reshape(9) for p in poses]))
+    t_all = np.ascontiguousarray(np.stack([np.asarray(p[1], np.float64).reshape(3) for p in poses]))
+    ones_all = np.ones(n_res)
+
     def step(s, icp=args.icp, centroid=args.centroid, frames=F):
         # registration of group g+1 (one batched launch: every pair through all its iterations) runs while group g is fused
         G = 64
@@ -183,10 +188,9 @@ def main():
                 ctx.icp_batch_collect()
                 if gi + 1 < len(groups):
                     enqueue(gi + 1)
-            for k in ks:
-                ctx.integrate(k, poses[k])
-                if centroid:
-                    ctx.accumulate_centroid(k, poses[k], subsample=2)
+            idx = np.asarray(ks, np.int32)
+            ctx.fuse_frames_packed(idx, np.ascontiguousarray(R_all[idx]), np.ascontiguousarray(t_all[idx]), ones_all[:len(ks)],
+                                   centroid_subsample=2 if centroid else 0)
 
     def barrier():
         torch.cuda.synchronize(dev)

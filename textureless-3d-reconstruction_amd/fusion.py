@@ -260,6 +260,16 @@ class FusionContext:
         mx_d = self.max_depth if max_depth is None else float(max_depth)
         abi.check(self._lib.tl3d_fuse_frames(self._h, n, abi.ptr(sl), abi.ptr(R), abi.ptr(t), abi.ptr(sc), 0, int(centroid_subsample), mn_d, mx_d))
 
+    def fuse_frames_packed(self, slots_i32, R_f64, t_f64, scales_f64=None, centroid_subsample: int = 0):
+        """fuse_frames() on arrays the caller has already packed (int32 [n], float64 [n,9], float64 [n,3], float64 [n]): a
+        long-running loop pays the packing once."""
+        n = int(slots_i32.shape[0])
+        if n == 0:
+            return
+        sc = scales_f64 if scales_f64 is not None else np.ones(n)
+        abi.check(self._lib.tl3d_fuse_frames(self._h, n, abi.ptr(slots_i32), abi.ptr(R_f64), abi.ptr(t_f64), abi.ptr(sc), 0,
+                                             int(centroid_subsample), self.min_depth, self.max_depth))
+
     # ---- ICP -------------------------------------------------------------------------------
     def build_normals_many(self, slots, scales=None, depth_jump=0.05):
         n = len(slots)
