@@ -68,6 +68,10 @@ def main(argv=None):
     parser.add_argument("--depth-scale", type=float, default=1.0, help="metric scale of the depth files")
     parser.add_argument("--anchors", type=str, default=None,
                         help=".npz of sparse metric anchors (p3_<i>: [n,3], p2_<i>: [n,2] per frame i) for relative depth")
+    parser.add_argument("--estimate-scale", action="store_true",
+                        help="relative depth without anchors: every view's metric scale is estimated inside its registration (Sim(3) "
+                             "point-to-plane ICP) and chained with the reference's 0.7 / 0.3 rule (D2R:650); view 0 keeps --depth-scale")
+    parser.add_argument("--scale-update-weight", type=float, default=0.3, help="weight of a view's own scale estimate in the running scale")
     parser.add_argument("--tsdf-min-weight", type=int, default=0, help="> 0: keep only voxels the TSDF saw this often")
     parser.add_argument("--ascii", action="store_true", help="write the reference's ASCII fallback PLY instead of binary")
     parser.add_argument("--device", type=int, default=0)
@@ -93,7 +97,8 @@ def main(argv=None):
     config = ReconstructionConfig(fx=args.fx, fy=args.fy, cx=args.cx, cy=args.cy, voxel_size=args.voxel_size,
                                   subsample_factor=args.subsample, depth_scale=args.depth_scale, grid_dim=args.grid,
                                   sdf_trunc_voxels=args.sdf_trunc, icp_iters=args.icp_iters, icp_stride=args.icp_stride,
-                                  icp_max_dist=args.icp_max_dist, tsdf_min_weight=args.tsdf_min_weight, device=args.device)
+                                  icp_max_dist=args.icp_max_dist, tsdf_min_weight=args.tsdf_min_weight, device=args.device,
+                                  scale_update_weight=args.scale_update_weight)
     pipeline = DepthToReconstructionPipeline(config)
     # a rank decodes every frame on its host (pose chain and scale rule run over the whole sequence) and uploads its share
     streaming = args.stream and dist is None
@@ -115,6 +120,8 @@ def main(argv=None):
         z = np.load(args.anchors)
         anchors = {int(k[3:]): (z[k], z["p2_" + k[3:]]) for k in z.files if k.startswith("p3_")}
     if dist is not None:
+        if args.estimate_scale:
+            raise SystemExit("--estimate-scale chains every view's scale through its predecessor: run it on one GPU")
         points, colors, poses = pipeline.reconstruct_sharded(dist, anchors=anchors)
         rank = dist.get_rank()
         dist.barrier()
@@ -122,7 +129,7 @@ def main(argv=None):
         if rank != 0:                                   # rank 0 holds the merged cloud and writes the file
             return 0
     else:
-        points, colors, poses = pipeline.reconstruct(anchors=anchors)
+        points, colors, poses = pipeline.reconstruct(anchors=anchors, estimate_scale=args.estimate_scale)
     if points is not None and len(points) > 0:
         pipeline.save_reconstruction(points, colors, args.output, ascii=args.ascii)
         if not args.no_vis:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TL3D_ABI_VERSION 3
+#define TL3D_ABI_VERSION 4
 
 /* error codes */
 #define TL3D_OK 0
@@ -96,6 +96,8 @@ typedef struct tl3d_icp_result {
     int64_t n_src;              /* valid source samples                                            */
     int32_t iters_run;          /* iterations that produced an update                              */
     int32_t status;             /* 0 ok, 1 converged early, 2 singular system (T from last good)   */
+    double scale;               /* metric scale of the source depth at the end: the caller's scale_src, or the estimate
+                                   of a run with estimate_scale (replaces the SfM scale of D2R:297-326 / DER:659-697) */
 } tl3d_icp_result;
 
 typedef struct tl3d_icp_params {
@@ -105,6 +107,10 @@ typedef struct tl3d_icp_params {
     double damping;             /* Levenberg factor: A += damping * trace(A)/6 * I                 */
     double eps;                 /* stop when |update|_inf < eps                                    */
     double eig_rel;             /* drop directions with eigenvalue < eig_rel * largest (unobservable DOFs) */
+    int32_t estimate_scale;     /* 1: Sim(3) -- the metric scale of the SOURCE depth is a 7th unknown (sigma <- sigma
+                                   exp(alpha), Jacobian column n . (R sigma p)), solved with the pose under the same
+                                   eigenvalue cutoff: where the geometry does not observe it, it keeps scale_src    */
+    int32_t reserved;
 } tl3d_icp_params;
 
 /* per-launch statistics of the fusion kernels, for roofline accounting */

@@ -31,12 +31,14 @@ class OrcCfg(C.Structure):
 
 class OrcIcpParams(C.Structure):
     _fields_ = [("iters", C.c_int32), ("stride", C.c_int32),
-                ("max_dist", C.c_double), ("damping", C.c_double), ("eps", C.c_double), ("eig_rel", C.c_double)]
+                ("max_dist", C.c_double), ("damping", C.c_double), ("eps", C.c_double), ("eig_rel", C.c_double),
+                ("estimate_scale", C.c_int32), ("pad", C.c_int32)]
 
 
 class OrcIcpResult(C.Structure):
     _fields_ = [("T", C.c_double * 16), ("fitness", C.c_double), ("rmse", C.c_double),
-                ("n_corr", C.c_int64), ("n_src", C.c_int64), ("iters_run", C.c_int32), ("status", C.c_int32)]
+                ("n_corr", C.c_int64), ("n_src", C.c_int64), ("iters_run", C.c_int32), ("status", C.c_int32),
+                ("scale", C.c_double)]
 
 
 _lib = None
@@ -166,15 +168,15 @@ class Oracle:
         return nmap
 
     def icp(self, depth_src, nmap_tgt, T_init=None, iters=10, stride=4, max_dist=0.05, damping=1e-6, eps=1e-9,
-            scale_src=1.0, eig_rel=1e-4):
+            scale_src=1.0, eig_rel=1e-4, estimate_scale=False):
         d = self._depth(depth_src)
         nm = np.ascontiguousarray(nmap_tgt, dtype=np.float32)
         T0 = np.ascontiguousarray(np.eye(4) if T_init is None else np.asarray(T_init, np.float64).reshape(4, 4))
-        prm = OrcIcpParams(iters, stride, max_dist, damping, eps, eig_rel)
+        prm = OrcIcpParams(iters, stride, max_dist, damping, eps, eig_rel, 1 if estimate_scale else 0, 0)
         res = OrcIcpResult()
         lib().orc_icp(C.byref(self.cfg), _p(d), C.c_double(scale_src), _p(nm), _p(T0), C.byref(prm), C.byref(res))
         return dict(T=np.array(res.T).reshape(4, 4), fitness=res.fitness, rmse=res.rmse, n_corr=res.n_corr,
-                    n_src=res.n_src, iters_run=res.iters_run, status=res.status)
+                    n_src=res.n_src, iters_run=res.iters_run, status=res.status, scale=res.scale)
 
     def icp_sums(self, depth_src, nmap_tgt, T, stride=4, max_dist=0.05, scale_src=1.0):
         d = self._depth(depth_src)

@@ -47,6 +47,7 @@ typedef struct orc_cfg {
 typedef struct orc_icp_params {
     int32_t iters, stride;
     double max_dist, damping, eps, eig_rel;
+    int32_t estimate_scale, pad;            /* 1: the metric scale of the source depth is a 7th unknown (Sim(3)) */
 } orc_icp_params;
 
 typedef struct orc_icp_result {
@@ -54,6 +55,7 @@ typedef struct orc_icp_result {
     double fitness, rmse;
     int64_t n_corr, n_src;
     int32_t iters_run, status;
+    double scale;                           /* scale of the source depth at the end (= scale_s unless estimated) */
 } orc_icp_result;
 
 int orc_threads(void) {
@@ -392,10 +394,13 @@ void orc_normals(const orc_cfg *c, const float *depth, double scale, double dept
  * Solve (A + damping*trace(A)/6*I) x = -b by eigen-decomposition with a relative eigenvalue cutoff (solve6);
  * T <- [exp(w) | tau] * T.  A final pass evaluates fitness/rmse at T.
  * ------------------------------------------------------------------------------------------------ */
-typedef struct { double a[21], b[6], e; int64_t cnt, nsrc; } icp_sums;
+typedef struct { double a[21], b[6], e; int64_t cnt, nsrc; double c[6], cc, bc; } icp_sums;
 
+/* est_scale: also the scale column.  The source point is sigma * p_hat (p_hat from depth * sc, sc = the current scale estimate);
+ * a step sigma <- sigma * exp(alpha) moves the transformed point q = R sigma p_hat + t by alpha * (q - t), so
+ * J_alpha = n . (q - t);  c[a] = sum J_a J_alpha, cc = sum J_alpha^2, bc = sum J_alpha r. */
 static void icp_pass(const orc_cfg *c, const float *depth_s, float sc, const float *nmap_t, const double T[16],
-                     int stride, float max_dist, icp_sums *s) {
+                     int stride, float max_dist, int est_scale, icp_sums *s) {
     const int W = c->width, H = c->height;
     const float fx = (float)c->fx, fy = (float)c->fy, cx = (float)c->cx, cy = (float)c->cy;
     const float mind = (float)c->min_depth, maxd = (float)c->max_depth;
@@ -443,6 +448,12 @@ static void icp_pass(const orc_cfg *c, const float *depth_s, float sc, const flo
             }
             s->e += rr * rr;
             s->cnt++;
+            if (est_scale) {
+                const double ja = (double)fmaf(nx, px - t[0], fmaf(ny, py - t[1], nz * (pz - t[2])));
+                for (int a = 0; a < 6; ++a) s->c[a] += J[a] * ja;
+                s->cc += ja * ja;
+                s->bc += ja * rr;
+            }
         }
 }
 
@@ -573,6 +584,124 @@ static int solve6(const double a21[21], const double b[6], double damping, doubl
     return used == 0;
 }
 
+/* The same solve for n <= 7 unknowns (Sim(3): the 6 of the pose + log-scale): packed upper triangle a[n (n + 1) / 2] (row by
+ * row), damping * trace / n on the diagonal, direct LDL^T path when no eigen-direction can be truncated, else cyclic Jacobi
+ * (row-cyclic order, <= 16 sweeps) with the relative eigenvalue cutoff.  The device runs this very sequence on one lane. */
+static int solve_n(int n, const double *ap, const double *b, double damping, double eig_rel, double *x) {
+    double A[7][7], V[7][7], L[7][7], M[7][7], d[7];
+    int m = 0;
+    double tr = 0.0;
+    for (int i = 0; i < n; ++i)
+        for (int j = i; j < n; ++j) { A[i][j] = A[j][i] = ap[m++]; }
+    for (int i = 0; i < n; ++i) tr += A[i][i];
+    if (!(tr > 0.0)) return 1;
+    const double lam = damping * (tr / (double)n);
+    for (int i = 0; i < n; ++i) A[i][i] += lam;
+    tr = 0.0;
+    for (int i = 0; i < n; ++i) tr += A[i][i];
+    {   /* direct path */
+        int ok = 1;
+        for (int j = 0; j < n && ok; ++j) {
+            double s = A[j][j];
+            for (int k = 0; k < j; ++k) s -= (L[j][k] * L[j][k]) * d[k];
+            if (!(s > 0.0)) { ok = 0; break; }
+            d[j] = s;
+            for (int i = j + 1; i < n; ++i) {
+                double t = A[i][j];
+                for (int k = 0; k < j; ++k) t -= (L[i][k] * L[j][k]) * d[k];
+                L[i][j] = t / s;
+            }
+        }
+        if (ok) {
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < i; ++j) {
+                    double t = L[i][j];
+                    for (int k = j + 1; k < i; ++k) t += L[i][k] * M[k][j];
+                    M[i][j] = -t;
+                }
+            double tinv = 0.0;
+            for (int j = 0; j < n; ++j) {
+                double s = 1.0 / d[j];
+                for (int i = j + 1; i < n; ++i) s += (M[i][j] * M[i][j]) / d[i];
+                tinv += s;
+            }
+            if (tinv > 0.0 && 1.0 / tinv > eig_rel * tr) {
+                double y[7];
+                for (int i = 0; i < n; ++i) {
+                    double t = -b[i];
+                    for (int j = 0; j < i; ++j) t += M[i][j] * -b[j];
+                    y[i] = t / d[i];
+                }
+                for (int j = 0; j < n; ++j) {
+                    double t = y[j];
+                    for (int i = j + 1; i < n; ++i) t += M[i][j] * y[i];
+                    x[j] = t;
+                }
+                return 0;
+            }
+        }
+    }
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 16; ++sweep) {
+        double offmax = 0.0;
+        for (int i = 0; i < n; ++i)
+            for (int k = 0; k < n; ++k)
+                if (k != i && fabs(A[i][k]) > offmax) offmax = fabs(A[i][k]);
+        if (!(offmax > 1e-15 * tr)) break;
+        for (int pp = 0; pp < n - 1; ++pp)
+            for (int q = pp + 1; q < n; ++q) {
+                const double apq = A[pp][q];
+                if (fabs(apq) < 1e-300) continue;
+                const double theta = (A[q][q] - A[pp][pp]) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+                for (int k = 0; k < n; ++k) {
+                    const double akp = A[k][pp], akq = A[k][q];
+                    A[k][pp] = cs * akp - sn * akq;
+                    A[k][q] = sn * akp + cs * akq;
+                    const double vkp = V[k][pp], vkq = V[k][q];
+                    V[k][pp] = cs * vkp - sn * vkq;
+                    V[k][q] = sn * vkp + cs * vkq;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double apk = A[pp][k], aqk = A[q][k];
+                    A[pp][k] = cs * apk - sn * aqk;
+                    A[q][k] = sn * apk + cs * aqk;
+                }
+            }
+    }
+    double lmax = 0.0;
+    for (int i = 0; i < n; ++i) if (A[i][i] > lmax) lmax = A[i][i];
+    if (!(lmax > 0.0)) return 1;
+    for (int i = 0; i < n; ++i) x[i] = 0.0;
+    int used = 0;
+    for (int e = 0; e < n; ++e) {
+        const double l = A[e][e];
+        if (!(l > eig_rel * lmax) || !(l > 0.0)) continue;
+        double proj = 0.0;
+        for (int k = 0; k < n; ++k) proj += V[k][e] * b[k];
+        const double coef = -proj / l;
+        for (int k = 0; k < n; ++k) x[k] += coef * V[k][e];
+        ++used;
+    }
+    return used == 0;
+}
+
+/* the 7x7 system of the pose + log-scale from the sums: rows 0..5 = the pose block with the scale column appended */
+static int solve7(const icp_sums *s, double damping, double eig_rel, double x[7]) {
+    double ap[28], b[7];
+    int m = 0, k = 0;
+    for (int i = 0; i < 6; ++i) {
+        for (int j = i; j < 6; ++j) ap[k++] = s->a[m++];
+        ap[k++] = s->c[i];
+    }
+    ap[k++] = s->cc;
+    for (int i = 0; i < 6; ++i) b[i] = s->b[i];
+    b[6] = s->bc;
+    return solve_n(7, ap, b, damping, eig_rel, x);
+}
+
 /* T <- [exp(w) | tau] * T */
 static void se3_apply(const double x[6], double T[16]) {
     const double wx = x[0], wy = x[1], wz = x[2];
@@ -608,17 +737,21 @@ int orc_icp(const orc_cfg *c, const float *depth_s, double scale_s, const float 
     memcpy(T, T_init, sizeof(T));
     icp_sums s;
     int status = 0, iters_run = 0;
+    double scale = scale_s;
+    const int est = prm->estimate_scale != 0;
     for (int it = 0; it < prm->iters; ++it) {
-        icp_pass(c, depth_s, (float)scale_s, nmap_t, T, prm->stride, (float)prm->max_dist, &s);
-        double x[6];
-        if (s.cnt < 6 || solve6(s.a, s.b, prm->damping, prm->eig_rel, x)) { status = 2; break; }
+        icp_pass(c, depth_s, (float)scale, nmap_t, T, prm->stride, (float)prm->max_dist, est, &s);
+        double x[7];
+        x[6] = 0.0;
+        if (s.cnt < 6 || (est ? solve7(&s, prm->damping, prm->eig_rel, x) : solve6(s.a, s.b, prm->damping, prm->eig_rel, x))) { status = 2; break; }
         se3_apply(x, T);
+        if (est) scale *= exp(x[6]);
         ++iters_run;
         double mx = 0;
-        for (int i = 0; i < 6; ++i) if (fabs(x[i]) > mx) mx = fabs(x[i]);
+        for (int i = 0; i < (est ? 7 : 6); ++i) if (fabs(x[i]) > mx) mx = fabs(x[i]);
         if (mx < prm->eps) { status = 1; break; }
     }
-    icp_pass(c, depth_s, (float)scale_s, nmap_t, T, prm->stride, (float)prm->max_dist, &s);
+    icp_pass(c, depth_s, (float)scale, nmap_t, T, prm->stride, (float)prm->max_dist, 0, &s);
     memcpy(out->T, T, sizeof(T));
     out->n_corr = s.cnt;
     out->n_src = s.nsrc;
@@ -626,6 +759,7 @@ int orc_icp(const orc_cfg *c, const float *depth_s, double scale_s, const float 
     out->rmse = s.cnt > 0 ? sqrt(s.e / (double)s.cnt) : 0.0;
     out->iters_run = iters_run;
     out->status = status;
+    out->scale = scale;
     return 0;
 }
 
@@ -633,7 +767,7 @@ int orc_icp(const orc_cfg *c, const float *depth_s, double scale_s, const float 
 void orc_icp_sums(const orc_cfg *c, const float *depth_s, double scale_s, const float *nmap_t, const double T[16],
                   int stride, double max_dist, double out29[29], int64_t *cnt, int64_t *nsrc) {
     icp_sums s;
-    icp_pass(c, depth_s, (float)scale_s, nmap_t, T, stride, (float)max_dist, &s);
+    icp_pass(c, depth_s, (float)scale_s, nmap_t, T, stride, (float)max_dist, 0, &s);
     memcpy(out29, s.a, 21 * sizeof(double));
     memcpy(out29 + 21, s.b, 6 * sizeof(double));
     out29[27] = s.e;

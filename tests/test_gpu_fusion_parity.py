@@ -684,3 +684,59 @@ def test_fuse_frames_and_normals_many_equal_the_per_frame_calls():
     assert np.array_equal(grids[0][0], grids[1][0]) and np.array_equal(grids[0][1], grids[1][1])
     assert all(np.array_equal(a, b) for a, b in zip(nmaps[0], nmaps[1]))
     assert int((grids[0][0][:, 1] > 0).sum()) > 1000
+
+
+def test_sim3_icp_matches_the_oracle_and_recovers_the_scale():
+    """Row f3, scale as the 7th unknown of the registration: source depth maps divided by s in [0.7, 1.4] -- per-iteration
+    kernel and batched kernel vs the C oracle (pose <= 1e-4 Frobenius, scale <= 1e-6 relative), and the recovered scale is
+    the true one (<= 2e-3: pixel quantisation of the projective association)."""
+    from tl3d import synth
+    cam = dict(width=320, height=240, fx=280.0, fy=280.0, cx=159.5, cy=119.5)
+    scene = synth.object_scene()
+    poses = synth.orbit_poses(4, 1.0, 4.0)
+    frames = [synth.render(scene, p, want_color=False, **cam)[0] for p in poses]
+    true_s = [1.0, 0.8, 1.3, 0.72]
+    rel = [(f / s).astype(np.float32) for f, s in zip(frames, true_s)]
+    ctx, orc = make_pair(cam=cam, dims=(64, 64, 64), voxel=0.04, n_slots=4)
+    lv = dict(iters=25, stride=2, max_dist=0.5, estimate_scale=True)
+    with ctx:
+        for i, d in enumerate(rel):
+            ctx.upload(i, d, None)
+        ctx.build_normals(0, scale=1.0)
+        nm0 = orc.normals(rel[0], scale=1.0)
+        batch = ctx.icp_batch([(i, 0) for i in (1, 2, 3)], [lv], scales=[1.0, 1.0, 1.0])
+        for k, i in enumerate((1, 2, 3)):
+            ores = orc.icp(rel[i], nm0, iters=25, stride=2, max_dist=0.5, scale_src=1.0, estimate_scale=True)
+            one = ctx.icp(i, 0, iters=25, stride=2, max_dist=0.5, scale_src=1.0, estimate_scale=True)
+            for res in (one, batch[k]):
+                assert np.linalg.norm(res["T"] - ores["T"]) < 1e-4, (i, np.linalg.norm(res["T"] - ores["T"]))
+                assert abs(res["scale"] - ores["scale"]) < 1e-6 * ores["scale"], (i, res["scale"], ores["scale"])
+                assert res["n_corr"] == ores["n_corr"]
+            assert abs(one["scale"] - true_s[i]) < 2e-3 * true_s[i], (i, one["scale"])
+            r_rel, t_rel = synth.relative_pose(poses[i], poses[0])             # view i -> view 0
+            assert np.linalg.norm(one["T"][:3, :3] - r_rel) < 8e-3 and np.linalg.norm(one["T"][:3, 3] - t_rel.ravel()) < 8e-3      # (240-line frames, up to 12 degrees apart)
+        # without the flag the scale is the caller's and the run is the 6-unknown one, bit for bit
+        a = ctx.icp(1, 0, iters=10, stride=2, max_dist=0.1, scale_src=0.8)
+        b = orc.icp(rel[1], nm0, iters=10, stride=2, max_dist=0.1, scale_src=0.8)
+        assert a["scale"] == 0.8 and np.linalg.norm(a["T"] - b["T"]) < 1e-9
+
+
+def test_sim3_icp_keeps_the_prior_where_the_scale_is_not_observed():
+    """A single plane seen from two positions: the plane's distance is one constraint on (translation along the normal,
+    scale) -- the combination the data does not see is dropped by the eigenvalue cutoff, so a true prior is kept (and the
+    solve takes the eigen path: a plane also leaves two translations and one rotation free)."""
+    from tl3d import synth
+    cam = dict(width=320, height=240, fx=280.0, fy=280.0, cx=159.5, cy=119.5)
+    scene = synth.Scene(planes=[((0.0, 0.0, -1.0), -1.5)])                     # z = 1.5 seen from the origin
+    poses = synth.dolly_poses(2, (0.0, 0.0, 0.0), (0.03, 0.0, 0.0))
+    frames = [synth.render(scene, p, want_color=False, **cam)[0] for p in poses]
+    ctx, orc = make_pair(cam=cam, dims=(64, 64, 64), voxel=0.04, n_slots=2)
+    with ctx:
+        for i, d in enumerate(frames):
+            ctx.upload(i, d, None)
+        ctx.build_normals(0)
+        res = ctx.icp(1, 0, iters=15, stride=2, max_dist=0.2, scale_src=1.0, estimate_scale=True)
+        ores = orc.icp(frames[1], orc.normals(frames[0]), iters=15, stride=2, max_dist=0.2, scale_src=1.0, estimate_scale=True)
+    assert res["status"] in (0, 1) and abs(res["scale"] - 1.0) < 1e-4, res["scale"]
+    assert abs(res["scale"] - ores["scale"]) < 1e-6 and np.linalg.norm(res["T"] - ores["T"]) < 1e-4
+    assert np.linalg.norm(res["T"] - np.eye(4)) < 1e-3                         # sliding along the plane is not observed either

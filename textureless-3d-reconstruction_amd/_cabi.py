@@ -10,7 +10,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TL3D_LIB") or os.path.join(_HERE, "libtl3d.so")     # TL3D_LIB: a diagnostic build
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 OK, E_INVALID, E_HIP, E_NOMEM, E_CAPACITY, E_STATE, E_NODEVICE = 0, -1, -2, -3, -4, -5, -6
 CH_TSDF, CH_CENTROID = 1, 2
 DEPTH_F32_M, DEPTH_U16_MM = 0, 1
@@ -49,12 +49,14 @@ class Config(C.Structure):
 
 class IcpResult(C.Structure):
     _fields_ = [("T", C.c_double * 16), ("fitness", C.c_double), ("rmse", C.c_double),
-                ("n_corr", C.c_int64), ("n_src", C.c_int64), ("iters_run", C.c_int32), ("status", C.c_int32)]
+                ("n_corr", C.c_int64), ("n_src", C.c_int64), ("iters_run", C.c_int32), ("status", C.c_int32),
+                ("scale", C.c_double)]
 
 
 class IcpParams(C.Structure):
     _fields_ = [("iters", C.c_int32), ("stride", C.c_int32),
-                ("max_dist", C.c_double), ("damping", C.c_double), ("eps", C.c_double), ("eig_rel", C.c_double)]
+                ("max_dist", C.c_double), ("damping", C.c_double), ("eps", C.c_double), ("eig_rel", C.c_double),
+                ("estimate_scale", C.c_int32), ("reserved", C.c_int32)]
 
 
 class IcpPair(C.Structure):

@@ -68,6 +68,7 @@ __global__ __launch_bounds__(256) void normals_kernel(Cam cam, const float *__re
 // accumulate this workgroup's share of the sums and leave the workgroup total in sm_out[0..31] (valid for threads < 32
 // after the function's last barrier)
 // `member` of `members` workgroups share one registration: member m takes samples m*256 + tid, + members*256, ...
+template <bool SCALE>
 __device__ __forceinline__ void icp_accumulate_core(const Cam &cam, const float *__restrict__ depth_s, const float4 *__restrict__ nmap_t,
                                                     float sc, float mind, float maxd, float md2, int stride, int Ws, int Hs,
                                                     const float r[9], const float t[3], int member, int members,
@@ -76,6 +77,9 @@ __device__ __forceinline__ void icp_accumulate_core(const Cam &cam, const float 
     double acc[30];
 #pragma unroll
     for (int i = 0; i < 30; ++i) acc[i] = 0.0;
+    double accs[8];                                      // scale column (Sim(3) runs): sum J_a J_alpha (6), J_alpha^2, J_alpha r
+#pragma unroll
+    for (int i = 0; i < 8; ++i) accs[i] = 0.0;
     const long long ns = (long long)Ws * Hs;
     // Two samples per trip, every load of the pair issued before its first use (source depths, then the two normal-map
     // gathers): a thread's trip costs one depth latency + one gather latency instead of two of each.  Addresses of
@@ -128,6 +132,14 @@ __device__ __forceinline__ void icp_accumulate_core(const Cam &cam, const float 
         }
         acc[27] += rr * rr;
         acc[28] += 1.0;
+        if (SCALE) {
+            // sigma <- sigma exp(alpha) moves q = R sigma p_hat + t by alpha (q - t):  J_alpha = n . (q - t)
+            const double ja = (double)fmaf(nd.x, px - t[0], fmaf(nd.y, py - t[1], nd.z * (pz - t[2])));
+#pragma unroll
+            for (int a = 0; a < 6; ++a) accs[a] += J[a] * ja;
+            accs[6] += ja * ja;
+            accs[7] += ja * rr;
+        }
     };
     for (long long s0 = (long long)member * 256 + threadIdx.x; s0 < ns; s0 += 2 * step) {
         const long long s1 = s0 + step;
@@ -168,11 +180,22 @@ __device__ __forceinline__ void icp_accumulate_core(const Cam &cam, const float 
     }
     v[0] += __shfl_xor(v[0], 1);
     if (!(lane & 1)) sm[wid][lane >> 1] = v[0];
+    if (SCALE) {                                         // the 8 sums of the scale column: plain shuffle trees
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            double w = accs[k];
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) w += __shfl_xor(w, d);
+            if (lane == 0) sm[wid][32 + k] = w;
+        }
+    } else if (lane < 8) {
+        sm[wid][32 + lane] = 0.0;
+    }
     if (stamp) stamp[1] = wall_clock64();
     __syncthreads();
     if (threadIdx.x < ICP_SLAB) {
         const int i = threadIdx.x;
-        sm_out[i] = ((sm[0][i] + sm[1][i]) + sm[2][i]) + sm[3][i];            // (sums 30 and 31 are zero)
+        sm_out[i] = ((sm[0][i] + sm[1][i]) + sm[2][i]) + sm[3][i];            // (sums 30 and 31 are zero; 32..39 too unless the scale is estimated)
     }
 }
 
@@ -182,8 +205,13 @@ __device__ __forceinline__ void icp_accumulate(const Cam &cam, const IcpRun *__r
     r[0] = (float)state->T[0]; r[1] = (float)state->T[1]; r[2] = (float)state->T[2];  t[0] = (float)state->T[3];
     r[3] = (float)state->T[4]; r[4] = (float)state->T[5]; r[5] = (float)state->T[6];  t[1] = (float)state->T[7];
     r[6] = (float)state->T[8]; r[7] = (float)state->T[9]; r[8] = (float)state->T[10]; t[2] = (float)state->T[11];
-    icp_accumulate_core(cam, run->depth_src, run->nmap_tgt, run->scale, run->mind, run->maxd, run->md2, run->stride, run->Ws, run->Hs,
-                        r, t, (int)blockIdx.x, (int)gridDim.x, sm, sm_out);
+    const float sc = (float)state->scale;                  // the caller's scale, or the running estimate of a Sim(3) run
+    if (run->est_scale)
+        icp_accumulate_core<true>(cam, run->depth_src, run->nmap_tgt, sc, run->mind, run->maxd, run->md2, run->stride, run->Ws, run->Hs,
+                                  r, t, (int)blockIdx.x, (int)gridDim.x, sm, sm_out);
+    else
+        icp_accumulate_core<false>(cam, run->depth_src, run->nmap_tgt, sc, run->mind, run->maxd, run->md2, run->stride, run->Ws, run->Hs,
+                                   r, t, (int)blockIdx.x, (int)gridDim.x, sm, sm_out);
 }
 
 // 1/x and 1/sqrt(x) to ~1e-16 relative: hardware seed + two Newton steps (no IEEE division / square-root sequence)
@@ -397,6 +425,123 @@ __device__ __forceinline__ int solve6_wave(const double *__restrict__ a21, const
     return used == 0;
 }
 
+// The solve for n <= 7 unknowns (Sim(3): pose + log-scale), on ONE lane: oracle/tl3d_oracle.c solve_n, same sequence (direct
+// LDL^T path when no eigen-direction can be truncated, else row-cyclic Jacobi with the relative eigenvalue cutoff).
+__device__ int solve_n_serial(int n, const double *ap, const double *b, double damping, double eig_rel, double *x) {
+    double A[7][7], V[7][7], L[7][7], M[7][7], d[7];
+    int m = 0;
+    double tr = 0.0;
+    for (int i = 0; i < n; ++i)
+        for (int j = i; j < n; ++j) { A[i][j] = A[j][i] = ap[m++]; }
+    for (int i = 0; i < n; ++i) tr += A[i][i];
+    if (!(tr > 0.0)) return 1;
+    const double lam = damping * (tr / (double)n);
+    for (int i = 0; i < n; ++i) A[i][i] += lam;
+    tr = 0.0;
+    for (int i = 0; i < n; ++i) tr += A[i][i];
+    {
+        int ok = 1;
+        for (int j = 0; j < n && ok; ++j) {
+            double s = A[j][j];
+            for (int k = 0; k < j; ++k) s -= (L[j][k] * L[j][k]) * d[k];
+            if (!(s > 0.0)) { ok = 0; break; }
+            d[j] = s;
+            for (int i = j + 1; i < n; ++i) {
+                double t = A[i][j];
+                for (int k = 0; k < j; ++k) t -= (L[i][k] * L[j][k]) * d[k];
+                L[i][j] = t / s;
+            }
+        }
+        if (ok) {
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < i; ++j) {
+                    double t = L[i][j];
+                    for (int k = j + 1; k < i; ++k) t += L[i][k] * M[k][j];
+                    M[i][j] = -t;
+                }
+            double tinv = 0.0;
+            for (int j = 0; j < n; ++j) {
+                double s = 1.0 / d[j];
+                for (int i = j + 1; i < n; ++i) s += (M[i][j] * M[i][j]) / d[i];
+                tinv += s;
+            }
+            if (tinv > 0.0 && 1.0 / tinv > eig_rel * tr) {
+                double y[7];
+                for (int i = 0; i < n; ++i) {
+                    double t = -b[i];
+                    for (int j = 0; j < i; ++j) t += M[i][j] * -b[j];
+                    y[i] = t / d[i];
+                }
+                for (int j = 0; j < n; ++j) {
+                    double t = y[j];
+                    for (int i = j + 1; i < n; ++i) t += M[i][j] * y[i];
+                    x[j] = t;
+                }
+                return 0;
+            }
+        }
+    }
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 16; ++sweep) {
+        double offmax = 0.0;
+        for (int i = 0; i < n; ++i)
+            for (int k = 0; k < n; ++k)
+                if (k != i && fabs(A[i][k]) > offmax) offmax = fabs(A[i][k]);
+        if (!(offmax > 1e-15 * tr)) break;
+        for (int pp = 0; pp < n - 1; ++pp)
+            for (int q = pp + 1; q < n; ++q) {
+                const double apq = A[pp][q];
+                if (fabs(apq) < 1e-300) continue;
+                const double theta = (A[q][q] - A[pp][pp]) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+                for (int k = 0; k < n; ++k) {
+                    const double akp = A[k][pp], akq = A[k][q];
+                    A[k][pp] = cs * akp - sn * akq;
+                    A[k][q] = sn * akp + cs * akq;
+                    const double vkp = V[k][pp], vkq = V[k][q];
+                    V[k][pp] = cs * vkp - sn * vkq;
+                    V[k][q] = sn * vkp + cs * vkq;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double apk = A[pp][k], aqk = A[q][k];
+                    A[pp][k] = cs * apk - sn * aqk;
+                    A[q][k] = sn * apk + cs * aqk;
+                }
+            }
+    }
+    double lmax = 0.0;
+    for (int i = 0; i < n; ++i) if (A[i][i] > lmax) lmax = A[i][i];
+    if (!(lmax > 0.0)) return 1;
+    for (int i = 0; i < n; ++i) x[i] = 0.0;
+    int used = 0;
+    for (int e = 0; e < n; ++e) {
+        const double l = A[e][e];
+        if (!(l > eig_rel * lmax) || !(l > 0.0)) continue;
+        double proj = 0.0;
+        for (int k = 0; k < n; ++k) proj += V[k][e] * b[k];
+        const double coef = -proj / l;
+        for (int k = 0; k < n; ++k) x[k] += coef * V[k][e];
+        ++used;
+    }
+    return used == 0;
+}
+
+// the 7x7 system from the sums (layout of IcpState::sums): rows 0..5 = the pose block with the scale column appended
+__device__ int solve7_serial(const double *sums, double damping, double eig_rel, double x[7]) {
+    double ap[28], b[7];
+    int m = 0, k = 0;
+    for (int i = 0; i < 6; ++i) {
+        for (int j = i; j < 6; ++j) ap[k++] = sums[m++];
+        ap[k++] = sums[32 + i];
+    }
+    ap[k++] = sums[38];
+    for (int i = 0; i < 6; ++i) b[i] = sums[21 + i];
+    b[6] = sums[39];
+    return solve_n_serial(7, ap, b, damping, eig_rel, x);
+}
+
 // State words another workgroup of the same launch reads next (batched runs): write-through (agent-scope) stores, so that
 // they need no L2 write-back before the hand-off; the reader acquires as before.
 template <typename V> __device__ __forceinline__ void st_agent(V *p, V v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -435,7 +580,8 @@ __device__ void se3_apply(const double x[6], double *T, float *T_f32 = nullptr) 
 // Returns (thread 0 only) 1 when the run converged, 2 when it failed in this pass, else 0.  T_f32: where thread 0 leaves the
 // new pose as the 12 floats a pass uses (LDS; untouched when the pose did not change).
 __device__ __forceinline__ int icp_finish(const double *slab, int nblocks, IcpState *state, double damping, double eps, double eig_rel,
-                                          int final_pass, double (*part)[ICP_SLAB], double *sums, float *T_f32 = nullptr, int updates_so_far = -1) {
+                                          int final_pass, double (*part)[ICP_SLAB], double *sums, int est_scale, float *T_f32 = nullptr,
+                                          int updates_so_far = -1) {
     const int t = threadIdx.x;
     {   // slab reduction: 8 groups x 32 components, loads batched 8 deep, combined in a fixed order (deterministic).
         // The partials were written by other CUs in THIS launch: agent-scope (sc1) loads, never served from this CU's L1
@@ -452,8 +598,14 @@ __device__ __forceinline__ int icp_finish(const double *slab, int nblocks, IcpSt
         for (; b < nblocks; b += 8) s += __hip_atomic_load(slab + (size_t)b * ICP_SLAB + comp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         part[grp][comp] = s;
     }
+    if (est_scale && t < 8) {                              // the scale column's 8 sums: member order, one thread each
+        double s = 0.0;
+        for (int b = 0; b < nblocks; ++b) s += __hip_atomic_load(slab + (size_t)b * ICP_SLAB + 32 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sums[32 + t] = s;
+        state->sums[32 + t] = s;
+    }
     __syncthreads();
-    if (t < ICP_SLAB) {
+    if (t < 32) {
         double s = part[0][t];
 #pragma unroll
         for (int g = 1; g < 8; ++g) s += part[g][t];
@@ -462,8 +614,14 @@ __device__ __forceinline__ int icp_finish(const double *slab, int nblocks, IcpSt
     }
     __syncthreads();
     if (final_pass || t >= 64) return 0;                   // wave 0 solves
-    double x[6];
-    const int fail = (sums[28] < 6.0) ? 1 : solve6_wave(sums, sums + 21, damping, eig_rel, x);
+    double x[7];
+    x[6] = 0.0;
+    int fail = 0;
+    if (est_scale) {                                       // Sim(3): the 7x7 system, on one lane (wave-uniform branch)
+        if (t == 0) fail = (sums[28] < 6.0) ? 1 : solve7_serial(sums, damping, eig_rel, x);
+    } else {
+        fail = (sums[28] < 6.0) ? 1 : solve6_wave(sums, sums + 21, damping, eig_rel, x);
+    }
     if (t != 0) return 0;
     if (fail) {
         st_agent(&state->done, 1);
@@ -471,9 +629,14 @@ __device__ __forceinline__ int icp_finish(const double *slab, int nblocks, IcpSt
         return 2;
     }
     se3_apply(x, state->T, T_f32);
+    if (est_scale) {
+        const double sn = ld_agent(&state->scale) * exp(x[6]);
+        st_agent(&state->scale, sn);
+        if (T_f32) T_f32[12] = (float)sn;
+    }
     st_agent(&state->iters_run, (updates_so_far >= 0 ? updates_so_far : ld_agent(&state->iters_run)) + 1);    // (the load is a round trip)
     double mx = 0.0;
-    for (int i = 0; i < 6; ++i) mx = fmax(mx, fabs(x[i]));
+    for (int i = 0; i < (est_scale ? 7 : 6); ++i) mx = fmax(mx, fabs(x[i]));
     if (mx < eps) {
         st_agent(&state->done, 1);
         st_agent(&state->status, 1);
@@ -510,7 +673,7 @@ __global__ __launch_bounds__(256) void icp_iter_kernel(Cam cam, const IcpRun *__
     }
     __syncthreads();
     if (!s_last) return;
-    (void)icp_finish(slab, (int)gridDim.x, state, run->damping, run->eps, run->eig_rel, final_pass, sm, tot);
+    (void)icp_finish(slab, (int)gridDim.x, state, run->damping, run->eps, run->eig_rel, final_pass, sm, tot, final_pass ? 0 : run->est_scale);
     if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // re-arm for the next launch
 }
 
@@ -536,7 +699,7 @@ __device__ __forceinline__ size_t icp_sync_line(int pair, int rows) {        // 
 __global__ __launch_bounds__(256) void icp_batch_kernel(Cam cam, IcpBatchArgs a) {
     __shared__ double sm[8][ICP_SLAB];
     __shared__ double tot[ICP_SLAB];
-    __shared__ float sT[12];
+    __shared__ float sT[13];                               // the pose as 12 floats + the source depth's scale
     __shared__ int s_flag[4];                              // [0] ticket, [1] last arriver, [2] generation word seen, [3] wait failed
     const int tid = threadIdx.x;
     if (tid == 0) s_flag[0] = (int)__hip_atomic_fetch_add(a.ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -555,7 +718,8 @@ __global__ __launch_bounds__(256) void icp_batch_kernel(Cam cam, IcpBatchArgs a)
     int failed_run = 0;                                    // a pass of this pair found the system singular (status 2)
     unsigned long long *dbg = (a.dbg && pair == 0 && tid == 0) ? a.dbg + (size_t)member * 16 * 8 : nullptr;
 #define ICP_STAMP(k_) do { if (dbg && gen < 16u) dbg[gen * 8 + (k_)] = wall_clock64(); } while (0)
-    if (tid < 12) sT[tid] = (float)st->T[tid];             // the initial pose: uploaded before the launch
+    if (tid < 12) sT[tid] = (float)st->T[tid];             // the initial pose and scale: uploaded before the launch
+    if (tid == 12) sT[12] = (float)st->scale;
     __syncthreads();
     for (int lv = 0; lv < a.n_levels; ++lv) {
         const IcpLevel L = a.lv[lv];
@@ -568,8 +732,13 @@ __global__ __launch_bounds__(256) void icp_batch_kernel(Cam cam, IcpBatchArgs a)
             r[3] = sT[4]; r[4] = sT[5]; r[5] = sT[6];  t[1] = sT[7];
             r[6] = sT[8]; r[7] = sT[9]; r[8] = sT[10]; t[2] = sT[11];
             ICP_STAMP(1);
-            icp_accumulate_core(cam, pr.depth_src, pr.nmap_tgt, pr.scale, a.mind, a.maxd, L.md2, L.stride, L.Ws, L.Hs, r, t, member, a.members, sm, tot,
-                                (dbg && gen < 16u) ? dbg + gen * 8 + 3 : nullptr);
+            const int est = final_pass ? 0 : L.est_scale;
+            if (est)
+                icp_accumulate_core<true>(cam, pr.depth_src, pr.nmap_tgt, sT[12], a.mind, a.maxd, L.md2, L.stride, L.Ws, L.Hs, r, t, member, a.members, sm, tot,
+                                          (dbg && gen < 16u) ? dbg + gen * 8 + 3 : nullptr);
+            else
+                icp_accumulate_core<false>(cam, pr.depth_src, pr.nmap_tgt, sT[12], a.mind, a.maxd, L.md2, L.stride, L.Ws, L.Hs, r, t, member, a.members, sm, tot,
+                                           (dbg && gen < 16u) ? dbg + gen * 8 + 3 : nullptr);
             ICP_STAMP(2);
             if (stage && tid == 0) stage[0] = 2u + 16u * gen;
             if (tid < ICP_SLAB) {
@@ -592,7 +761,7 @@ __global__ __launch_bounds__(256) void icp_batch_kernel(Cam cam, IcpBatchArgs a)
             __syncthreads();
             const int last = s_flag[1];
             if (last) {
-                const int fin = icp_finish(slab, a.members, st, L.damping, L.eps, L.eig_rel, final_pass, sm, tot, sT, it);
+                const int fin = icp_finish(slab, a.members, st, L.damping, L.eps, L.eig_rel, final_pass, sm, tot, est, sT, it);
                 if (tid < 64) {                            // wave 0 publishes
                     // thread 0 may just have written the new pose to sT: make that visible to lanes 1..12 of this wave
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -601,8 +770,8 @@ __global__ __launch_bounds__(256) void icp_batch_kernel(Cam cam, IcpBatchArgs a)
                     // pose words and the arrival counter of the next pass: one instruction, issued before the state stores have drained
                     // (returning forms: their data comes back only after the memory side has performed them)
                     unsigned old = 0;
-                    if (tid >= 1 && tid <= 12) old = __hip_atomic_exchange(genl + tid, __float_as_uint(sT[tid - 1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (tid == 13) old = __hip_atomic_exchange(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (tid >= 1 && tid <= 13) old = __hip_atomic_exchange(genl + tid, __float_as_uint(sT[tid - 1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (tid == 14) old = __hip_atomic_exchange(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     asm volatile("" ::"v"(old));
                     unsigned word = 0;
                     if (tid == 0) {
@@ -632,7 +801,7 @@ __global__ __launch_bounds__(256) void icp_batch_kernel(Cam cam, IcpBatchArgs a)
                 int failed = 0;
                 __builtin_amdgcn_s_sleep(100);             // the last arriver needs >= 3 us (sum, solve, update)
                 for (;;) {
-                    if (tid < 13) w = __hip_atomic_fetch_add(genl + tid, (unsigned)a.zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (tid < 14) w = __hip_atomic_fetch_add(genl + tid, (unsigned)a.zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     word = __builtin_amdgcn_readfirstlane(w);
                     if ((word >> 3) != gen) break;
                     if ((++polls & 63u) == 0u &&
@@ -648,7 +817,7 @@ __global__ __launch_bounds__(256) void icp_batch_kernel(Cam cam, IcpBatchArgs a)
                     a.ctl[9] = word;
                     a.ctl[10] = (unsigned)lv; a.ctl[11] = (unsigned)it;
                 }
-                if (tid >= 1 && tid <= 12) sT[tid - 1] = __uint_as_float(w);
+                if (tid >= 1 && tid <= 13) sT[tid - 1] = __uint_as_float(w);
                 if (tid == 0) { s_flag[2] = (int)word; s_flag[3] = failed; }
             }
             ICP_STAMP(6);

@@ -1121,7 +1121,8 @@ int tl3d_icp_enqueue(tl3d_ctx *ctx, int lane, int slot_src, double scale_src, in
     r->stride = prm->stride;
     r->Ws = (ctx->cam.W + prm->stride - 1) / prm->stride;
     r->Hs = (ctx->cam.H + prm->stride - 1) / prm->stride;
-    r->pad = 0;
+    r->est_scale = prm->estimate_scale ? 1 : 0;
+    h->scale = scale_src;
     r->damping = prm->damping;
     r->eps = prm->eps;
     r->eig_rel = prm->eig_rel;
@@ -1177,6 +1178,7 @@ int tl3d_icp_collect(tl3d_ctx *ctx, int lane, tl3d_icp_result *out) {
     out->rmse = h.sums[28] > 0 ? sqrt(h.sums[27] / h.sums[28]) : 0.0;
     out->iters_run = h.iters_run;
     out->status = h.status;
+    out->scale = h.scale;
     return TL3D_OK;
 }
 
@@ -1294,6 +1296,7 @@ int tl3d_icp_batch_enqueue(tl3d_ctx *ctx, const tl3d_icp_pair *pairs, int n_pair
         L.Ws = (ctx->cam.W + p.stride - 1) / p.stride;
         L.Hs = (ctx->cam.H + p.stride - 1) / p.stride;
         L.iters = p.iters;
+        L.est_scale = p.estimate_scale ? 1 : 0;
         L.damping = p.damping;
         L.eps = p.eps;
         L.eig_rel = p.eig_rel;
@@ -1329,6 +1332,7 @@ int tl3d_icp_batch_enqueue(tl3d_ctx *ctx, const tl3d_icp_pair *pairs, int n_pair
         IcpState &h = b.states_host[i];
         memset(&h, 0, sizeof(h));
         memcpy(h.T, pairs[i].T_init, sizeof(h.T));
+        h.scale = pairs[i].scale_src;
     }
     // uploads and normal maps are issued on the main stream: everything issued there so far precedes the batch
     TL3D_HIP(hipEventRecord(b.ev_ready, ctx->stream));
@@ -1430,6 +1434,7 @@ int tl3d_icp_batch_collect(tl3d_ctx *ctx, tl3d_icp_result *out, int n_out) {
         out[i].rmse = h.sums[28] > 0 ? sqrt(h.sums[27] / h.sums[28]) : 0.0;
         out[i].iters_run = h.iters_run;
         out[i].status = h.status;
+        out[i].scale = h.scale;
     }
     return TL3D_OK;
 }

@@ -48,7 +48,8 @@ struct Frustum {
 
 struct IcpState {                // lives in device memory for the whole ICP run (no host round trips)
     double T[16];
-    double sums[32];             // last reduced sums: a[21] b[6] e cnt nsrc
+    double sums[40];             // last reduced sums: a[21] b[6] e cnt nsrc . . c[6] cc bc (scale column, Sim(3) runs only)
+    double scale;                // metric scale of the source depth: the caller's value, updated by runs that estimate it
     int done;                    // set on convergence or failure: remaining iteration kernels exit at once
     int status;
     int iters_run;
@@ -59,7 +60,7 @@ struct IcpRun {                  // per-run arguments of the ICP kernels, read f
     const float *depth_src;      // kernel chain has constant launch arguments and can be replayed as a hipGraph
     const float4 *nmap_tgt;
     float scale, md2, mind, maxd;
-    int stride, Ws, Hs, pad;
+    int stride, Ws, Hs, est_scale;   // est_scale: the source depth's scale is a 7th unknown (Sim(3))
     double damping, eps, eig_rel;
 };
 
@@ -68,7 +69,7 @@ constexpr int ICP_MAX_LEVELS = 4;
 constexpr int ICP_BATCH_MAX_MEMBERS = 64;    // workgroups that share one pair
 constexpr int ICP_BATCH_SAMPLES_PER_MEMBER = 4096;
 struct IcpBatchPair { const float *depth_src; const float4 *nmap_tgt; float scale; int pad; };
-struct IcpLevel { float md2; int stride, Ws, Hs, iters, pad; double damping, eps, eig_rel; };
+struct IcpLevel { float md2; int stride, Ws, Hs, iters, est_scale; double damping, eps, eig_rel; };
 struct IcpBatchArgs {
     const IcpBatchPair *pairs;   // [n_pairs]
     IcpState *states;            // [n_pairs] initial pose in, result out
@@ -109,7 +110,7 @@ struct Slot {
 };
 
 constexpr int ICP_MAX_BLOCKS = 256;     // one reduce workgroup per CU; the solve sums the slab serially
-constexpr int ICP_SLAB = 32;     // doubles per block partial
+constexpr int ICP_SLAB = 40;     // doubles per block partial: 30 sums of the pose system (+ 2 unused), 8 of the scale column
 
 }  // namespace tl3d
 

@@ -288,22 +288,22 @@ class FusionContext:
         return out
 
     def icp(self, slot_src: int, slot_tgt: int, T_init=None, iters=10, stride=4, max_dist=0.05, damping=1e-6,
-            eps=1e-9, scale_src=1.0, eig_rel=1e-4):
+            eps=1e-9, scale_src=1.0, eig_rel=1e-4, estimate_scale=False):
         """Point-to-plane ICP; returns T (src camera -> tgt camera) and statistics.  With src = previous frame and
         tgt = current frame, (T[:3,:3], T[:3,3]) is (R_rel, t_rel) of depth_to_reconstruction.py:618-620."""
         T0 = np.ascontiguousarray(np.eye(4) if T_init is None else np.asarray(T_init, np.float64).reshape(4, 4))
-        prm = abi.IcpParams(int(iters), int(stride), float(max_dist), float(damping), float(eps), float(eig_rel))
+        prm = abi.IcpParams(int(iters), int(stride), float(max_dist), float(damping), float(eps), float(eig_rel), 1 if estimate_scale else 0, 0)
         res = abi.IcpResult()
         abi.check(self._lib.tl3d_icp_p2plane(self._h, int(slot_src), float(scale_src), int(slot_tgt), abi.ptr(T0),
                                              C.byref(prm), C.byref(res)))
         return dict(T=np.array(res.T).reshape(4, 4), fitness=res.fitness, rmse=res.rmse, n_corr=res.n_corr,
-                    n_src=res.n_src, iters_run=res.iters_run, status=res.status)
+                    n_src=res.n_src, iters_run=res.iters_run, status=res.status, scale=res.scale)
 
     def icp_enqueue(self, lane: int, slot_src: int, slot_tgt: int, T_init=None, iters=10, stride=4, max_dist=0.05,
-                    damping=1e-6, eps=1e-9, scale_src=1.0, eig_rel=1e-4):
+                    damping=1e-6, eps=1e-9, scale_src=1.0, eig_rel=1e-4, estimate_scale=False):
         """Asynchronous form: up to abi.ICP_LANES independent registrations in flight (one per lane)."""
         T0 = np.ascontiguousarray(np.eye(4) if T_init is None else np.asarray(T_init, np.float64).reshape(4, 4))
-        prm = abi.IcpParams(int(iters), int(stride), float(max_dist), float(damping), float(eps), float(eig_rel))
+        prm = abi.IcpParams(int(iters), int(stride), float(max_dist), float(damping), float(eps), float(eig_rel), 1 if estimate_scale else 0, 0)
         abi.check(self._lib.tl3d_icp_enqueue(self._h, int(lane), int(slot_src), float(scale_src), int(slot_tgt), abi.ptr(T0),
                                              C.byref(prm)))
 
@@ -311,7 +311,7 @@ class FusionContext:
         res = abi.IcpResult()
         abi.check(self._lib.tl3d_icp_collect(self._h, int(lane), C.byref(res)))
         return dict(T=np.array(res.T).reshape(4, 4), fitness=res.fitness, rmse=res.rmse, n_corr=res.n_corr,
-                    n_src=res.n_src, iters_run=res.iters_run, status=res.status)
+                    n_src=res.n_src, iters_run=res.iters_run, status=res.status, scale=res.scale)
 
     def icp_batch_enqueue(self, pairs, levels, T_init=None, scales=None):
         """Register every (slot_src, slot_tgt) of `pairs` through all of `levels` in ONE launch (asynchronous).
@@ -329,7 +329,8 @@ class FusionContext:
         lv = (abi.IcpParams * len(levels))()
         for i, kw in enumerate(levels):
             lv[i] = abi.IcpParams(int(kw.get("iters", 10)), int(kw.get("stride", 4)), float(kw.get("max_dist", 0.05)),
-                                  float(kw.get("damping", 1e-6)), float(kw.get("eps", 1e-9)), float(kw.get("eig_rel", 1e-4)))
+                                  float(kw.get("damping", 1e-6)), float(kw.get("eps", 1e-9)), float(kw.get("eig_rel", 1e-4)),
+                                  1 if kw.get("estimate_scale", False) else 0, 0)
         abi.check(self._lib.tl3d_icp_batch_enqueue(self._h, arr, n, lv, len(levels)))
         self._icp_batch_n = n
 
@@ -339,7 +340,7 @@ class FusionContext:
         abi.check(self._lib.tl3d_icp_batch_collect(self._h, res, n))
         self._icp_batch_n = 0
         return [dict(T=np.array(r.T).reshape(4, 4), fitness=r.fitness, rmse=r.rmse, n_corr=r.n_corr, n_src=r.n_src,
-                     iters_run=r.iters_run, status=r.status) for r in res[:n]]
+                     iters_run=r.iters_run, status=r.status, scale=r.scale) for r in res[:n]]
 
     def icp_batch(self, pairs, levels, T_init=None, scales=None):
         self.icp_batch_enqueue(pairs, levels, T_init, scales)

@@ -79,9 +79,10 @@ class ScaleTracker:
         self.history = [self.avg, self.avg]
         return self.avg
 
-    def update(self, scale_i=None) -> float:
+    def update(self, scale_i=None, weight: float = 0.3) -> float:
+        """D2R:650 with weight = 0.3; weight = 1 takes every view's own estimate as it comes."""
         if scale_i is not None:
-            self.avg = 0.7 * self.avg + 0.3 * scale_i
+            self.avg = (1.0 - weight) * self.avg + weight * scale_i
         self.history.append(self.avg)
         return self.avg
 
@@ -246,14 +247,66 @@ class DepthToReconstructionPipeline:
             i = batch[-1] + 1
         return poses, index
 
+    def _register_with_scale(self, ctx: FusionContext, scale0: float, init_poses=None, weight: float = 0.3):
+        """Registration of RELATIVE depth maps (row f3): every view's metric scale is the 7th unknown of its registration
+        against the previous kept view (Sim(3) point-to-plane ICP, tl3d_icp_params.estimate_scale), which replaces the
+        reference's median of Z_triangulated / depth over SIFT points (D2R:297-326, DER:659-697).  View 0 fixes the gauge
+        (scale0 = config.depth_scale, or the anchors' estimate); the running scale follows the reference's rule
+        avg = (1 - w) avg + w scale_i (D2R:650, w = 0.3; config.scale_update_weight = 1 trusts every view's own estimate).
+        The source of a run is the NEW view (unknown scale), the target the previous one (scale known, normals built with
+        it), so the run returns cur -> prev; its inverse is the (R_rel, t_rel) the reference chains (D2R:618-620).
+        Sequential by nature: a view's target needs that view's scale."""
+        cfg = self.config
+        n = len(self.depths)
+        wide = [(15, max(2, int(cfg.icp_stride) * 2), 1.0)] + [tuple(l) for l in cfg.icp_coarse] + [(cfg.icp_iters, cfg.icp_stride, cfg.icp_max_dist)]
+        common = dict(damping=cfg.icp_damping, eig_rel=cfg.icp_eig_rel, eps=cfg.icp_eps, estimate_scale=True)
+        level_list = [dict(iters=int(lv[0]), stride=int(lv[1]), max_dist=float(lv[2]), **common) for lv in wide][-abi.ICP_MAX_LEVELS:]
+        poses = [(np.eye(3), np.zeros((3, 1)))]
+        index, scales = [0], [float(scale0)] * n
+        tr = ScaleTracker(scale0)
+        tr.history = [tr.avg]
+        prev = 0
+        ctx.build_normals(0, scale=scale0)
+        T_guess = np.eye(4)                                  # cur -> prev of the last pair (constant velocity)
+        for cur in range(1, n):
+            print(f"\nProcessing image {cur}...")
+            T0 = T_guess
+            if init_poses is not None:
+                r0, t0 = init_poses[prev]
+                r1, t1 = init_poses[cur]
+                rr = np.asarray(r0) @ np.asarray(r1).T       # cur -> prev
+                T0 = np.eye(4)
+                T0[:3, :3], T0[:3, 3] = rr, (np.asarray(t0).reshape(3) - rr @ np.asarray(t1).reshape(3))
+            res = ctx.icp_batch([(cur, prev)], level_list, T_init=[T0], scales=[tr.avg])[0]
+            self.icp_log.append(dict(frame=cur, against=prev, scale=res["scale"], **{k: res[k] for k in ("fitness", "rmse", "n_corr", "iters_run", "status")}))
+            if res["status"] == 2 or res["n_corr"] < 8 or not np.isfinite(res["scale"]) or not (1e-3 < res["scale"] < 1e3):
+                print(f"  Skipping - registration failed (correspondences: {res['n_corr']})")
+                continue
+            s_cur = tr.update(res["scale"], weight)
+            scales[cur] = s_cur
+            T = res["T"]
+            Ti = np.eye(4)
+            Ti[:3, :3] = T[:3, :3].T
+            Ti[:3, 3] = -T[:3, :3].T @ T[:3, 3]              # prev -> cur = (R_rel, t_rel)
+            r_c, t_c = compose(Ti[:3, :3], Ti[:3, 3], *poses[-1])
+            poses.append((r_c, t_c))
+            index.append(cur)
+            print(f"  ICP: fitness {res['fitness']:.3f}, rmse {res['rmse'] * 1e3:.2f} mm, {res['iters_run']} iterations, scale {res['scale']:.6f} -> {s_cur:.6f}")
+            ctx.build_normals(cur, scale=s_cur)
+            T_guess = T
+            prev = cur
+        return poses, index, scales
+
     # ---- reconstruct ---------------------------------------------------------------------------------
-    def reconstruct(self, grid: Optional[GridSpec] = None, init_poses=None, poses=None, anchors=None):
+    def reconstruct(self, grid: Optional[GridSpec] = None, init_poses=None, poses=None, anchors=None, estimate_scale: bool = False):
         """(points, colors, camera_poses) like D2R:479-671.
 
         grid: fix the fusion volume (else planned from the data with Open3D's voxel origin).
         init_poses: optional per-frame pose priors for ICP; poses: skip registration and fuse with these poses.
         anchors: {frame: (points3d, pixels)} sparse metric anchors -> per-frame depth scale by the reference's rule
         (ScaleTracker); default: config.depth_scale for every frame (metric depth).
+        estimate_scale: relative depth with no anchors -- every view's scale is estimated by its registration (Sim(3) ICP,
+        _register_with_scale); view 0 keeps config.depth_scale (or its anchors' estimate).
         """
         if len(self.images) < 2:
             print("Need at least 2 images")
@@ -293,8 +346,13 @@ class DepthToReconstructionPipeline:
             if poses is not None:
                 self.camera_poses, self.frame_index = list(poses), list(range(len(poses)))
             else:
-                print("\n--- Step 1: Register frames (point-to-plane ICP, frame to frame) ---")
-                self.camera_poses, self.frame_index = self._register(ctx, self.scales, init_poses)
+                if estimate_scale:
+                    print("\n--- Step 1: Register frames (Sim(3) point-to-plane ICP: pose and depth scale, frame to frame) ---")
+                    self.camera_poses, self.frame_index, self.scales = self._register_with_scale(
+                        ctx, self.scales[0], init_poses, weight=float(getattr(cfg, "scale_update_weight", 0.3)))
+                else:
+                    print("\n--- Step 1: Register frames (point-to-plane ICP, frame to frame) ---")
+                    self.camera_poses, self.frame_index = self._register(ctx, self.scales, init_poses)
             marks.append(("register", clock()))
             if len(self.camera_poses) < 2:
                 print("Pose estimation failed")
@@ -379,7 +437,9 @@ class DepthToReconstructionPipeline:
           3. scene bounds: per-rank min / max, MIN / MAX all-reduce -> every rank plans the same grid;
           4. rank r fuses its own frames into its private grid;
           5. ONE sum all-reduce of the integer grids (RCCL over xGMI with the nccl backend) -> every rank holds the merged
-             grid, bit-identical to a single-GPU run; rank 0 extracts, filters and returns the cloud (other ranks return
+             grid, bit-identical to a single-GPU run GIVEN THE SAME POSES (pairs are registered independently here, from
+             identity or init_poses; reconstruct() seeds later batches with a constant-velocity prior, so the two can converge
+             to poses that differ in the last bits); rank 0 extracts, filters and returns the cloud (other ranks return
              (None, None, poses)).
         Every frame must be loaded on every rank's host (load_data); only the rank's own range goes to its GPU."""
         from . import distributed as dd
@@ -431,7 +491,7 @@ class DepthToReconstructionPipeline:
                         src_slot = slot_of
                         if want not in slot_of:                               # the source frame lives on another rank's GPU: bring it here
                             ctx.upload(spare, self.depths[want], self.images[want])
-                            src_slot = dict(slot_of, **{want: spare})
+                            src_slot = {**slot_of, want: spare}
                         fixed = self._register_pairs(ctx, [(want, cur)], src_slot, self.scales, init_poses)
                     dd.exchange_registrations(fixed, n, dist, into=table)
                 self.camera_poses, self.frame_index, self.icp_log = dd.chain_from_table(table, n)
