@@ -127,6 +127,10 @@ typedef struct tl3d_stats {
     uint64_t centroid_dropped;       /* valid points that fell outside the grid                         */
     double tsdf_kernel_ms;           /* summed hipEvent time of the integrate kernels (profile mode)    */
     uint64_t tsdf_kernel_timed;      /* launches contributing to tsdf_kernel_ms                         */
+    uint64_t tsdf_batch_bricks;      /* bricks the update launches visited (a brick once per batch of frames; counting mode) */
+    uint64_t bp_lookback_retries;    /* tl3d_backproject calls repeated in dynamic tile order after a look-back time-out */
+    uint64_t icp_batch_timeouts;     /* batched registrations whose in-launch barrier timed out ...                  */
+    uint64_t icp_batch_fallback_pairs; /* ... and the pairs re-registered through the per-iteration kernel instead   */
 } tl3d_stats;
 
 const char *tl3d_last_error(void);

@@ -469,8 +469,9 @@ def test_free_space_counters_fold_to_the_same_grid():
     """Free-space bricks are counted (one add per brick and frame) and folded into the records before anything reads the
     TSDF channel: download, merge, extraction, weight check and checkpoint see the oracle's grid bit for bit, and the counting
     mode reports which bricks were counted instead of streamed."""
-    poses, frames = small_scene_frames(n=6, deg=9.0, scene=None)
-    ctx, orc = make_pair(dims=(96, 96, 96), voxel=0.025, centre=(0.0, -0.2, 0.0), n_slots=6)
+    cam = dict(width=320, height=240, fx=280.0, fy=280.0, cx=159.5, cy=119.5)
+    poses, frames = small_scene_frames(n=6, deg=9.0, scene=None, cam=cam)
+    ctx, orc = make_pair(cam=cam, dims=(160, 136, 160), voxel=0.0125, centre=(0.0, -0.2, 0.0), n_slots=6, channels=tl3d.CH_TSDF)
     with ctx:
         ctx.set_profile(True, False)
         for i, (d, c) in enumerate(frames):
@@ -479,7 +480,7 @@ def test_free_space_counters_fold_to_the_same_grid():
             ctx.integrate(i, poses[i])
             orc.tsdf_integrate(frames[i][0], poses[i][0], poses[i][1])
         st = ctx.stats()
-        assert st["tsdf_bricks_free"] >= 5 and st["tsdf_bricks_free_counted"] == st["tsdf_bricks_free"]      # default: counted
+        assert st["tsdf_bricks_free"] >= 300 and st["tsdf_bricks_free_counted"] == st["tsdf_bricks_free"], st["tsdf_bricks_free"]
         assert np.array_equal(ctx.download_grid(tl3d.CH_TSDF), orc.tsdf)                    # folded by the download
         for i in range(3, 6):                                                               # more frames on top of folded + new counts
             ctx.integrate(i, poses[i])
@@ -741,3 +742,69 @@ def test_sim3_icp_keeps_the_prior_where_the_scale_is_not_observed():
     assert res["status"] in (0, 1) and abs(res["scale"] - 1.0) < 1e-4, res["scale"]
     assert abs(res["scale"] - ores["scale"]) < 1e-6 and np.linalg.norm(res["T"] - ores["T"]) < 1e-4
     assert np.linalg.norm(res["T"] - np.eye(4)) < 1e-3                         # sliding along the plane is not observed either
+
+
+def test_a_timed_out_batched_registration_falls_back_to_the_per_iteration_kernel(tmp_path):
+    """icp_batch_kernel's workgroups wait for one another inside the launch (bounded waits).  When a wait does time out the
+    batch is registered again on the ICP lanes instead of failing the run; the rehearsal forces the time-out flag in the
+    experiments flavour of the library (the shipped one has no such switch) and compares with the normal run."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exp = os.path.join(root, "textureless-3d-reconstruction_amd", "libtl3d_exp.so")
+    if not os.path.exists(exp):
+        subprocess.check_call(["bash", os.path.join(root, "textureless-3d-reconstruction_amd", "csrc", "build.sh")],
+                              env=dict(os.environ, TL3D_FLAVOUR="experiments"))
+    code = r'''
+import json, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, tl3d
+from helpers import make_pair, small_scene_frames
+poses, frames = small_scene_frames(n=4, deg=2.0)
+ctx, orc = make_pair(n_slots=4)
+with ctx:
+    for i, (d, c) in enumerate(frames):
+        ctx.upload(i, d, None)
+        ctx.build_normals(i)
+    lv = [dict(iters=8, stride=4, max_dist=0.2), dict(iters=10, stride=2, max_dist=0.05)]
+    res = ctx.icp_batch([(0, 1), (1, 2), (2, 3)], lv)
+    st = ctx.stats()
+print(json.dumps(dict(T=[r["T"].tolist() for r in res], n=[r["n_corr"] for r in res], timeouts=st["icp_batch_timeouts"],
+                      fallback=st["icp_batch_fallback_pairs"])))
+''' % (root, os.path.join(root, "tests"))
+    outs = []
+    for env in (dict(os.environ), dict(os.environ, TL3D_LIB=exp, TL3D_ICP_FORCE_TIMEOUT="1")):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append((json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1]), r.stderr))
+    (a, _), (b, err) = outs
+    assert a["timeouts"] == 0 and a["fallback"] == 0
+    assert b["timeouts"] == 1 and b["fallback"] == 3 and "re-registering 3 pairs" in err
+    assert a["n"] == b["n"] and np.abs(np.asarray(a["T"]) - np.asarray(b["T"])).max() < 1e-8
+
+
+def test_reset_followed_at_once_by_integrate_on_a_large_grid():
+    """tl3d_grid_reset clears 1 GiB of records and the free-space counters on the main stream; the classification kernels of
+    the next frames add to those counters on a side stream.  They are ordered behind the clear (an event the prep chains wait
+    for): on a 512^3 grid, where the clear takes long enough to lose that race, reset -> integrate -> download == oracle."""
+    cam = dict(width=320, height=240, fx=280.0, fy=280.0, cx=159.5, cy=119.5)
+    poses, frames = small_scene_frames(n=3, deg=5.0, cam=cam)
+    ctx, orc = make_pair(cam=cam, dims=(512, 512, 512), voxel=0.005, centre=(0.0, -0.1, 0.0), n_slots=3, channels=tl3d.CH_TSDF)
+    with ctx:
+        for i, (d, c) in enumerate(frames):
+            ctx.upload(i, d, None)
+        for i in range(3):                                  # something to clear, counters included
+            ctx.integrate(i, poses[i])
+        ctx.sync()
+        for rep in range(2):
+            ctx.reset()
+            for i in range(3):
+                ctx.integrate(i, poses[i])
+            g = ctx.download_grid(tl3d.CH_TSDF)
+            if rep == 0:
+                for i in range(3):
+                    orc.tsdf_integrate(frames[i][0], poses[i][0], poses[i][1])
+            assert np.array_equal(g, orc.tsdf), rep
+    assert int(orc.tsdf[:, 1].sum()) > 10 ** 6

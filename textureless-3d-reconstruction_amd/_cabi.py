@@ -69,7 +69,9 @@ ICP_MAX_LEVELS = 4
 class Stats(C.Structure):
     _fields_ = [("tsdf_launches", C.c_uint64), ("tsdf_records_read", C.c_uint64), ("tsdf_records_written", C.c_uint64),
                 ("tsdf_bricks_visited", C.c_uint64), ("tsdf_bricks_free", C.c_uint64), ("tsdf_bricks_free_counted", C.c_uint64), ("centroid_launches", C.c_uint64), ("centroid_points", C.c_uint64),
-                ("centroid_dropped", C.c_uint64), ("tsdf_kernel_ms", C.c_double), ("tsdf_kernel_timed", C.c_uint64)]
+                ("centroid_dropped", C.c_uint64), ("tsdf_kernel_ms", C.c_double), ("tsdf_kernel_timed", C.c_uint64),
+                ("tsdf_batch_bricks", C.c_uint64), ("bp_lookback_retries", C.c_uint64), ("icp_batch_timeouts", C.c_uint64),
+                ("icp_batch_fallback_pairs", C.c_uint64)]
 
 
 _lib = None

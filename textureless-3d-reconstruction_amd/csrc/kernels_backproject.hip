@@ -53,9 +53,6 @@ __global__ __launch_bounds__(1024) void scan_kernel(const unsigned *__restrict__
 #ifndef TL3D_BP_SLEEP
 #define TL3D_BP_SLEEP 1                        // x 64 cycles between two polls of a granule
 #endif
-#ifndef TL3D_BP_PAD
-#define TL3D_BP_PAD 0                          // diagnostic builds only: unused LDS bytes in front of and behind the block
-#endif
 constexpr int BP_TILE = 2048;                  // samples per workgroup (8 per thread)
 constexpr int BP_PER = BP_TILE / 256;
 constexpr int BP_WIN = 1024;                   // predecessors one look-back round inspects (4 per thread)
@@ -79,10 +76,10 @@ __global__ __launch_bounds__(256) void bp_fused_kernel(Cam cam, BpArgs a, PoseD 
                                                        unsigned long long *__restrict__ total_out) {
     // one LDS block, carved by hand: [xyz staging | rgb staging | per-(iteration, wave) counts | reduction scratch | scalars]
     constexpr int XYZ_B = WRITE ? (3 * BP_TILE + 4) * 4 : 16, RGB_B = WRITE ? 3 * BP_TILE + 16 : 16;
-    constexpr int O_WAVE = TL3D_BP_PAD + XYZ_B + RGB_B, O_RED = O_WAVE + BP_PER * 16, O_SC = O_RED + 64;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[O_SC + 32 + TL3D_BP_PAD];
-    float *const s_xyz = reinterpret_cast<float *>(smem + TL3D_BP_PAD);
-    uint8_t *const s_rgb = smem + TL3D_BP_PAD + XYZ_B;
+    constexpr int O_WAVE = XYZ_B + RGB_B, O_RED = O_WAVE + BP_PER * 16, O_SC = O_RED + 64;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[O_SC + 32];
+    float *const s_xyz = reinterpret_cast<float *>(smem);
+    uint8_t *const s_rgb = smem + XYZ_B;
     unsigned *const s_wave = reinterpret_cast<unsigned *>(smem + O_WAVE);          // [j * 4 + w]: survivors, then exclusive prefix
     unsigned long long *const s_red = reinterpret_cast<unsigned long long *>(smem + O_RED);   // [0..3] per-wave partials, [4] result
     unsigned long long &s_excl = *reinterpret_cast<unsigned long long *>(smem + O_SC);
@@ -372,7 +369,19 @@ int launch_bp_fused(hipStream_t s, const Cam &cam, const BpArgs &a, const PoseD 
     constexpr int pin = 0;
 #endif
     BpArgs ad = a;
-    const bool stat = pin == 2 || (pin == 0 && !force_dynamic && nt <= 1024);
+    // how many workgroups of this kernel the device holds at once, from the runtime (registers, LDS, CU count), not a constant
+    static int resident = -1;
+    if (resident < 0) {
+        int per_cu = 0, cus = 0, dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bp_fused_kernel<true>, 256, 0) == hipSuccess && per_cu > 0 && cus > 0)
+            resident = per_cu * cus;
+        else {
+            (void)hipGetLastError();
+            resident = 0;                                  // unknown: always dynamic order
+        }
+    }
+    const bool stat = pin == 2 || (pin == 0 && !force_dynamic && nt <= resident);
     if (stat) ad.flags |= BP_F_STATIC_ORDER;
     if (xyz && rgb)
         hipLaunchKernelGGL(bp_fused_kernel<true>, dim3(nt), dim3(256), 0, s, cam, ad, p, depth, bgr, xf, yf, state, xyz, rgb, cap, total_out);

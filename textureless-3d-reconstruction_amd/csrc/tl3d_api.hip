@@ -513,6 +513,7 @@ int tl3d_sync(tl3d_ctx *ctx) {
         if (ctx->prep_stream[q]) TL3D_HIP(hipStreamSynchronize(ctx->prep_stream[q]));
     for (int l = 0; l < TL3D_ICP_LANES; ++l)
         if (ctx->icp_lanes[l].stream) TL3D_HIP(hipStreamSynchronize(ctx->icp_lanes[l].stream));
+    if (ctx->icp_batch.stream) TL3D_HIP(hipStreamSynchronize(ctx->icp_batch.stream));
     TL3D_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->bp_async_pending && ctx->bp_state) {
         ctx->bp_async_pending = false;
@@ -706,6 +707,7 @@ int tl3d_backproject(tl3d_ctx *ctx, int slot, const double R[9], const double t[
         rc = bp_check_error(ctx, h[1]);
         if (rc == TL3D_OK) break;
         if (attempt == 1) return rc;
+        ctx->stats.bp_lookback_retries++;                               // (never seen so far; tl3d_get_stats shows it if it happens)
     }
     const unsigned long long total = h[0];
     *out_n = (int64_t)total;
@@ -737,8 +739,13 @@ int tl3d_backproject_device(tl3d_ctx *ctx, int slot, const double R[9], const do
     if (rc) return rc;
     const PoseD p = make_pose_d(R, t, (flags & TL3D_F_NO_POSE) != 0);
     ctx->bp_async_pending = true;                       // tl3d_sync reports a look-back time-out of these launches
+    // nobody reads the error word back between these launches: an earlier time-out must not make every later launch give up
+    // (the word is cleared IN STREAM ORDER; tl3d_sync still reports a time-out of the last launch), and with a batched
+    // registration spinning on the chip the static tile order's "every tile is resident" cannot be taken for granted
+    TL3D_HIP(hipMemsetAsync(ctx->bp_state + 1, 0, sizeof(unsigned long long), ctx->stream));
     return launch_bp_fused(ctx->stream, ctx->cam, a, p, s.depth, s.has_color ? s.bgr : nullptr, ctx->bp_factors, ctx->bp_factors + ctx->cam.W,
-                           ctx->bp_state, out_xyz_dev, out_rgb_dev, (unsigned long long)cap, reinterpret_cast<unsigned long long *>(out_n_dev));
+                           ctx->bp_state, out_xyz_dev, out_rgb_dev, (unsigned long long)cap, reinterpret_cast<unsigned long long *>(out_n_dev),
+                           ctx->icp_batch.busy);
 }
 
 int tl3d_frames_bounds(tl3d_ctx *ctx, int n_frames, const int32_t *slots, const double *R, const double *t, const double *scales,
@@ -1227,6 +1234,7 @@ static void icp_batch_free(tl3d_ctx::IcpBatch &b) {
     if (b.pairs_host) (void)hipHostFree(b.pairs_host);
     if (b.states_host) (void)hipHostFree(b.states_host);
     if (b.ctl_host) (void)hipHostFree(b.ctl_host);
+    free(b.req_pairs);
     if (b.ev_ready) (void)hipEventDestroy(b.ev_ready);
     if (b.ev_done) (void)hipEventDestroy(b.ev_done);
     if (b.stream) (void)hipStreamDestroy(b.stream);
@@ -1323,6 +1331,15 @@ int tl3d_icp_batch_enqueue(tl3d_ctx *ctx, const tl3d_icp_pair *pairs, int n_pair
     int rc = icp_batch_reserve(ctx, n_pairs, (size_t)n_pairs * (size_t)members * ICP_SLAB);
     if (rc) return rc;
     tl3d_ctx::IcpBatch &b = ctx->icp_batch;
+    if (n_pairs > b.req_cap) {
+        free(b.req_pairs);
+        b.req_pairs = (tl3d_icp_pair *)malloc((size_t)n_pairs * sizeof(tl3d_icp_pair));
+        b.req_cap = b.req_pairs ? n_pairs : 0;
+        REQUIRE(b.req_pairs != nullptr, TL3D_E_NOMEM, "host allocation failed");
+    }
+    memcpy(b.req_pairs, pairs, (size_t)n_pairs * sizeof(tl3d_icp_pair));
+    memcpy(b.req_levels, levels, (size_t)n_levels * sizeof(tl3d_icp_params));
+    b.req_n_levels = n_levels;
     for (int i = 0; i < n_pairs; ++i) {
         const Slot &ss = ctx->slots[pairs[i].slot_src], &st = ctx->slots[pairs[i].slot_tgt];
         b.pairs_host[i].depth_src = ss.depth;
@@ -1380,6 +1397,40 @@ int tl3d_icp_batch_enqueue(tl3d_ctx *ctx, const tl3d_icp_pair *pairs, int n_pair
     return TL3D_OK;
 }
 
+// The batch of the last enqueue, registered by the per-iteration kernel: up to TL3D_ICP_LANES pairs side by side, level
+// after level; a pair's next level starts from the pose (and scale) its previous level ended with, and a pair stops when a
+// level fails or ends with fewer than 8 correspondences -- the rule icp_batch_kernel applies between its levels.
+static int icp_batch_fallback(tl3d_ctx *ctx, tl3d_icp_result *out, int n_out) {
+    tl3d_ctx::IcpBatch &b = ctx->icp_batch;
+    for (int l = 0; l < TL3D_ICP_LANES; ++l)
+        REQUIRE(!ctx->icp_lanes[l].busy, TL3D_E_STATE, "the batched registration timed out and ICP lane %d holds an uncollected run: cannot fall back", l);
+    std::vector<char> over((size_t)n_out, 0);
+    for (int i = 0; i < n_out; ++i) {
+        memset(&out[i], 0, sizeof(out[i]));
+        memcpy(out[i].T, b.req_pairs[i].T_init, sizeof(out[i].T));
+        out[i].scale = b.req_pairs[i].scale_src;
+    }
+    for (int lv = 0; lv < b.req_n_levels; ++lv)
+        for (int i0 = 0; i0 < n_out; i0 += TL3D_ICP_LANES) {
+            const int m = n_out - i0 < TL3D_ICP_LANES ? n_out - i0 : TL3D_ICP_LANES;
+            for (int k = 0; k < m; ++k) {
+                const int i = i0 + k;
+                if (over[i]) continue;
+                const int rc = tl3d_icp_enqueue(ctx, k, b.req_pairs[i].slot_src, out[i].scale, b.req_pairs[i].slot_tgt, out[i].T, &b.req_levels[lv]);
+                if (rc) return rc;
+            }
+            for (int k = 0; k < m; ++k) {
+                const int i = i0 + k;
+                if (over[i]) continue;
+                const int rc = tl3d_icp_collect(ctx, k, &out[i]);
+                if (rc) return rc;
+                if (out[i].status == 2 || out[i].n_corr < 8) over[i] = 1;
+            }
+        }
+    ctx->stats.icp_batch_fallback_pairs += (uint64_t)n_out;
+    return TL3D_OK;
+}
+
 int tl3d_icp_batch_collect(tl3d_ctx *ctx, tl3d_icp_result *out, int n_out) {
     REQUIRE(ctx && out, TL3D_E_INVALID, "null argument");
     tl3d_ctx::IcpBatch &b = ctx->icp_batch;
@@ -1422,9 +1473,21 @@ int tl3d_icp_batch_collect(tl3d_ctx *ctx, tl3d_icp_result *out, int n_out) {
         }
     }
 #endif
-    REQUIRE(b.ctl_host[1] == 0, TL3D_E_HIP, "ICP batch: a workgroup timed out waiting for its pair (pair %u member %u pass %u level %u iteration %u: "
-            "%u of its workgroups had arrived, generation word %u; %u workgroups started, %u polls)", b.ctl_host[4], b.ctl_host[5], b.ctl_host[6],
-            b.ctl_host[10], b.ctl_host[11], b.ctl_host[8], b.ctl_host[9], b.ctl_host[0], b.ctl_host[7]);
+    bool timed_out = b.ctl_host[1] != 0;
+#ifdef TL3D_EXPERIMENTS
+    if (getenv("TL3D_ICP_FORCE_TIMEOUT")) timed_out = true;              // rehearsal of the fallback below
+#endif
+    if (timed_out) {
+        // A wait inside the launch ran into its time bound (the waits need a pair's other workgroups to be running; other
+        // work on the chip can, in principle, keep them off it).  The launch has ended; its results are discarded and the
+        // whole batch is registered again by the per-iteration kernel on the ICP lanes, which waits for nobody inside a
+        // launch: same levels, same chaining rule.
+        ctx->stats.icp_batch_timeouts++;
+        fprintf(stderr, "libtl3d: batched registration timed out inside its launch (pair %u member %u pass %u level %u iteration %u: %u of its "
+                        "workgroups had arrived, %u workgroups started); re-registering %d pairs on the per-iteration kernel\n",
+                b.ctl_host[4], b.ctl_host[5], b.ctl_host[6], b.ctl_host[10], b.ctl_host[11], b.ctl_host[8], b.ctl_host[0], n_out);
+        return icp_batch_fallback(ctx, out, n_out);
+    }
     for (int i = 0; i < n_out; ++i) {
         const IcpState &h = b.states_host[i];
         memcpy(out[i].T, h.T, sizeof(out[i].T));
@@ -1777,6 +1840,7 @@ int tl3d_get_stats(tl3d_ctx *ctx, tl3d_stats *out) {
     ctx->stats.tsdf_bricks_visited = h[4];
     ctx->stats.tsdf_bricks_free = h[5];
     ctx->stats.tsdf_bricks_free_counted = h[6];
+    ctx->stats.tsdf_batch_bricks = h[7];
     *out = ctx->stats;
     return TL3D_OK;
 }

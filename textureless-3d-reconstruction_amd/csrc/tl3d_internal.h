@@ -211,6 +211,9 @@ struct tl3d_ctx {
         unsigned *sync, *ctl, *ctl_host;
         double *slab;
         int n_pairs;             // of the run in flight
+        tl3d_icp_pair *req_pairs;                // the request as the caller made it: the fallback of a timed-out launch re-registers from it
+        int req_cap, req_n_levels;
+        tl3d_icp_params req_levels[TL3D_ICP_MAX_LEVELS];
         unsigned *stage; size_t stage_n;  // experiments (TL3D_ICP_STAGES)
         unsigned long long *dbg; // experiments (TL3D_ICP_TRACE)
         int dbg_members;
