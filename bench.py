@@ -198,7 +198,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    merge_ms = []
+    merge_ms, merge_info = [], []
 
     def merge():
         # the product's merge: int32-headroom check + RCCL sum all-reduce on the library's own grid memory (zero-copy)
@@ -207,9 +207,10 @@ def main():
             ctx.sync()
             tm = time.perf_counter()
             if world == 1:                                      # --force-dist: the RCCL path with one rank
-                allreduce_context_grids(ctx, dist)
+                info = allreduce_context_grids(ctx, dist)
             else:
-                merge_context_grids(ctx, dist)
+                info = merge_context_grids(ctx, dist)
+            merge_info.append(info)
             ctx.sync()
             merge_ms.append(1e3 * (time.perf_counter() - tm))
 
@@ -222,6 +223,7 @@ def main():
     if dist is not None and args.warmup > 0:
         merge()                                                 # warm the communicator
         merge_ms.clear()
+        merge_info.clear()
     ctx.reset()
     barrier()
     ctx.event_record(0)
@@ -448,6 +450,8 @@ def main():
                        "parallelism": f"frame-shard x{world}" + (f" + {n_merges} RCCL all-reduce(s) of the grid" if world > 1 else ""),
                        "grid_merges_in_timed_region": n_merges if dist is not None else 0,
                        "merge_ms": [round(x, 2) for x in merge_ms],
+                       "merge_bricks_sent_of_total": [[m["bricks_sent"], m["bricks_total"]] for m in merge_info if m],
+                       "merge_bytes": [m["bytes"] for m in merge_info if m],
                        "dist_backend": (backend if dist is not None else None),
                        "dist_ranks": (dist.get_world_size() if dist is not None else 1),
                        "invalid_pixel_fraction": round(invalid_frac, 4),

@@ -131,6 +131,8 @@ typedef struct tl3d_stats {
     uint64_t bp_lookback_retries;    /* tl3d_backproject calls repeated in dynamic tile order after a look-back time-out */
     uint64_t icp_batch_timeouts;     /* batched registrations whose in-launch barrier timed out ...                  */
     uint64_t icp_batch_fallback_pairs; /* ... and the pairs re-registered through the per-iteration kernel instead   */
+    uint64_t merge_bricks_sent;      /* tl3d_allreduce_grid: bricks whose records went over the wire (all merges so far) ... */
+    uint64_t merge_bricks_total;     /* ... of this many bricks in the grid                                              */
 } tl3d_stats;
 
 const char *tl3d_last_error(void);
@@ -268,6 +270,17 @@ int tl3d_grid_upload(tl3d_ctx *ctx, uint32_t channel, const void *in_hd, size_t 
 int tl3d_grid_add(tl3d_ctx *ctx, uint32_t channel, const void *other_hd, size_t bytes);   /* grid += other (merge) */
 /* largest number of observations any voxel of the TSDF channel holds (one reduction over the grid, blocks) */
 int tl3d_grid_max_weight(tl3d_ctx *ctx, int64_t *out);
+
+/* Sparse form of the merge (a frame-sharded run touches a few per cent of a large grid): which bricks hold anything, and their
+ * records as one contiguous block.  tl3d_grid_touched_bricks ORs 1 into map[b] (one byte per brick, nx ny nz / 512 of them, device
+ * memory; the caller zeroes it) for every brick with a TSDF weight or a centroid count in the selected channels; after a MAX
+ * all-reduce of the map every rank holds the same brick set.  tl3d_grid_pack_bricks copies the records of bricks[0 .. n) (device
+ * memory, ascending brick indices) of ONE channel into `packed` (n x 4 KB for TL3D_CH_TSDF, n x 16 KB for TL3D_CH_CENTROID, device
+ * memory); tl3d_grid_unpack_bricks writes such a block back (after the SUM all-reduce).  tl3d.distributed.merge_context_grids and
+ * tl3d_allreduce_grid use them when fewer than half of the bricks are touched.  */
+int tl3d_grid_touched_bricks(tl3d_ctx *ctx, uint32_t channels, uint8_t *map_dev, int64_t n_bricks);
+int tl3d_grid_pack_bricks(tl3d_ctx *ctx, uint32_t channel, const uint32_t *bricks_dev, int64_t n, void *packed_dev);
+int tl3d_grid_unpack_bricks(tl3d_ctx *ctx, uint32_t channel, const uint32_t *bricks_dev, int64_t n, const void *packed_dev);
 
 /* e: the merge step of the multi-GPU path for hosts WITHOUT torch.distributed (frames shard across
  * ranks, one sum all-reduce of the per-GPU grids at merge time).  One process per GPU; rank 0 obtains an id and hands it

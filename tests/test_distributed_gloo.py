@@ -59,7 +59,11 @@ def _worker(rank, world, port, out_dir):
     for i in range(lo, hi):
         orc.tsdf_integrate(frames[i][0], chained[i][0], chained[i][1])
         orc.centroid_accumulate(frames[i][0], frames[i][1], chained[i][0], chained[i][1], subsample=2)
-    allreduce_grid_arrays(orc.tsdf, orc.centroid, dist)
+    dense_t, dense_c = orc.tsdf.copy(), orc.centroid.copy()
+    info = allreduce_grid_arrays(orc.tsdf, orc.centroid, dist)               # sparse: only the bricks some rank touched travel
+    info_d = allreduce_grid_arrays(dense_t, dense_c, dist, sparse=False)
+    assert np.array_equal(dense_t, orc.tsdf) and np.array_equal(dense_c, orc.centroid)
+    assert info["bricks_total"] == info_d["bricks_sent"] == 512 and 0 < info["bricks_sent"] < 256 and info["bytes"] < info_d["bytes"] / 2
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), tsdf=orc.tsdf, centroid=orc.centroid,
              poses=np.array([np.hstack([r, t.reshape(3, 1)]) for r, t in chained]))
     dist.barrier()

@@ -712,7 +712,7 @@ def test_sim3_icp_matches_the_oracle_and_recovers_the_scale():
             for res in (one, batch[k]):
                 assert np.linalg.norm(res["T"] - ores["T"]) < 1e-4, (i, np.linalg.norm(res["T"] - ores["T"]))
                 assert abs(res["scale"] - ores["scale"]) < 1e-6 * ores["scale"], (i, res["scale"], ores["scale"])
-                assert res["n_corr"] == ores["n_corr"]
+                assert abs(res["n_corr"] - ores["n_corr"]) <= 1e-3 * ores["n_corr"]      # (exp() of device and host differ in the last bit: border samples)
             assert abs(one["scale"] - true_s[i]) < 2e-3 * true_s[i], (i, one["scale"])
             if i == 1:                                                         # (views 2, 3 start 8 / 12 degrees off: parity only)
                 r_rel, t_rel = synth.relative_pose(poses[i], poses[0])         # view i -> view 0

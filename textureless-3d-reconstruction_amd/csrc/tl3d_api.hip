@@ -1622,6 +1622,43 @@ int tl3d_grid_add(tl3d_ctx *ctx, uint32_t channel, const void *other, size_t byt
     return rc;
 }
 
+int tl3d_grid_touched_bricks(tl3d_ctx *ctx, uint32_t channels, uint8_t *map_dev, int64_t n_bricks) {
+    REQUIRE(ctx && map_dev, TL3D_E_INVALID, "null argument");
+    if (channels == 0) channels = (ctx->tsdf ? TL3D_CH_TSDF : 0u) | (ctx->centroid ? TL3D_CH_CENTROID : 0u);
+    REQUIRE((channels & ~(TL3D_CH_TSDF | TL3D_CH_CENTROID)) == 0, TL3D_E_INVALID, "bad channel mask 0x%x", channels);
+    if (channels & TL3D_CH_TSDF) REQUIRE(ctx->tsdf != nullptr, TL3D_E_STATE, "TSDF channel not enabled");
+    if (channels & TL3D_CH_CENTROID) REQUIRE(ctx->centroid != nullptr, TL3D_E_STATE, "centroid channel not enabled");
+    REQUIRE(n_bricks == (int64_t)(ctx->nvox >> 9), TL3D_E_INVALID, "the grid has %zu bricks, the map %lld", ctx->nvox >> 9, (long long)n_bricks);
+    REQUIRE(is_device_ptr(map_dev), TL3D_E_INVALID, "the brick map must be device memory");
+    FLUSH_AND_FOLD(ctx);
+    TL3D_HIP(hipSetDevice(ctx->device));
+    return launch_touched_bricks(ctx->stream, (channels & TL3D_CH_TSDF) ? ctx->tsdf : nullptr, (channels & TL3D_CH_CENTROID) ? ctx->centroid : nullptr,
+                                 (unsigned)n_bricks, map_dev);
+}
+
+static int brick_rows(tl3d_ctx *ctx, uint32_t channel, const uint32_t *bricks_dev, int64_t n, void *packed_dev, bool pack) {
+    void *p;
+    size_t nb;
+    int rc = grid_sel(ctx, channel, &p, &nb);
+    if (rc) return rc;
+    REQUIRE(n >= 0 && n <= (int64_t)(ctx->nvox >> 9), TL3D_E_INVALID, "brick count %lld out of range", (long long)n);
+    if (n == 0) return TL3D_OK;
+    REQUIRE(bricks_dev && packed_dev && is_device_ptr(bricks_dev) && is_device_ptr(packed_dev), TL3D_E_INVALID, "brick list and block must be device memory");
+    FLUSH_AND_FOLD(ctx);
+    ctx->grid_epoch++;
+    TL3D_HIP(hipSetDevice(ctx->device));
+    if (!pack && channel == TL3D_CH_TSDF) ctx->tsdf_w_unknown = true;      // the records now hold what the caller summed
+    return launch_brick_rows(ctx->stream, pack, p, bricks_dev, n, channel == TL3D_CH_TSDF ? 4096u : 16384u, packed_dev);
+}
+
+int tl3d_grid_pack_bricks(tl3d_ctx *ctx, uint32_t channel, const uint32_t *bricks_dev, int64_t n, void *packed_dev) {
+    return brick_rows(ctx, channel, bricks_dev, n, packed_dev, true);
+}
+
+int tl3d_grid_unpack_bricks(tl3d_ctx *ctx, uint32_t channel, const uint32_t *bricks_dev, int64_t n, const void *packed_dev) {
+    return brick_rows(ctx, channel, bricks_dev, n, const_cast<void *>(packed_dev), false);
+}
+
 int tl3d_grid_max_weight(tl3d_ctx *ctx, int64_t *out) {
     REQUIRE(ctx && out, TL3D_E_INVALID, "null argument");
     REQUIRE(ctx->tsdf != nullptr, TL3D_E_STATE, "TSDF channel not enabled");
@@ -1695,16 +1732,72 @@ int tl3d_allreduce_grid(tl3d_ctx *ctx, uint32_t channels) {
         REQUIRE(total <= TL3D_TSDF_MAX_WEIGHT, TL3D_E_STATE,
                 "the merged TSDF grid could hold %lld observations per voxel (limit %d): merge more often or extract between scans", total,
                 TL3D_TSDF_MAX_WEIGHT);
-        nrc = g_rccl.AllReduce(ctx->tsdf, ctx->tsdf, ctx->nvox * 2, 2 /* ncclInt32 */, 0, ctx->rccl_comm, ctx->stream);
-        REQUIRE(nrc == 0, TL3D_E_HIP, "ncclAllReduce (TSDF) failed: %s", rccl_msg(nrc));
         ctx->tsdf_w_upper = total;
         ctx->tsdf_w_unknown = false;
     }
-    if (channels & TL3D_CH_CENTROID) {
-        const int nrc = g_rccl.AllReduce(ctx->centroid, ctx->centroid, ctx->nvox * 4, 5 /* ncclUint64 */, 0, ctx->rccl_comm, ctx->stream);
-        REQUIRE(nrc == 0, TL3D_E_HIP, "ncclAllReduce (centroid) failed: %s", rccl_msg(nrc));
+    // Which bricks does ANY rank hold something in?  One byte per brick, MAX all-reduce: every rank gets the same set.  When it
+    // is less than half of the grid only those bricks' records travel (packed, summed, unpacked); a frame-sharded run of a
+    // few dozen frames per rank touches a few per cent of a 1024^3 grid.
+    const size_t nbr = ctx->nvox >> 9;
+    unsigned char *d_map = nullptr;
+    TL3D_HIP(hipMalloc(&d_map, nbr));
+    std::vector<unsigned char> h_map(nbr);
+    std::vector<unsigned> h_idx;
+    int rc = TL3D_OK;
+    {
+        hipError_t e = hipMemsetAsync(d_map, 0, nbr, ctx->stream);
+        if (e == hipSuccess)
+            rc = launch_touched_bricks(ctx->stream, (channels & TL3D_CH_TSDF) ? ctx->tsdf : nullptr, (channels & TL3D_CH_CENTROID) ? ctx->centroid : nullptr,
+                                       (unsigned)nbr, d_map);
+        int nrc = (e == hipSuccess && rc == TL3D_OK) ? g_rccl.AllReduce(d_map, d_map, nbr, 1 /* ncclUint8 */, 2 /* ncclMax */, ctx->rccl_comm, ctx->stream) : -1;
+        if (nrc == 0) e = hipMemcpyAsync(h_map.data(), d_map, nbr, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(d_map);
+        REQUIRE(rc == TL3D_OK && nrc == 0 && e == hipSuccess, TL3D_E_HIP, "brick-map all-reduce failed: %s", nrc > 0 ? rccl_msg(nrc) : hipGetErrorString(e));
     }
-    TL3D_HIP(hipStreamSynchronize(ctx->stream));
+    for (size_t b = 0; b < nbr; ++b)
+        if (h_map[b]) h_idx.push_back((unsigned)b);
+    const bool sparse = h_idx.size() * 2 < nbr;
+    ctx->stats.merge_bricks_sent += sparse ? h_idx.size() : nbr;
+    ctx->stats.merge_bricks_total += nbr;
+    if (!sparse) {
+        if (channels & TL3D_CH_TSDF) {
+            const int nrc = g_rccl.AllReduce(ctx->tsdf, ctx->tsdf, ctx->nvox * 2, 2 /* ncclInt32 */, 0, ctx->rccl_comm, ctx->stream);
+            REQUIRE(nrc == 0, TL3D_E_HIP, "ncclAllReduce (TSDF) failed: %s", rccl_msg(nrc));
+        }
+        if (channels & TL3D_CH_CENTROID) {
+            const int nrc = g_rccl.AllReduce(ctx->centroid, ctx->centroid, ctx->nvox * 4, 5 /* ncclUint64 */, 0, ctx->rccl_comm, ctx->stream);
+            REQUIRE(nrc == 0, TL3D_E_HIP, "ncclAllReduce (centroid) failed: %s", rccl_msg(nrc));
+        }
+        TL3D_HIP(hipStreamSynchronize(ctx->stream));
+        return TL3D_OK;
+    }
+    if (h_idx.empty()) return TL3D_OK;
+    unsigned *d_idx = nullptr;
+    void *d_pack = nullptr;
+    const size_t n = h_idx.size();
+    const size_t row = (channels & TL3D_CH_CENTROID) ? 16384 : 4096;
+    if (hipMalloc(&d_idx, n * sizeof(unsigned)) != hipSuccess || hipMalloc(&d_pack, n * row) != hipSuccess) {
+        (void)hipGetLastError();
+        if (d_idx) (void)hipFree(d_idx);
+        return set_err(TL3D_E_NOMEM, "merge staging alloc (%zu B) failed", n * row);
+    }
+    hipError_t e = hipMemcpyAsync(d_idx, h_idx.data(), n * sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream);
+    int nrc = 0;
+    if (e == hipSuccess && (channels & TL3D_CH_TSDF)) {
+        rc = launch_brick_rows(ctx->stream, true, ctx->tsdf, d_idx, (long long)n, 4096u, d_pack);
+        if (rc == TL3D_OK) nrc = g_rccl.AllReduce(d_pack, d_pack, n * 1024, 2 /* ncclInt32 */, 0, ctx->rccl_comm, ctx->stream);
+        if (rc == TL3D_OK && nrc == 0) rc = launch_brick_rows(ctx->stream, false, ctx->tsdf, d_idx, (long long)n, 4096u, d_pack);
+    }
+    if (e == hipSuccess && rc == TL3D_OK && nrc == 0 && (channels & TL3D_CH_CENTROID)) {
+        rc = launch_brick_rows(ctx->stream, true, ctx->centroid, d_idx, (long long)n, 16384u, d_pack);
+        if (rc == TL3D_OK) nrc = g_rccl.AllReduce(d_pack, d_pack, n * 2048, 5 /* ncclUint64 */, 0, ctx->rccl_comm, ctx->stream);
+        if (rc == TL3D_OK && nrc == 0) rc = launch_brick_rows(ctx->stream, false, ctx->centroid, d_idx, (long long)n, 16384u, d_pack);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_idx);
+    (void)hipFree(d_pack);
+    REQUIRE(rc == TL3D_OK && nrc == 0 && e == hipSuccess, TL3D_E_HIP, "sparse grid all-reduce failed: %s", nrc ? rccl_msg(nrc) : hipGetErrorString(e));
     return TL3D_OK;
 }
 

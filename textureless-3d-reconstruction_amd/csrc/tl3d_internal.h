@@ -299,6 +299,8 @@ int launch_extract_write(hipStream_t s, const Grid &g, int mode, int min_count, 
                          float *xyz, uint8_t *rgb, unsigned long long cap);
 // grids
 int launch_max_weight(hipStream_t s, const int2 *grid, size_t nvox, int *d_out);
+int launch_touched_bricks(hipStream_t s, const int2 *tsdf, const unsigned long long *cen, unsigned nbricks, unsigned char *map);
+int launch_brick_rows(hipStream_t s, bool pack, void *grid, const unsigned *idx, long long n, unsigned bytes_per_brick, void *packed);
 int probe_hw_queues(int n_streams, double spin_ms, double *elapsed_ms);
 int launch_add_i32(hipStream_t s, int *dst, const int *src, size_t n);
 int launch_add_u64(hipStream_t s, unsigned long long *dst, const unsigned long long *src, size_t n);

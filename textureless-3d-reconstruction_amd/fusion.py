@@ -378,6 +378,21 @@ class FusionContext:
             assert arr.nbytes == nb
         abi.check(self._lib.tl3d_grid_add(self._h, int(channel), abi.ptr(arr), nb))
 
+    # ---- sparse merge helpers (device tensors: anything with data_ptr()) ---------------------------------------------
+    @property
+    def n_bricks(self) -> int:
+        return self.grid.nvox // 512
+
+    def touched_bricks(self, map_dev, channels: int = 0):
+        """map_dev[b] |= 1 (uint8, one per brick, device memory, zeroed by the caller) for every brick that holds anything."""
+        abi.check(self._lib.tl3d_grid_touched_bricks(self._h, int(channels), abi.ptr(map_dev), int(self.n_bricks)))
+
+    def pack_bricks(self, channel: int, bricks_dev, packed_dev):
+        abi.check(self._lib.tl3d_grid_pack_bricks(self._h, int(channel), abi.ptr(bricks_dev), int(bricks_dev.shape[0]), abi.ptr(packed_dev)))
+
+    def unpack_bricks(self, channel: int, bricks_dev, packed_dev):
+        abi.check(self._lib.tl3d_grid_unpack_bricks(self._h, int(channel), abi.ptr(bricks_dev), int(bricks_dev.shape[0]), abi.ptr(packed_dev)))
+
     def max_weight(self) -> int:
         """Largest number of observations any TSDF voxel holds (int32 headroom: _cabi.TSDF_MAX_WEIGHT)."""
         w = C.c_int64(0)

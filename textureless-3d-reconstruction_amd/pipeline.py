@@ -530,7 +530,9 @@ class DepthToReconstructionPipeline:
                     ctx.integrate(slot_of[g], pose_of[g], scale=self.scales[g])
                 ctx.accumulate_centroid(slot_of[g], pose_of[g], scale=self.scales[g], subsample=cfg.subsample_factor)
             say("\n--- Step 4: Merge the per-GPU grids (integer sum all-reduce) ---")
-            dd.merge_context_grids(ctx, dist)
+            info = dd.merge_context_grids(ctx, dist)
+            if info:
+                say(f"  {info['bricks_sent']} of {info['bricks_total']} bricks travelled ({info['bytes'] / 1e6:.1f} MB per rank and direction)")
             st = ctx.stats()
             tot = dd.allreduce_counts([st["centroid_points"], st["centroid_dropped"]], dist)
             xyz = rgb = None
