@@ -42,6 +42,8 @@ extern "C" {
 /* grid channels */
 #define TL3D_CH_TSDF 1u         /* {int32 sum of quantised tsdf, int32 weight}         8 B/voxel  */
 #define TL3D_CH_CENTROID 2u     /* {sx|sy<<32, sz|n<<32, sr|sg<<32, sb} u64 x4         32 B/voxel */
+#define TL3D_CH_FREE 4u         /* tl3d_grid_device_ptr only: the per-brick free-space counts (uint32 [nx ny nz / 512]) that a SPARSE
+                                   grid keeps for bricks without records; a merge sums them like the records                     */
 
 /* fixed-point formats of the accumulators (exact, order-free sums => bit-identical multi-GPU merge) */
 #define TL3D_TSDF_QSCALE 32767          /* tsdf in [-1,1] -> rint(tsdf * 32767)                  */
@@ -85,6 +87,12 @@ typedef struct tl3d_config {
     void *ext_tsdf;             /* optional caller-owned device memory for the grids (e.g. a torch */
     void *ext_centroid;         /*   tensor's data_ptr, so torch.distributed can all-reduce it)    */
     void *stream;               /* optional hipStream_t to enqueue on; NULL = library-owned stream */
+    int64_t pool_bricks_tsdf;   /* SPARSE grid: the channel holds records for at most this many 8^3 bricks (4 KB each), handed out */
+    int64_t pool_bricks_centroid; /* on first touch through a brick table; 0 = dense (every brick has records, 16 KB each for the
+                                   centroid channel).  What the reference's hash-map merge gives for free (any extent at any voxel
+                                   size, D2R:404-410): nx ny nz may describe a volume far larger than memory.  Bricks that are only
+                                   ever free space hold a 4-byte count, no records.  When the pool runs out further new bricks are
+                                   refused and counted (tl3d_stats.pool_refused): nothing is written out of bounds.             */
 } tl3d_config;
 
 /* Result of an ICP run (device solve, read back once at the end). */
@@ -133,6 +141,9 @@ typedef struct tl3d_stats {
     uint64_t icp_batch_fallback_pairs; /* ... and the pairs re-registered through the per-iteration kernel instead   */
     uint64_t merge_bricks_sent;      /* tl3d_allreduce_grid: bricks whose records went over the wire (all merges so far) ... */
     uint64_t merge_bricks_total;     /* ... of this many bricks in the grid                                              */
+    uint64_t pool_slots_tsdf;        /* sparse grids: brick slots handed out so far, per channel (dense: every brick)             */
+    uint64_t pool_slots_centroid;
+    uint64_t pool_refused;           /* first touches refused because a pool was full: > 0 means the result lacks those bricks   */
 } tl3d_stats;
 
 const char *tl3d_last_error(void);

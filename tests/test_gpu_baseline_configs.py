@@ -206,3 +206,57 @@ def test_config2_with_one_millimetre_depth_noise():
     worst_r = max(float(np.degrees(np.arccos(np.clip((np.trace(r @ np.asarray(re).T) - 1) / 2, -1, 1)))) for (r, _), (re, _) in zip(rel, est))
     print(f"noisy chain over 40 degrees: worst translation error {worst_t * 1e3:.1f} mm, rotation {worst_r:.2f} deg")
     assert worst_t < 0.03 and worst_r < 2.0, (worst_t, worst_r)
+
+
+def test_a_30_m_corridor_at_5_mm_fuses_in_a_sparse_volume():
+    """What the reference's hash-map merge gives for free (any extent at any voxel size, D2R:404-410): a 2 m x 2.4 m x 30 m
+    corridor at 5 mm is 400 x 488 x 6008 voxels -- 9.4 GB of TSDF and 37.5 GB of centroid records as a dense grid.  The sparse
+    volume holds records only for the bricks near the walls: every point is kept (points_dropped == 0, no brick refused), in
+    well under 8 GB, and the cloud lies on the walls."""
+    from tl3d import synth
+    from tl3d.config import ReconstructionConfig
+    from tl3d.pipeline import DepthToReconstructionPipeline
+    W, H = 640, 480
+    cam = dict(fx=512.0, fy=512.0, cx=320.0, cy=240.0)
+    scene = synth.Scene(room=((-1.0, -1.2, -0.5), (1.0, 1.2, 30.0)))
+    n = 58
+    poses = synth.dolly_poses(n, (0.0, 0.0, 0.0), (0.0, 0.0, 0.5))
+    r0, t0 = poses[0]
+    rel = [(r @ r0.T, t.reshape(3, 1) - (r @ r0.T) @ t0.reshape(3, 1)) for r, t in poses]
+    frames = [synth.render(scene, p, W, H, **cam) for p in poses]
+    cfg = ReconstructionConfig(**cam, voxel_size=0.005, subsample_factor=2, grid_dim=512, max_depth=4.0, outlier_filter=False)
+    pipe = DepthToReconstructionPipeline(cfg)
+    pipe.set_frames([c for d, c in frames], [d for d, c in frames])
+    pts, col, _ = pipe.reconstruct(poses=rel)
+    g = pipe.grid
+    assert g.sparse and g.nvox > 1.0e9 and g.dims[2] >= 5600, g          # (the floor comes into view 1.6 m ahead of the first camera)
+    assert g.device_bytes() < 8 * 2 ** 30, g.device_bytes() / 2 ** 30
+    st = pipe.stats
+    assert st["points_dropped"] == 0 and st["pool_refused"] == 0
+    assert st["bricks_centroid"] > 50000 and st["bricks_tsdf"] > st["bricks_centroid"]
+    assert len(pts) > 2_000_000
+    # on the walls / floor / ceiling of the corridor (camera-0 frame == world frame here up to cam0's pose)
+    pw = (pts - t0.reshape(1, 3)) @ r0
+    d = np.minimum(np.minimum(np.abs(np.abs(pw[:, 0]) - 1.0), np.abs(np.abs(pw[:, 1]) - 1.2)), np.abs(pw[:, 2] - 30.0))
+    assert d.mean() < 1e-3 and np.percentile(d, 99) < 4e-3
+
+
+def test_merge_pointclouds_of_a_large_extent_uses_a_sparse_grid():
+    """merge_pointclouds (D2R:386-420 / DER:615-645) on clouds 20 m apart at 5 mm: the dense centroid grid would take 99 GB (it
+    used to raise MemoryError); the occupied voxels are what Open3D's hash map holds, and what the sparse grid holds.  (The brick
+    tables index 2^32 voxels: beyond that extent the call still refuses.)"""
+    from tl3d.config import ReconstructionConfig
+    from tl3d.dense import DensePointCloudGenerator
+    from tl3d.config import CameraIntrinsics
+    from oracle import ref_numpy as rn
+    rng = np.random.default_rng(7)
+    a = (rng.random((40000, 3)) * np.array([1.0, 1.0, 0.02])).astype(np.float32)
+    b = a + np.array([20.0, 8.0, 1.0], np.float32)
+    ca = rng.integers(0, 255, (40000, 3)).astype(np.uint8)
+    gen = DensePointCloudGenerator(CameraIntrinsics(fx=500.0, fy=500.0, cx=320.0, cy=240.0, width=640, height=480))
+    try:
+        pts, colr = gen.merge_pointclouds([(a, ca), (b, ca)], voxel_size=0.005)
+    finally:
+        gen.close()
+    ref_p, ref_c = rn.merge_open3d([(a, ca), (b, ca)], 0.005, sor=False)
+    assert len(pts) == len(ref_p) and rn.chamfer_mean(pts, ref_p) < 2e-6

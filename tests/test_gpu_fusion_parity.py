@@ -808,3 +808,73 @@ def test_reset_followed_at_once_by_integrate_on_a_large_grid():
                     orc.tsdf_integrate(frames[i][0], poses[i][0], poses[i][1])
             assert np.array_equal(g, orc.tsdf), rep
     assert int(orc.tsdf[:, 1].sum()) > 10 ** 6
+
+
+def test_sparse_grid_equals_the_dense_grid_bit_for_bit():
+    """A sparse grid (records only for the bricks the data touches, handed out on first touch through a brick table; bricks that
+    are only ever free space keep a 4-byte count or nothing) holds what the dense grid holds wherever a surface ever came within
+    the truncation band: centroid channel, both extractions and the merge of two grids equal the oracle's / the dense context's
+    bit for bit, with a fraction of the bricks allocated."""
+    poses, frames = small_scene_frames(n=5, deg=4.0)
+    dims, voxel, centre = (96, 96, 96), 0.025, (0.0, -0.2, 0.0)
+    nbr = 96 ** 3 // 512
+    ctx, orc = make_pair(dims=dims, voxel=voxel, centre=centre, n_slots=5)
+    origin = tuple(centre[i] - 0.5 * dims[i] * voxel for i in range(3))
+    spec = tl3d.GridSpec(dims, origin, voxel, 4 * voxel, tl3d.CH_TSDF | tl3d.CH_CENTROID, pool_tsdf=nbr // 2, pool_centroid=nbr // 4)
+    sp = tl3d.FusionContext(SMALL["width"], SMALL["height"], SMALL["fx"], SMALL["fy"], SMALL["cx"], SMALL["cy"], n_slots=5, grid=spec)
+    with ctx, sp:
+        for c in (ctx, sp):
+            for i, (d, col) in enumerate(frames):
+                c.upload(i, d, col)
+            for i in range(5):
+                c.integrate(i, poses[i])
+                c.accumulate_centroid(i, poses[i], subsample=1)
+        for i, (d, col) in enumerate(frames):
+            orc.tsdf_integrate(d, poses[i][0], poses[i][1])
+            orc.centroid_accumulate(d, col, poses[i][0], poses[i][1], subsample=1)
+        st = sp.stats()
+        assert st["pool_refused"] == 0 and 0 < st["pool_slots_tsdf"] < nbr // 2 and 0 < st["pool_slots_centroid"] < nbr // 4
+        assert ctx.stats()["pool_slots_tsdf"] == nbr                            # dense: every brick has records
+        gt, gc = sp.download_grid(tl3d.CH_TSDF), sp.download_grid(tl3d.CH_CENTROID)
+        assert np.array_equal(gc, orc.centroid)
+        # TSDF: identical wherever a voxel ever came within the truncation band; the one difference: bricks that saw nothing but
+        # free space through a footprint with holes / beyond the image border get no records in a sparse grid (a dense grid
+        # keeps their (+32767, +1) observations)
+        diff = np.any(gt != orc.tsdf, axis=1)
+        assert diff.mean() < 0.2 and np.all(orc.tsdf[diff, 0] == 32767 * orc.tsdf[diff, 1]) and np.all(gt[diff, 1] < orc.tsdf[diff, 1])
+        band = np.abs(orc.tsdf[:, 0]) < 32767 * np.maximum(orc.tsdf[:, 1], 1)
+        assert band.sum() > 10000 and not diff[band].any()
+        gt_dense = orc.tsdf
+        assert np.array_equal(ctx.download_grid(tl3d.CH_TSDF), orc.tsdf)
+        assert sp.max_weight() == int(gt[:, 1].max()) and ctx.max_weight() == int(orc.tsdf[:, 1].max())
+        for mode, kw in ((tl3d.EXTRACT_CENTROID, dict(min_count=1)), (tl3d.EXTRACT_CENTROID, dict(min_count=2, min_weight=2, max_abs_tsdf=0.9)),
+                         (tl3d.EXTRACT_TSDF, dict(min_weight=2))):
+            a, ac = sp.extract(mode, **kw)
+            b, bc = ctx.extract(mode, **kw)
+            assert len(a) > 100 and np.array_equal(a, b) and np.array_equal(ac, bc), (mode, kw)
+        # merge: grid += dense image of another grid (records appear where the other grid has something)
+        sp.add_grid(tl3d.CH_TSDF, gt)
+        sp.add_grid(tl3d.CH_CENTROID, gc)
+        assert np.array_equal(sp.download_grid(tl3d.CH_TSDF), 2 * gt) and np.array_equal(sp.download_grid(tl3d.CH_CENTROID), 2 * orc.centroid)
+        sp.reset()
+        assert sp.stats()["pool_slots_tsdf"] == 0 and not sp.download_grid(tl3d.CH_TSDF).any()
+        sp.upload_grid(tl3d.CH_TSDF, gt_dense)
+        assert np.array_equal(sp.download_grid(tl3d.CH_TSDF), orc.tsdf)                 # (an uploaded image is kept whole)
+        with pytest.raises(tl3d.Tl3dError):
+            sp.grid_ptr(tl3d.CH_TSDF)                                           # no dense layout to point at
+
+
+def test_a_full_brick_pool_refuses_bricks_and_says_so():
+    poses, frames = small_scene_frames(n=2, deg=4.0)
+    dims, voxel, centre = (96, 96, 96), 0.025, (0.0, -0.2, 0.0)
+    origin = tuple(centre[i] - 0.5 * dims[i] * voxel for i in range(3))
+    spec = tl3d.GridSpec(dims, origin, voxel, 4 * voxel, tl3d.CH_TSDF | tl3d.CH_CENTROID, pool_tsdf=16, pool_centroid=8)
+    with tl3d.FusionContext(SMALL["width"], SMALL["height"], SMALL["fx"], SMALL["fy"], SMALL["cx"], SMALL["cy"], n_slots=2, grid=spec) as sp:
+        for i, (d, col) in enumerate(frames):
+            sp.upload(i, d, col)
+            sp.integrate(i, poses[i])
+            sp.accumulate_centroid(i, poses[i])
+        st = sp.stats()
+        assert st["pool_slots_tsdf"] == 16 and st["pool_slots_centroid"] == 8 and st["pool_refused"] > 100
+        xyz, _ = sp.extract(tl3d.EXTRACT_CENTROID)
+        assert 0 < len(xyz) <= 8 * 512

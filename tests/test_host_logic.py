@@ -98,12 +98,19 @@ def test_plan_grid_uses_open3d_origin_and_caps_a_voxel_budget():
     # BASELINE config 3: a 2 m x 2.4 m corridor seen 12.5 m deep at 5 mm fits the default budget unclipped
     spec, clipped = plan_grid([-1.0, -1.2, -0.5], [1.0, 1.2, 12.0], 0.005, 1024)
     assert not clipped and spec.dims == (408, 488, 2504)
-    # over budget: the longest axis is shaved about the scene centre, the others stay whole, the caller is told
+    # over budget: the grid keeps its full extent and goes SPARSE (records only where the data is: the reference's hash-map merge,
+    # D2R:404-410); the pools take what the dense budget would have taken
     spec, clipped = plan_grid([-1.0, -1.2, -0.5], [1.0, 1.2, 12.0], 0.005, 512)
-    assert clipped and spec.dims[:2] == (408, 488) and spec.nvox <= 512 ** 3 < spec.nvox + 8 * 408 * 488
-    assert abs((spec.origin[2] + 0.5 * spec.dims[2] * 0.005) - 5.75) < 1e-9 and np.allclose(spec.origin[:2], [-1.0025, -1.2025])
-    spec, clipped = plan_grid([0, 0, 0], [10, 10, 10], 0.005, 256, max_voxels=64 ** 3)
-    assert clipped and spec.dims == (64, 64, 64)
+    assert not clipped and spec.dims == (408, 488, 2504) and spec.sparse and np.allclose(spec.origin, [-1.0025, -1.2025, -0.5025])
+    assert 0 < spec.pool_centroid < spec.pool_tsdf <= spec.nvox // 512 and spec.device_bytes() <= 512 ** 3 * 40 * 1.1
+    spec, clipped = plan_grid([-1.0, -1.2, -0.5], [1.0, 1.2, 30.0], 0.005, 512, sparse_bytes=6 * 2 ** 30)
+    assert not clipped and spec.sparse and spec.dims[2] >= 6000 and spec.device_bytes() < 7 * 2 ** 30
+    # beyond 2^32 voxels the brick tables cannot index the volume: shaved about the scene centre, longest axis first, and the caller is told
+    spec, clipped = plan_grid([0, 0, 0], [40, 10, 10], 0.005, 1024)
+    assert clipped and spec.nvox <= 1 << 32 < spec.nvox + 8 * spec.dims[1] * spec.dims[2] and spec.sparse
+    assert abs((spec.origin[0] + 0.5 * spec.dims[0] * 0.005) - 20.0) < 1e-9
+    spec, clipped = plan_grid([0, 0, 0], [5, 5, 5], 0.005, 256, max_voxels=64 ** 3)
+    assert not clipped and spec.sparse and spec.dims == (1008, 1008, 1008)                      # the volume is sparse, not cut
 
 
 def test_sharding_covers_every_frame_once():

@@ -44,7 +44,8 @@ class Config(C.Structure):
                 ("n_slots", C.c_int32), ("channels", C.c_uint32),
                 ("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32),
                 ("origin", C.c_double * 3), ("voxel_size", C.c_double), ("sdf_trunc", C.c_double),
-                ("ext_tsdf", C.c_void_p), ("ext_centroid", C.c_void_p), ("stream", C.c_void_p)]
+                ("ext_tsdf", C.c_void_p), ("ext_centroid", C.c_void_p), ("stream", C.c_void_p),
+                ("pool_bricks_tsdf", C.c_int64), ("pool_bricks_centroid", C.c_int64)]
 
 
 class IcpResult(C.Structure):
@@ -71,7 +72,8 @@ class Stats(C.Structure):
                 ("tsdf_bricks_visited", C.c_uint64), ("tsdf_bricks_free", C.c_uint64), ("tsdf_bricks_free_counted", C.c_uint64), ("centroid_launches", C.c_uint64), ("centroid_points", C.c_uint64),
                 ("centroid_dropped", C.c_uint64), ("tsdf_kernel_ms", C.c_double), ("tsdf_kernel_timed", C.c_uint64),
                 ("tsdf_batch_bricks", C.c_uint64), ("bp_lookback_retries", C.c_uint64), ("icp_batch_timeouts", C.c_uint64),
-                ("icp_batch_fallback_pairs", C.c_uint64), ("merge_bricks_sent", C.c_uint64), ("merge_bricks_total", C.c_uint64)]
+                ("icp_batch_fallback_pairs", C.c_uint64), ("merge_bricks_sent", C.c_uint64), ("merge_bricks_total", C.c_uint64),
+                ("pool_slots_tsdf", C.c_uint64), ("pool_slots_centroid", C.c_uint64), ("pool_refused", C.c_uint64)]
 
 
 _lib = None

@@ -96,7 +96,7 @@ __device__ __forceinline__ bool centroid_reduce_runs(CenAdd &k) {
 // Tails of a wave straight to the grid.  The L2's atomic units are bound by REQUESTS (an 8-B add costs a 64-B request) and
 // lanes that add to consecutive words in one instruction share one: the tails are listed in LDS and lanes 4j .. 4j+3 add
 // the four words of tail j's record.  stage: this wave's [64][5] words.
-__device__ __forceinline__ void centroid_commit_runs(CenAdd k, unsigned long long *__restrict__ grid, unsigned long long (*stage)[5]) {
+__device__ __forceinline__ void centroid_commit_runs(const Grid &g, CenAdd k, unsigned long long *__restrict__ grid, unsigned long long (*stage)[5]) {
     const bool tail = centroid_reduce_runs(k);
     const int lane = threadIdx.x & 63;
     const unsigned long long m = __ballot(tail);
@@ -108,7 +108,13 @@ __device__ __forceinline__ void centroid_commit_runs(CenAdd k, unsigned long lon
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int n4 = 4 * (int)__popcll(m);
-    for (int i = lane; i < n4; i += 64) atomicAdd(grid + 4 * stage[i >> 2][0] + (i & 3), stage[i >> 2][1 + (i & 3)]);
+    for (int base = 0; base < n4; base += 64) {                     // (wave-uniform trip count: wave_slots needs every lane)
+        const int i = base + lane;
+        const bool want = i < n4;
+        const unsigned long long rec = want ? stage[i >> 2][0] : 0ull;
+        const unsigned slot = wave_slots(g.cen_tab, g.cursors + 2, g.cen_cap, (unsigned)(rec >> 9), want);      // first touch of a sparse grid's brick: a slot
+        if (want && slot < SLOT_FULL) atomicAdd(grid + 4 * (((unsigned long long)slot << 9) | (rec & 511ull)) + (i & 3), stage[i >> 2][1 + (i & 3)]);
+    }
 }
 
 // LDS table of the per-frame kernel: open addressing, 1024 slots for the at most 1024 samples of a 32 x 32 tile (never more
@@ -219,9 +225,13 @@ __global__ __launch_bounds__(256) void centroid_frame_kernel(Cam cam, Grid g, Bp
     __syncthreads();
     if (VAR == 2) return;                                         // timing ablation: no grid atomics
     const unsigned n4 = 4u * s_nused;
-    for (unsigned i = threadIdx.x; i < n4; i += 256) {
-        const unsigned h = s_used[i >> 2], c = i & 3u;
-        atomicAdd(grid + 4 * (s_key[h] - 1ull) + c, s_val[h][c]);
+    for (unsigned base = 0; base < n4; base += 256) {              // (wave-uniform trip count: wave_slots needs every lane)
+        const unsigned i = base + threadIdx.x;
+        const bool want = i < n4;
+        const unsigned h = want ? s_used[i >> 2] : 0u, c = i & 3u;
+        const unsigned long long rec = want ? s_key[h] - 1ull : 0ull;
+        const unsigned slot = wave_slots(g.cen_tab, g.cursors + 2, g.cen_cap, (unsigned)(rec >> 9), want);      // first touch of a sparse grid's brick: a slot
+        if (want && slot < SLOT_FULL) atomicAdd(grid + 4 * (((unsigned long long)slot << 9) | (rec & 511ull)) + c, s_val[h][c]);
     }
 }
 
@@ -237,7 +247,7 @@ __global__ __launch_bounds__(256) void centroid_direct_kernel(Cam cam, Grid g, B
     CenAdd k = centroid_sample(cam, g, a, p, depth, bgr, xf, yf, s < ns ? us : a.Ws, vs, valid);
     centroid_stats(valid ? 1 : 0, (k.rec != ~0ull) ? 1 : 0, counters);
     __shared__ unsigned long long s_stage[4][64][5];
-    centroid_commit_runs(k, grid, s_stage[threadIdx.x >> 6]);
+    centroid_commit_runs(g, k, grid, s_stage[threadIdx.x >> 6]);
 }
 
 __global__ __launch_bounds__(256) void centroid_points_kernel(Grid g, const float *__restrict__ xyz, const uint8_t *__restrict__ rgb,
@@ -255,7 +265,7 @@ __global__ __launch_bounds__(256) void centroid_points_kernel(Grid g, const floa
     }
     centroid_stats(valid ? 1 : 0, (k.rec != ~0ull) ? 1 : 0, counters);
     __shared__ unsigned long long s_stage[4][64][5];
-    centroid_commit_runs(k, grid, s_stage[threadIdx.x >> 6]);
+    centroid_commit_runs(g, k, grid, s_stage[threadIdx.x >> 6]);
 }
 
 // per-block min/max of a point list -> slab[block][6]

@@ -40,12 +40,13 @@ __device__ __forceinline__ int extract_record(const Grid &g, const ExtArgs &a, c
     rec_coords(idx, g.nbx, g.nby, ijk[0], ijk[1], ijk[2]);
     const double org[3] = {g.oxd, g.oyd, g.ozd};
     if (a.mode == TL3D_EXTRACT_CENTROID) {
-        const unsigned long long *rec = cen + 4 * idx;
+        const unsigned long long *rec = cen_record(g, cen, idx);
+        if (!rec) return 0;
         const unsigned long long r1 = rec[1];
         const unsigned long long n = r1 >> 32;
         if (n < (unsigned long long)a.min_count) return 0;
         if (tsdf && a.min_weight > 0) {
-            const int2 tw = tsdf[idx];
+            const int2 tw = tsdf_record(g, tsdf, idx);
             if (tw.y < a.min_weight) return 0;
             const double mean = (double)tw.x / ((double)tw.y * 32767.0);
             if (!(fabs(mean) <= a.max_abs)) return 0;
@@ -66,7 +67,7 @@ __device__ __forceinline__ int extract_record(const Grid &g, const ExtArgs &a, c
     }
     // TSDF zero crossings
     const int mw = a.min_weight < 1 ? 1 : a.min_weight;
-    const int2 ta_ = tsdf[idx];
+    const int2 ta_ = tsdf_record(g, tsdf, idx);
     if (ta_.y < mw) return 0;
     const double ta = (double)ta_.x / ((double)ta_.y * 32767.0);
     if (!(fabs(ta) < 0.98)) return 0;
@@ -78,7 +79,7 @@ __device__ __forceinline__ int extract_record(const Grid &g, const ExtArgs &a, c
         nb[e] += 1;
         if (nb[e] >= dims[e]) continue;
         const size_t jdx = vox_index(nb[0], nb[1], nb[2], g.nbx, g.nby);
-        const int2 tb_ = tsdf[jdx];
+        const int2 tb_ = tsdf_record(g, tsdf, jdx);
         if (tb_.y < mw) continue;
         const double tb = (double)tb_.x / ((double)tb_.y * 32767.0);
         if (!(fabs(tb) < 0.98)) continue;
@@ -95,13 +96,13 @@ __device__ __forceinline__ int extract_record(const Grid &g, const ExtArgs &a, c
             uint8_t c[3] = {128, 128, 128};
             if (cen) {
                 const size_t first = (r0 <= r1) ? idx : jdx, second = (r0 <= r1) ? jdx : idx;
-                const unsigned long long *ra = cen + 4 * first;
-                const unsigned long long na = ra[1] >> 32;
+                const unsigned long long *ra = cen_record(g, cen, first);
+                const unsigned long long na = ra ? ra[1] >> 32 : 0ull;
                 if (na > 0) {
                     mean_colour(ra, na, c);
                 } else {
-                    const unsigned long long *rb = cen + 4 * second;
-                    const unsigned long long nb2 = rb[1] >> 32;
+                    const unsigned long long *rb = cen_record(g, cen, second);
+                    const unsigned long long nb2 = rb ? rb[1] >> 32 : 0ull;
                     if (nb2 > 0) mean_colour(rb, nb2, c);
                 }
             }

@@ -8,8 +8,37 @@
 
 namespace tl3d {
 
-// largest record weight: 16-B loads (two records per lane), wave shuffle, one atomicMax per workgroup
-__global__ __launch_bounds__(256) void max_weight_kernel(const int4 *__restrict__ grid2, size_t n2, int *__restrict__ out) {
+// largest record weight over the pool slots in use (16-B loads, two records per lane; wave shuffle, one atomicMax per
+// workgroup) and, for bricks that have no records, their pending free-space count (readers see it as the weight)
+__global__ __launch_bounds__(256) void max_weight_kernel(const int4 *__restrict__ pool2, const unsigned *__restrict__ cursor, unsigned cap,
+                                                         const unsigned *__restrict__ free_cnt, unsigned nbricks, int *__restrict__ out) {
+    __shared__ int sm[4];
+    int m = 0;
+    const unsigned used = min(cursor[0], cap);
+    const size_t n2 = (size_t)used << 8;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (size_t)gridDim.x * 256) {
+        const int4 r = pool2[i];
+        m = max(m, max(r.y, r.w));
+    }
+    if (free_cnt)
+        for (unsigned b = blockIdx.x * 256u + threadIdx.x; b < nbricks; b += gridDim.x * 256u) m = max(m, (int)free_cnt[b]);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) m = max(m, __shfl_down(m, d));
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(out, max(max(sm[0], sm[1]), max(sm[2], sm[3])));
+}
+
+int launch_max_weight(hipStream_t s, const Grid &g, const int2 *pool, int *d_out) {
+    TL3D_HIP(hipMemsetAsync(d_out, 0, sizeof(int), s));
+    const unsigned nbricks = (unsigned)(g.nbx * g.nby * g.nbz);
+    hipLaunchKernelGGL(max_weight_kernel, dim3(2048), dim3(256), 0, s, reinterpret_cast<const int4 *>(pool), g.cursors, g.tsdf_cap, g.free_cnt, nbricks, d_out);
+    TL3D_HIP(hipGetLastError());
+    return TL3D_OK;
+}
+
+// the same over a plain dense record array (the other grid of a merge)
+__global__ __launch_bounds__(256) void max_weight_dense_kernel(const int4 *__restrict__ grid2, size_t n2, int *__restrict__ out) {
     __shared__ int sm[4];
     int m = 0;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (size_t)gridDim.x * 256) {
@@ -23,68 +52,133 @@ __global__ __launch_bounds__(256) void max_weight_kernel(const int4 *__restrict_
     if (threadIdx.x == 0) atomicMax(out, max(max(sm[0], sm[1]), max(sm[2], sm[3])));
 }
 
-int launch_max_weight(hipStream_t s, const int2 *grid, size_t nvox, int *d_out) {
+int launch_max_weight_dense(hipStream_t s, const int2 *grid, size_t nvox, int *d_out) {
     TL3D_HIP(hipMemsetAsync(d_out, 0, sizeof(int), s));
     const size_t n2 = nvox / 2;                           // nvox is a multiple of 512
     const unsigned nb = (unsigned)((n2 + 255) / 256 < 2048 ? (n2 + 255) / 256 : 2048);
-    hipLaunchKernelGGL(max_weight_kernel, dim3(nb ? nb : 1), dim3(256), 0, s, reinterpret_cast<const int4 *>(grid), n2, d_out);
+    hipLaunchKernelGGL(max_weight_dense_kernel, dim3(nb ? nb : 1), dim3(256), 0, s, reinterpret_cast<const int4 *>(grid), n2, d_out);
     TL3D_HIP(hipGetLastError());
     return TL3D_OK;
 }
 
 // ---- sparse merge: which bricks hold anything, and their records as one contiguous block --------------------------------
 // map[b] |= 1 when brick b has a voxel with a TSDF weight or a centroid count.  One wave per brick; TSDF: 16 B per lane x 4,
-// centroid: the record's second word (sz | n << 32) of 8 records per lane.
-__global__ __launch_bounds__(256) void touched_bricks_kernel(const int4 *__restrict__ tsdf2, const unsigned long long *__restrict__ cen,
+// centroid: the record's second word (sz | n << 32) of 8 records per lane.  (Pending free-space counts are not records: they
+// travel as the small per-brick counter array, tl3d_grid_device_ptr(TL3D_CH_FREE).)
+__global__ __launch_bounds__(256) void touched_bricks_kernel(Grid g, const int4 *__restrict__ tsdf2, const unsigned long long *__restrict__ cen,
                                                              unsigned nbricks, unsigned char *__restrict__ map) {
     const int lane = threadIdx.x & 63;
     for (unsigned b = blockIdx.x * 4u + (threadIdx.x >> 6); b < nbricks; b += gridDim.x * 4u) {
         bool any = false;
         if (tsdf2) {
-            const int4 *r = tsdf2 + ((size_t)b << 8);
+            const unsigned slot = (unsigned)__builtin_amdgcn_readfirstlane((int)brick_slot(g.tsdf_tab, b));
+            if (slot < SLOT_FULL) {
+                const int4 *r = tsdf2 + ((size_t)slot << 8);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int4 v = r[k * 64 + lane];
-                any = any || v.y != 0 || v.w != 0;
+                for (int k = 0; k < 4; ++k) {
+                    const int4 v = r[k * 64 + lane];
+                    any = any || v.y != 0 || v.w != 0;
+                }
             }
         }
         if (cen) {
-            const unsigned long long *r = cen + ((size_t)b << 11);
+            const unsigned slot = (unsigned)__builtin_amdgcn_readfirstlane((int)brick_slot(g.cen_tab, b));
+            if (slot < SLOT_FULL) {
+                const unsigned long long *r = cen + ((size_t)slot << 11);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) any = any || (r[(size_t)(k * 64 + lane) * 4 + 1] >> 32) != 0ull;
+                for (int k = 0; k < 8; ++k) any = any || (r[(size_t)(k * 64 + lane) * 4 + 1] >> 32) != 0ull;
+            }
         }
         if (__ballot(any) != 0ull && lane == 0) map[b] = 1;
     }
 }
 
-// rows of `words16` 16-byte words each: dst[i] = src[idx[i]] (pack) or dst[idx[i]] = src[i] (unpack)
-template <bool PACK>
-__global__ __launch_bounds__(256) void brick_rows_kernel(int4 *__restrict__ grid, const unsigned *__restrict__ idx, long long n, unsigned words16,
-                                                         int4 *__restrict__ packed) {
+// Rows of `words16` 16-byte words each, row i <-> virtual brick idx[i] (idx == nullptr: row i <-> brick i, a dense image of the
+// channel).  MODE 0: row = the brick's records (zeros when it has none; TSDF rows get the pending free-space count folded in when
+// add_free is set: the image a reader of a dense grid would see).  MODE 1: the brick's records = row.  MODE 2: records += row
+// (32-bit lanes for the TSDF channel, 64-bit for the centroid channel).  MODE 1 / 2 give a brick without records a slot when its
+// row holds anything.
+template <int MODE, bool IS_TSDF>
+__global__ __launch_bounds__(256) void brick_rows_kernel(Grid g, int4 *__restrict__ pool, const unsigned *__restrict__ idx, long long n,
+                                                         int4 *__restrict__ rows, int add_free) {
+    constexpr unsigned words16 = IS_TSDF ? 256u : 1024u;
+    __shared__ unsigned s_slot;
+    __shared__ int s_any;
+    unsigned *table = IS_TSDF ? g.tsdf_tab : g.cen_tab;
     for (long long i = blockIdx.x; i < n; i += gridDim.x) {
-        int4 *g = grid + (size_t)idx[i] * words16;
-        int4 *q = packed + (size_t)i * words16;
-        for (unsigned w = threadIdx.x; w < words16; w += 256) {
-            if (PACK) q[w] = g[w];
-            else g[w] = q[w];
+        const unsigned brick = idx ? idx[i] : (unsigned)i;
+        int4 *q = rows + (size_t)i * words16;
+        if (MODE == 0) {
+            const unsigned slot = brick_slot(table, brick);
+            const unsigned c = (IS_TSDF && add_free && g.free_cnt) ? g.free_cnt[brick] : 0u;
+            const int dq = (int)(c * 32767u), dw = (int)c;
+            for (unsigned w = threadIdx.x; w < words16; w += 256) {
+                int4 v = make_int4(0, 0, 0, 0);
+                if (slot < SLOT_FULL) v = pool[((size_t)slot * words16) + w];
+                if (IS_TSDF) { v.x += dq; v.y += dw; v.z += dq; v.w += dw; }
+                q[w] = v;
+            }
+        } else {
+            if (threadIdx.x == 0) s_any = 0;
+            __syncthreads();
+            int any = 0;
+            for (unsigned w = threadIdx.x; w < words16; w += 256) {
+                const int4 v = q[w];
+                any |= (v.x | v.y | v.z | v.w) != 0;
+            }
+            if (any) s_any = 1;
+            __syncthreads();
+            if (threadIdx.x == 0) s_slot = s_any ? brick_slot_ensure(table, g.cursors + (IS_TSDF ? 0 : 2), IS_TSDF ? g.tsdf_cap : g.cen_cap, brick) : brick_slot(table, brick);
+            __syncthreads();
+            const unsigned slot = s_slot;
+            if (slot < SLOT_FULL) {
+                int4 *r = pool + (size_t)slot * words16;
+                for (unsigned w = threadIdx.x; w < words16; w += 256) {
+                    if (MODE == 1) {
+                        r[w] = q[w];
+                    } else if (IS_TSDF) {
+                        int4 a = r[w];
+                        const int4 b = q[w];
+                        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+                        r[w] = a;
+                    } else {
+                        ulonglong2 a = reinterpret_cast<ulonglong2 *>(r)[w];
+                        const ulonglong2 b = reinterpret_cast<const ulonglong2 *>(q)[w];
+                        a.x += b.x; a.y += b.y;
+                        reinterpret_cast<ulonglong2 *>(r)[w] = a;
+                    }
+                }
+            }
+            __syncthreads();
         }
     }
 }
 
-int launch_touched_bricks(hipStream_t s, const int2 *tsdf, const unsigned long long *cen, unsigned nbricks, unsigned char *map) {
+int launch_touched_bricks(hipStream_t s, const Grid &g, const int2 *tsdf, const unsigned long long *cen, unsigned nbricks, unsigned char *map) {
     const unsigned nb = (nbricks + 3u) / 4u < 4096u ? (nbricks + 3u) / 4u : 4096u;
-    hipLaunchKernelGGL(touched_bricks_kernel, dim3(nb ? nb : 1), dim3(256), 0, s, reinterpret_cast<const int4 *>(tsdf), cen, nbricks, map);
+    hipLaunchKernelGGL(touched_bricks_kernel, dim3(nb ? nb : 1), dim3(256), 0, s, g, reinterpret_cast<const int4 *>(tsdf), cen, nbricks, map);
     TL3D_HIP(hipGetLastError());
     return TL3D_OK;
 }
 
-int launch_brick_rows(hipStream_t s, bool pack, void *grid, const unsigned *idx, long long n, unsigned bytes_per_brick, void *packed) {
+// mode 0 rows <- bricks, 1 bricks <- rows, 2 bricks += rows; idx may be null (row i = brick i)
+int launch_brick_rows(hipStream_t s, const Grid &g, int mode, bool is_tsdf, void *pool, const unsigned *idx, long long n, void *rows, bool add_free) {
     if (n <= 0) return TL3D_OK;
     const unsigned nb = (unsigned)(n < 8192 ? n : 8192);
-    if (pack)
-        hipLaunchKernelGGL(brick_rows_kernel<true>, dim3(nb), dim3(256), 0, s, static_cast<int4 *>(grid), idx, n, bytes_per_brick / 16u, static_cast<int4 *>(packed));
-    else
-        hipLaunchKernelGGL(brick_rows_kernel<false>, dim3(nb), dim3(256), 0, s, static_cast<int4 *>(grid), idx, n, bytes_per_brick / 16u, static_cast<int4 *>(packed));
+#define TL3D_ROWS(M_, T_) hipLaunchKernelGGL((brick_rows_kernel<M_, T_>), dim3(nb), dim3(256), 0, s, g, static_cast<int4 *>(pool), idx, n, static_cast<int4 *>(rows), add_free ? 1 : 0)
+    if (is_tsdf) { if (mode == 0) TL3D_ROWS(0, true); else if (mode == 1) TL3D_ROWS(1, true); else TL3D_ROWS(2, true); }
+    else { if (mode == 0) TL3D_ROWS(0, false); else if (mode == 1) TL3D_ROWS(1, false); else TL3D_ROWS(2, false); }
+#undef TL3D_ROWS
+    TL3D_HIP(hipGetLastError());
+    return TL3D_OK;
+}
+
+// table[b] = b (a dense grid: every brick has its records)
+__global__ __launch_bounds__(256) void iota_kernel(unsigned *__restrict__ t, unsigned n) {
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) t[i] = i;
+}
+int launch_iota(hipStream_t s, unsigned *t, unsigned n) {
+    hipLaunchKernelGGL(iota_kernel, dim3(n / 256 + 1 < 2048 ? n / 256 + 1 : 2048), dim3(256), 0, s, t, n);
     TL3D_HIP(hipGetLastError());
     return TL3D_OK;
 }

@@ -325,6 +325,12 @@ __global__ __launch_bounds__(256) void brick_cull_kernel(Cam cam, Grid g, BatchB
                                 a.z = fminf(a.z, b.z);
                             }
                         cls = classify_box(g, a, zmin, zmax, inside);
+                        // A SPARSE grid keeps no records for free space.  A brick that every VALID pixel under it puts at
+                        // least trunc in front of the surface, but whose footprint has holes or leaves the image, would get
+                        // (+32767, +1) on some of its voxels and nothing on the others: records for free space only.  It is
+                        // skipped there (the band around the surfaces, the centroids and both extractions do not see the
+                        // difference; a dense grid keeps these observations and equals the oracle voxel for voxel).
+                        if (cls == 1 && g.tsdf_cap < (unsigned)(g.nbx * g.nby * g.nbz) && (a.x - (zmax + 0.01f * g.vs) >= g.trunc * 1.001f)) cls = 0;
                     }
                 }
             }
@@ -332,7 +338,10 @@ __global__ __launch_bounds__(256) void brick_cull_kernel(Cam cam, Grid g, BatchB
     }
     // MIXED: the brick's bit in the frame mask; the first frame of the batch to set a bit also puts the brick on the batch list
     bool first = false;
-    if (cls == 1) first = atomicOr(B.framemask + brick, 1u << blockIdx.y) == 0u;
+    if (cls == 1) {
+        first = atomicOr(B.framemask + brick, 1u << blockIdx.y) == 0u;
+        if (first) (void)brick_slot_ensure(g.tsdf_tab, g.cursors, g.tsdf_cap, (unsigned)brick);     // sparse grid: records on first touch
+    }
     // Free space: every voxel of the brick gets exactly (+32767, +1).  That is ONE integer add here instead of a 4 KB read +
     // 4 KB write by the update kernel; the counters are folded into the records before anything reads them (fold_free_kernel).
     if (cls == 2) atomicAdd(free_cnt + brick, 1u);
@@ -355,15 +364,18 @@ __global__ __launch_bounds__(256) void brick_cull_kernel(Cam cam, Grid g, BatchB
 // records += count x (32767, 1) for every brick with a pending free-space count; the count returns to zero (exchanged, so a
 // count that lands between the read and the reset cannot be lost).  One wave per brick, 16 B per lane.  Runs on the main
 // stream before anything reads the TSDF channel (download, merge, extraction, weight check), i.e. once per scan, not per frame.
-__global__ __launch_bounds__(256) void fold_free_kernel(int2 *__restrict__ grid, unsigned *__restrict__ free_cnt, unsigned nbricks) {
+// A brick WITHOUT records (sparse grid: free space nobody ever saw a surface in) keeps its count: readers add it (tsdf_record).
+__global__ __launch_bounds__(256) void fold_free_kernel(Grid g, int2 *__restrict__ grid, unsigned *__restrict__ free_cnt, unsigned nbricks) {
     const int lane = threadIdx.x & 63;
     for (unsigned b = blockIdx.x * 4u + (threadIdx.x >> 6); b < nbricks; b += gridDim.x * 4u) {
         if (__builtin_amdgcn_readfirstlane(free_cnt[b]) == 0u) continue;
+        const unsigned slot = (unsigned)__builtin_amdgcn_readfirstlane((int)brick_slot(g.tsdf_tab, b));
+        if (slot >= SLOT_FULL) continue;
         unsigned c = 0;
         if (lane == 0) c = atomicExch(free_cnt + b, 0u);
         c = __builtin_amdgcn_readfirstlane(c);
         if (c == 0u) continue;
-        int4 *__restrict__ recs = reinterpret_cast<int4 *>(grid + ((size_t)b << 9));
+        int4 *__restrict__ recs = reinterpret_cast<int4 *>(grid + ((size_t)slot << 9));
         const int dq = (int)(c * 32767u), dw = (int)c;
         int4 r0 = recs[lane], r1 = recs[64 + lane], r2 = recs[128 + lane], r3 = recs[192 + lane];
         r0.x += dq; r0.y += dw; r0.z += dq; r0.w += dw;
@@ -551,9 +563,10 @@ __global__ __launch_bounds__(256) void tsdf_update_kernel(Cam cam, Grid g, Batch
     const DescPtr frames = const_descs(B);
 
     // the next brick of this wave, its frame mask and (lane f) its sub-brick masks in frame f: fetched one trip ahead
-    auto fetch = [&](unsigned t, unsigned &brick, unsigned &fm, unsigned &subv) {
+    auto fetch = [&](unsigned t, unsigned &brick, unsigned &fm, unsigned &subv, unsigned &slot) {
         brick = min((unsigned)__builtin_amdgcn_readfirstlane((int)B.list[t]), nbricks - 1u);
         fm = (unsigned)__builtin_amdgcn_readfirstlane((int)B.framemask[brick]);
+        slot = (unsigned)__builtin_amdgcn_readfirstlane((int)brick_slot(g.tsdf_tab, brick));     // where the brick's records live (set by the classification)
         subv = 0u;
         if (lane < B.n_frames && ((fm >> lane) & 1u)) subv = frames[lane].sub[brick];
     };
@@ -564,17 +577,17 @@ __global__ __launch_bounds__(256) void tsdf_update_kernel(Cam cam, Grid g, Batch
         return (unsigned)__builtin_amdgcn_readfirstlane((int)k) + waves_in_group;
     };
     unsigned t = entry_of(bi * 4u + (unsigned)wid);                // list entry of this trip
-    unsigned brick_n = 0, fm_n = 0, subv_n = 0;
-    if (t < ntask) fetch(t, brick_n, fm_n, subv_n);
+    unsigned brick_n = 0, fm_n = 0, subv_n = 0, slot_n = 0;
+    if (t < ntask) fetch(t, brick_n, fm_n, subv_n, slot_n);
     unsigned k_next = t < ntask ? take_ticket() : 0u;             // the entry after this one: its ticket is drawn a trip ahead of its fetch
     while (t < ntask) {
-        const unsigned brick = brick_n, subv = subv_n;
+        const unsigned brick = brick_n, subv = subv_n, slot = slot_n;
         unsigned fm = fm_n;
         if (lane == 0) B.framemask[brick] = 0u;                       // re-armed for the next batch that uses this buffer
         // saturating: a ticket far beyond the list must not wrap into it
         const unsigned t_next = entry_of(k_next);
         if (t_next < ntask) {
-            fetch(t_next, brick_n, fm_n, subv_n);
+            fetch(t_next, brick_n, fm_n, subv_n, slot_n);
             k_next = take_ticket();
         }
         t = t_next;
@@ -664,7 +677,8 @@ __global__ __launch_bounds__(256) void tsdf_update_kernel(Cam cam, Grid g, Batch
         }
         if (touched == 0u) continue;
         // load the records that change (8 B per lane, a sub-brick = one 512-B run), add, store
-        int2 *__restrict__ recs = grid + ((size_t)brick << 9);
+        if (slot >= SLOT_FULL) continue;                              // (sparse grid whose pool ran out: counted when the slot was refused)
+        int2 *__restrict__ recs = grid + ((size_t)slot << 9);
         int2 rec[8];
 #pragma unroll
         for (int s = 0; s < 8; ++s)
@@ -833,7 +847,7 @@ int launch_tsdf_prepare(hipStream_t s, const Cam &cam, const Grid &g, int n, int
 int launch_fold_free(hipStream_t s, const Grid &g, int2 *grid, unsigned *free_cnt) {
     const unsigned nbricks = (unsigned)(g.nbx * g.nby * g.nbz);
     const unsigned nb = (nbricks + 3u) / 4u < 2048u ? (nbricks + 3u) / 4u : 2048u;
-    hipLaunchKernelGGL(fold_free_kernel, dim3(nb ? nb : 1), dim3(256), 0, s, grid, free_cnt, nbricks);
+    hipLaunchKernelGGL(fold_free_kernel, dim3(nb ? nb : 1), dim3(256), 0, s, g, grid, free_cnt, nbricks);
     TL3D_HIP(hipGetLastError());
     return TL3D_OK;
 }

@@ -169,7 +169,9 @@ static int order_after_lanes(tl3d_ctx *ctx, int slot, bool rewrites_depth, bool 
 // exact largest voxel weight of the TSDF channel (blocks; the deferred updates must have been issued)
 static int measure_max_weight(tl3d_ctx *ctx, const int2 *grid, long long *out) {
     if (!ctx->d_maxw && hipMalloc(&ctx->d_maxw, sizeof(int)) != hipSuccess) return set_err(TL3D_E_NOMEM, "alloc failed");
-    int rc = launch_max_weight(ctx->stream, grid, ctx->nvox, ctx->d_maxw);
+    // the context's own channel: the pool slots in use + the counts of bricks without records; anything else: a dense array
+    int rc = grid == ctx->tsdf ? launch_max_weight(ctx->stream, ctx->grid, ctx->tsdf, ctx->d_maxw)
+                               : launch_max_weight_dense(ctx->stream, grid, ctx->nvox, ctx->d_maxw);
     if (rc) return rc;
     int h = 0;
     TL3D_HIP(hipMemcpyAsync(&h, ctx->d_maxw, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -212,6 +214,34 @@ static int validate_grid(const tl3d_config *cfg) {
     REQUIRE((double)cfg->nx * cfg->ny * cfg->nz <= 4294967296.0, TL3D_E_INVALID, "grid larger than 2^32 voxels");
     REQUIRE(cfg->voxel_size > 0, TL3D_E_INVALID, "voxel_size must be positive");
     if (cfg->channels & TL3D_CH_TSDF) REQUIRE(cfg->sdf_trunc > 0, TL3D_E_INVALID, "sdf_trunc must be positive");
+    REQUIRE(cfg->pool_bricks_tsdf >= 0 && cfg->pool_bricks_centroid >= 0, TL3D_E_INVALID, "negative brick pool size");
+    if (cfg->pool_bricks_tsdf > 0 || cfg->pool_bricks_centroid > 0)
+        REQUIRE(cfg->ext_tsdf == nullptr && cfg->ext_centroid == nullptr, TL3D_E_INVALID, "a sparse grid (pool_bricks_*) cannot live in caller-owned dense memory");
+    return TL3D_OK;
+}
+
+// brick tables and cursors of a fresh (or reset) grid, on the main stream: a dense channel's table is the identity and its
+// cursor sits at the end of the pool; a sparse channel starts empty
+static int reset_brick_tables(tl3d_ctx *ctx) {
+    Grid &g = ctx->grid;
+    const size_t nbr = ctx->nvox >> 9;
+    unsigned cur[4] = {0u, 0u, 0u, 0u};
+    if (g.tsdf_cap >= nbr) {
+        const int rc = launch_iota(ctx->stream, g.tsdf_tab, (unsigned)nbr);
+        if (rc) return rc;
+        cur[0] = (unsigned)nbr;
+    } else {
+        TL3D_HIP(hipMemsetAsync(g.tsdf_tab, 0xff, nbr * sizeof(unsigned), ctx->stream));
+    }
+    if (g.cen_cap >= nbr) {
+        const int rc = launch_iota(ctx->stream, g.cen_tab, (unsigned)nbr);
+        if (rc) return rc;
+        cur[2] = (unsigned)nbr;
+    } else {
+        TL3D_HIP(hipMemsetAsync(g.cen_tab, 0xff, nbr * sizeof(unsigned), ctx->stream));
+    }
+    TL3D_HIP(hipMemcpyAsync(g.cursors, cur, sizeof(cur), hipMemcpyHostToDevice, ctx->stream));
+    TL3D_HIP(hipStreamSynchronize(ctx->stream));           // `cur` is on this stack; the prep streams do not wait for the main stream
     return TL3D_OK;
 }
 
@@ -227,14 +257,28 @@ static int alloc_grid(tl3d_ctx *ctx, const tl3d_config *cfg) {
     ctx->nvox = (size_t)g.nx * g.ny * g.nz;
     ctx->tsdf_w_upper = 0;
     ctx->tsdf_w_unknown = false;
+    {   // brick tables: identity for a dense channel, empty for a sparse one (slots handed out on first touch)
+        const size_t nbr = ctx->nvox >> 9;
+        ctx->sparse = cfg->pool_bricks_tsdf > 0 || cfg->pool_bricks_centroid > 0;
+        g.tsdf_cap = (unsigned)((cfg->pool_bricks_tsdf > 0 && (size_t)cfg->pool_bricks_tsdf < nbr) ? (size_t)cfg->pool_bricks_tsdf : nbr);
+        g.cen_cap = (unsigned)((cfg->pool_bricks_centroid > 0 && (size_t)cfg->pool_bricks_centroid < nbr) ? (size_t)cfg->pool_bricks_centroid : nbr);
+        if (hipMalloc(&ctx->brick_tabs, (2 * nbr + 64) * sizeof(unsigned)) != hipSuccess) return set_err(TL3D_E_NOMEM, "brick table alloc failed");
+        g.tsdf_tab = ctx->brick_tabs;
+        g.cen_tab = ctx->brick_tabs + nbr;
+        g.cursors = ctx->brick_tabs + 2 * nbr;
+        g.free_cnt = nullptr;
+        const int trc = reset_brick_tables(ctx);
+        if (trc) return trc;
+    }
     if (cfg->channels & TL3D_CH_TSDF) {
         if (cfg->ext_tsdf) {
             ctx->tsdf = (int2 *)cfg->ext_tsdf;
             ctx->tsdf_w_unknown = true;                 // caller-owned memory: contents unknown
         } else {
-            if (hipMalloc(&ctx->tsdf, ctx->nvox * sizeof(int2)) != hipSuccess) return set_err(TL3D_E_NOMEM, "TSDF grid alloc (%zu B) failed", ctx->nvox * 8);
+            const size_t pool_b = (size_t)g.tsdf_cap << 12;
+            if (hipMalloc(&ctx->tsdf, pool_b) != hipSuccess) return set_err(TL3D_E_NOMEM, "TSDF record pool alloc (%zu B) failed", pool_b);
             ctx->own_tsdf = true;
-            if (hipMemsetAsync(ctx->tsdf, 0, ctx->nvox * sizeof(int2), ctx->stream) != hipSuccess) return set_err(TL3D_E_HIP, "memset failed");
+            if (hipMemsetAsync(ctx->tsdf, 0, pool_b, ctx->stream) != hipSuccess) return set_err(TL3D_E_HIP, "memset failed");
         }
         {   // side streams for the per-frame prep chains (tiles, pyramid, classification): a chain is three small dependent
             // kernels that crawl beside the update kernels (~45-75 us).  TWO by default.  Measured: on the 1080p bench three
@@ -254,6 +298,7 @@ static int alloc_grid(tl3d_ctx *ctx, const tl3d_config *cfg) {
             const size_t nbr = (size_t)g.nbx * g.nby * g.nbz;
             ctx->free_dirty = false;
             if (hipMalloc(&ctx->free_cnt, nbr * sizeof(unsigned)) != hipSuccess) return set_err(TL3D_E_NOMEM, "free-space counter alloc failed");
+            g.free_cnt = ctx->free_cnt;
             if (hipMemsetAsync(ctx->free_cnt, 0, nbr * sizeof(unsigned), ctx->stream) != hipSuccess) return set_err(TL3D_E_HIP, "memset failed");
             const int mrc = mark_free_cnt_write(ctx);
             if (mrc) return mrc;
@@ -288,9 +333,10 @@ static int alloc_grid(tl3d_ctx *ctx, const tl3d_config *cfg) {
         if (cfg->ext_centroid) {
             ctx->centroid = (unsigned long long *)cfg->ext_centroid;
         } else {
-            if (hipMalloc(&ctx->centroid, ctx->nvox * 32) != hipSuccess) return set_err(TL3D_E_NOMEM, "centroid grid alloc (%zu B) failed", ctx->nvox * 32);
+            const size_t pool_b = (size_t)g.cen_cap << 14;
+            if (hipMalloc(&ctx->centroid, pool_b) != hipSuccess) return set_err(TL3D_E_NOMEM, "centroid record pool alloc (%zu B) failed", pool_b);
             ctx->own_centroid = true;
-            if (hipMemsetAsync(ctx->centroid, 0, ctx->nvox * 32, ctx->stream) != hipSuccess) return set_err(TL3D_E_HIP, "memset failed");
+            if (hipMemsetAsync(ctx->centroid, 0, pool_b, ctx->stream) != hipSuccess) return set_err(TL3D_E_HIP, "memset failed");
         }
     }
     ctx->cfg.channels = cfg->channels;
@@ -462,6 +508,7 @@ int tl3d_destroy(tl3d_ctx *ctx) {
     pool_release(ctx->pool_u16);
     pool_release(ctx->pool_bgr);
     pool_release(ctx->pool_nmap);
+    if (ctx->brick_tabs) (void)hipFree(ctx->brick_tabs);
     if (ctx->own_tsdf && ctx->tsdf) (void)hipFree(ctx->tsdf);
     if (ctx->own_centroid && ctx->centroid) (void)hipFree(ctx->centroid);
     for (int q = 0; q < 4; ++q)
@@ -1524,8 +1571,12 @@ int tl3d_grid_reset(tl3d_ctx *ctx) {
     FLUSH_UPDATES(ctx);
     ctx->grid_epoch++;
     TL3D_HIP(hipSetDevice(ctx->device));
-    if (ctx->tsdf) TL3D_HIP(hipMemsetAsync(ctx->tsdf, 0, ctx->nvox * sizeof(int2), ctx->stream));
-    if (ctx->centroid) TL3D_HIP(hipMemsetAsync(ctx->centroid, 0, ctx->nvox * 32, ctx->stream));
+    if (ctx->tsdf) TL3D_HIP(hipMemsetAsync(ctx->tsdf, 0, (size_t)ctx->grid.tsdf_cap << 12, ctx->stream));
+    if (ctx->centroid) TL3D_HIP(hipMemsetAsync(ctx->centroid, 0, (size_t)ctx->grid.cen_cap << 14, ctx->stream));
+    if (ctx->sparse) {
+        const int trc = reset_brick_tables(ctx);
+        if (trc) return trc;
+    }
     if (ctx->free_cnt) {
         TL3D_HIP(hipMemsetAsync(ctx->free_cnt, 0, (ctx->nvox >> 9) * sizeof(unsigned), ctx->stream));
         const int mrc = mark_free_cnt_write(ctx);
@@ -1539,6 +1590,14 @@ int tl3d_grid_reset(tl3d_ctx *ctx) {
 
 int tl3d_grid_device_ptr(tl3d_ctx *ctx, uint32_t channel, void **ptr, size_t *bytes) {
     REQUIRE(ptr && bytes, TL3D_E_INVALID, "null out pointer");
+    if (ctx && channel == TL3D_CH_FREE) {
+        REQUIRE(ctx->free_cnt != nullptr, TL3D_E_STATE, "TSDF channel not enabled");
+        FLUSH_AND_FOLD(ctx);
+        *ptr = ctx->free_cnt;
+        *bytes = (ctx->nvox >> 9) * sizeof(unsigned);
+        return TL3D_OK;
+    }
+    if (ctx) REQUIRE(!ctx->sparse, TL3D_E_STATE, "a sparse grid has no dense layout to point at: use tl3d_grid_download / tl3d_grid_pack_bricks");
     if (ctx) {
         FLUSH_AND_FOLD(ctx);
         ctx->grid_epoch++;                  // the caller may write through the pointer (all-reduce)
@@ -1555,6 +1614,24 @@ int tl3d_grid_download(tl3d_ctx *ctx, uint32_t channel, void *out, size_t bytes)
     FLUSH_AND_FOLD(ctx);
     REQUIRE(out && bytes == nb, TL3D_E_INVALID, "buffer is %zu B, grid channel is %zu B", bytes, nb);
     TL3D_HIP(hipSetDevice(ctx->device));
+    if (ctx->sparse) {
+        // the dense image of the channel (what a dense grid would hold, free-space counts folded in): bricks gathered through the table
+        void *tmp = nullptr;
+        void *dst = out;
+        const bool dev_out = is_device_ptr(out);
+        if (!dev_out) {
+            if (hipMalloc(&tmp, nb) != hipSuccess) return set_err(TL3D_E_NOMEM, "dense image of the sparse grid (%zu B) does not fit", nb);
+            dst = tmp;
+        }
+        rc = launch_brick_rows(ctx->stream, ctx->grid, 0, channel == TL3D_CH_TSDF, p, nullptr, (long long)(ctx->nvox >> 9), dst, true);
+        hipError_t e = hipSuccess;
+        if (rc == TL3D_OK && !dev_out) e = hipMemcpyAsync(out, tmp, nb, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (tmp) (void)hipFree(tmp);
+        if (rc) return rc;
+        TL3D_HIP(e);
+        return TL3D_OK;
+    }
     TL3D_HIP(hipMemcpyAsync(out, p, nb, hipMemcpyDefault, ctx->stream));
     TL3D_HIP(hipStreamSynchronize(ctx->stream));
     return TL3D_OK;
@@ -1577,6 +1654,21 @@ int tl3d_grid_upload(tl3d_ctx *ctx, uint32_t channel, const void *in, size_t byt
             if (mrc) return mrc;
         }
         ctx->free_dirty = false;
+    }
+    if (ctx->sparse) {
+        // the channel becomes the dense image `in`: bricks that hold anything get records, the others' records are cleared
+        void *tmp = nullptr;
+        const void *src = in;
+        if (!is_device_ptr(in)) {
+            if (hipMalloc(&tmp, nb) != hipSuccess) return set_err(TL3D_E_NOMEM, "grid staging alloc failed");
+            hipError_t e = hipMemcpyAsync(tmp, in, nb, hipMemcpyHostToDevice, ctx->stream);
+            if (e != hipSuccess) { (void)hipFree(tmp); return set_err(TL3D_E_HIP, "grid upload failed"); }
+            src = tmp;
+        }
+        rc = launch_brick_rows(ctx->stream, ctx->grid, 1, channel == TL3D_CH_TSDF, p, nullptr, (long long)(ctx->nvox >> 9), const_cast<void *>(src), false);
+        (void)hipStreamSynchronize(ctx->stream);
+        if (tmp) (void)hipFree(tmp);
+        return rc;
     }
     TL3D_HIP(hipMemcpyAsync(p, in, nb, hipMemcpyDefault, ctx->stream));
     TL3D_HIP(hipStreamSynchronize(ctx->stream));
@@ -1611,10 +1703,12 @@ int tl3d_grid_add(tl3d_ctx *ctx, uint32_t channel, const void *other, size_t byt
         if (rc == TL3D_OK) {
             ctx->tsdf_w_upper = wa + wb;
             ctx->tsdf_w_unknown = false;
-            rc = launch_add_i32(ctx->stream, (int *)p, (const int *)src, nb / 4);
+            rc = ctx->sparse ? launch_brick_rows(ctx->stream, ctx->grid, 2, true, p, nullptr, (long long)(ctx->nvox >> 9), const_cast<void *>(src), false)
+                             : launch_add_i32(ctx->stream, (int *)p, (const int *)src, nb / 4);
         }
     } else
-        rc = launch_add_u64(ctx->stream, (unsigned long long *)p, (const unsigned long long *)src, nb / 8);
+        rc = ctx->sparse ? launch_brick_rows(ctx->stream, ctx->grid, 2, false, p, nullptr, (long long)(ctx->nvox >> 9), const_cast<void *>(src), false)
+                         : launch_add_u64(ctx->stream, (unsigned long long *)p, (const unsigned long long *)src, nb / 8);
     if (tmp) {
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipFree(tmp);
@@ -1632,7 +1726,7 @@ int tl3d_grid_touched_bricks(tl3d_ctx *ctx, uint32_t channels, uint8_t *map_dev,
     REQUIRE(is_device_ptr(map_dev), TL3D_E_INVALID, "the brick map must be device memory");
     FLUSH_AND_FOLD(ctx);
     TL3D_HIP(hipSetDevice(ctx->device));
-    return launch_touched_bricks(ctx->stream, (channels & TL3D_CH_TSDF) ? ctx->tsdf : nullptr, (channels & TL3D_CH_CENTROID) ? ctx->centroid : nullptr,
+    return launch_touched_bricks(ctx->stream, ctx->grid, (channels & TL3D_CH_TSDF) ? ctx->tsdf : nullptr, (channels & TL3D_CH_CENTROID) ? ctx->centroid : nullptr,
                                  (unsigned)n_bricks, map_dev);
 }
 
@@ -1648,7 +1742,7 @@ static int brick_rows(tl3d_ctx *ctx, uint32_t channel, const uint32_t *bricks_de
     ctx->grid_epoch++;
     TL3D_HIP(hipSetDevice(ctx->device));
     if (!pack && channel == TL3D_CH_TSDF) ctx->tsdf_w_unknown = true;      // the records now hold what the caller summed
-    return launch_brick_rows(ctx->stream, pack, p, bricks_dev, n, channel == TL3D_CH_TSDF ? 4096u : 16384u, packed_dev);
+    return launch_brick_rows(ctx->stream, ctx->grid, pack ? 0 : 1, channel == TL3D_CH_TSDF, p, bricks_dev, n, packed_dev, false);
 }
 
 int tl3d_grid_pack_bricks(tl3d_ctx *ctx, uint32_t channel, const uint32_t *bricks_dev, int64_t n, void *packed_dev) {
@@ -1747,7 +1841,7 @@ int tl3d_allreduce_grid(tl3d_ctx *ctx, uint32_t channels) {
     {
         hipError_t e = hipMemsetAsync(d_map, 0, nbr, ctx->stream);
         if (e == hipSuccess)
-            rc = launch_touched_bricks(ctx->stream, (channels & TL3D_CH_TSDF) ? ctx->tsdf : nullptr, (channels & TL3D_CH_CENTROID) ? ctx->centroid : nullptr,
+            rc = launch_touched_bricks(ctx->stream, ctx->grid, (channels & TL3D_CH_TSDF) ? ctx->tsdf : nullptr, (channels & TL3D_CH_CENTROID) ? ctx->centroid : nullptr,
                                        (unsigned)nbr, d_map);
         int nrc = (e == hipSuccess && rc == TL3D_OK) ? g_rccl.AllReduce(d_map, d_map, nbr, 1 /* ncclUint8 */, 2 /* ncclMax */, ctx->rccl_comm, ctx->stream) : -1;
         if (nrc == 0) e = hipMemcpyAsync(h_map.data(), d_map, nbr, hipMemcpyDeviceToHost, ctx->stream);
@@ -1757,7 +1851,12 @@ int tl3d_allreduce_grid(tl3d_ctx *ctx, uint32_t channels) {
     }
     for (size_t b = 0; b < nbr; ++b)
         if (h_map[b]) h_idx.push_back((unsigned)b);
-    const bool sparse = h_idx.size() * 2 < nbr;
+    const bool sparse = ctx->sparse || h_idx.size() * 2 < nbr;
+    if (ctx->sparse && (channels & TL3D_CH_TSDF) && ctx->free_cnt) {
+        // bricks without records carry their free-space observations as a count: summed like the records (4 B per brick)
+        const int nrc = g_rccl.AllReduce(ctx->free_cnt, ctx->free_cnt, nbr, 3 /* ncclUint32 */, 0, ctx->rccl_comm, ctx->stream);
+        REQUIRE(nrc == 0, TL3D_E_HIP, "ncclAllReduce (free-space counts) failed: %s", rccl_msg(nrc));
+    }
     ctx->stats.merge_bricks_sent += sparse ? h_idx.size() : nbr;
     ctx->stats.merge_bricks_total += nbr;
     if (!sparse) {
@@ -1785,14 +1884,14 @@ int tl3d_allreduce_grid(tl3d_ctx *ctx, uint32_t channels) {
     hipError_t e = hipMemcpyAsync(d_idx, h_idx.data(), n * sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream);
     int nrc = 0;
     if (e == hipSuccess && (channels & TL3D_CH_TSDF)) {
-        rc = launch_brick_rows(ctx->stream, true, ctx->tsdf, d_idx, (long long)n, 4096u, d_pack);
+        rc = launch_brick_rows(ctx->stream, ctx->grid, 0, true, ctx->tsdf, d_idx, (long long)n, d_pack, false);
         if (rc == TL3D_OK) nrc = g_rccl.AllReduce(d_pack, d_pack, n * 1024, 2 /* ncclInt32 */, 0, ctx->rccl_comm, ctx->stream);
-        if (rc == TL3D_OK && nrc == 0) rc = launch_brick_rows(ctx->stream, false, ctx->tsdf, d_idx, (long long)n, 4096u, d_pack);
+        if (rc == TL3D_OK && nrc == 0) rc = launch_brick_rows(ctx->stream, ctx->grid, 1, true, ctx->tsdf, d_idx, (long long)n, d_pack, false);
     }
     if (e == hipSuccess && rc == TL3D_OK && nrc == 0 && (channels & TL3D_CH_CENTROID)) {
-        rc = launch_brick_rows(ctx->stream, true, ctx->centroid, d_idx, (long long)n, 16384u, d_pack);
+        rc = launch_brick_rows(ctx->stream, ctx->grid, 0, false, ctx->centroid, d_idx, (long long)n, d_pack, false);
         if (rc == TL3D_OK) nrc = g_rccl.AllReduce(d_pack, d_pack, n * 2048, 5 /* ncclUint64 */, 0, ctx->rccl_comm, ctx->stream);
-        if (rc == TL3D_OK && nrc == 0) rc = launch_brick_rows(ctx->stream, false, ctx->centroid, d_idx, (long long)n, 16384u, d_pack);
+        if (rc == TL3D_OK && nrc == 0) rc = launch_brick_rows(ctx->stream, ctx->grid, 1, false, ctx->centroid, d_idx, (long long)n, d_pack, false);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(d_idx);
@@ -1934,6 +2033,13 @@ int tl3d_get_stats(tl3d_ctx *ctx, tl3d_stats *out) {
     ctx->stats.tsdf_bricks_free = h[5];
     ctx->stats.tsdf_bricks_free_counted = h[6];
     ctx->stats.tsdf_batch_bricks = h[7];
+    if (ctx->brick_tabs) {
+        unsigned cur[4] = {0, 0, 0, 0};
+        TL3D_HIP(hipMemcpy(cur, ctx->grid.cursors, sizeof(cur), hipMemcpyDeviceToHost));
+        ctx->stats.pool_slots_tsdf = ctx->tsdf ? (cur[0] < ctx->grid.tsdf_cap ? cur[0] : ctx->grid.tsdf_cap) : 0;
+        ctx->stats.pool_slots_centroid = ctx->centroid ? (cur[2] < ctx->grid.cen_cap ? cur[2] : ctx->grid.cen_cap) : 0;
+        ctx->stats.pool_refused = (uint64_t)cur[1] + cur[3];
+    }
     *out = ctx->stats;
     return TL3D_OK;
 }

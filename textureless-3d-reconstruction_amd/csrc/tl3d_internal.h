@@ -22,7 +22,16 @@ struct Grid {
     float ox, oy, oz, vs;        // f32 origin / voxel size (TSDF path)
     double oxd, oyd, ozd, vsd;   // fp64 (centroid path, Open3D index semantics)
     float trunc, inv_trunc;
+    // Brick tables: the records of virtual brick b of a channel sit in pool slot table[b] (512 records each).  A dense grid has
+    // the identity table and a pool of every brick; a SPARSE grid starts with an empty table and hands out slots on first
+    // touch (brick_slot_ensure) until its pool is full.  cursors: [0] TSDF slots handed out, [1] TSDF refusals (pool full),
+    // [2] / [3] the same for the centroid channel.
+    unsigned *tsdf_tab, *cen_tab, *cursors;
+    unsigned tsdf_cap, cen_cap;
+    const unsigned *free_cnt;    // per-brick free-space counts not yet folded into records (readers add them: see tsdf_record)
 };
+constexpr unsigned SLOT_EMPTY = 0xffffffffu;    // no records yet
+constexpr unsigned SLOT_FULL = 0xfffffffeu;     // the pool had no slot left when the brick was first touched: its updates are dropped (counted)
 
 struct PoseF {                   // world->camera, f32 (or src->tgt for ICP)
     float r[9];
@@ -129,9 +138,11 @@ struct tl3d_ctx {
     size_t nvox;
     tl3d::Slot *slots;
     tl3d::FramePool pool_depth, pool_u16, pool_bgr, pool_nmap;
-    int2 *tsdf;                  // [nvox] {sum_q, weight}
-    unsigned long long *centroid;// [nvox][4]
+    int2 *tsdf;                  // record pool of the TSDF channel: [tsdf_cap bricks][512] {sum_q, weight}; a dense grid's pool is the grid
+    unsigned long long *centroid;// record pool of the centroid channel: [cen_cap bricks][512][4]
     bool own_tsdf, own_centroid;
+    bool sparse;                 // pools smaller than the grid, slots handed out on first touch (tl3d_config.pool_bricks_*)
+    unsigned *brick_tabs;        // one allocation: TSDF table [nbricks], centroid table [nbricks], cursors [4]
     // scratch
     // TSDF integration is double-buffered over two streams: the tile/pyramid/cull kernels of frame i+1 run on
     // prep_stream while the update kernel of frame i streams the grid on the main stream.
@@ -260,6 +271,65 @@ __device__ __forceinline__ size_t vox_index(int i, int j, int k, int nbx, int nb
     return brick_base(i >> 3, j >> 3, k >> 3, nbx, nby) + (size_t)in_brick_index(i, j, k);
 }
 
+// ---- brick tables ---------------------------------------------------------------------------------------------------------
+// The table is read and written by kernels that run side by side: agent-scope accesses only (a CU's L1 would go on showing
+// SLOT_EMPTY after another CU -- or this one, through the L2 -- filled the entry, and every such stale read would take, and
+// leak, a fresh slot).
+__device__ __forceinline__ unsigned brick_slot(const unsigned *table, unsigned brick) {
+    return __hip_atomic_load(table + brick, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Slot of `brick`, handing one out on first touch.  Wait-free: the slot is drawn before the compare-and-swap, the loser of a
+// race keeps the winner's slot and its own draw is lost to the pool (callers make sure that the lanes of ONE wave do not race
+// for the same brick -- see wave_slots -- so that only cross-wave races leak, and those are rare).  SLOT_FULL when the pool is
+// exhausted (sticky: later touches see it in the table).
+__device__ __forceinline__ unsigned brick_slot_ensure(unsigned *table, unsigned *cursor, unsigned cap, unsigned brick) {
+    unsigned s = brick_slot(table, brick);
+    if (s != SLOT_EMPTY) return s;
+    unsigned n = atomicAdd(cursor, 1u);
+    if (n >= cap) {
+        n = SLOT_FULL;
+        atomicAdd(cursor + 1, 1u);
+    }
+    const unsigned old = atomicCAS(table + brick, SLOT_EMPTY, n);
+    return old == SLOT_EMPTY ? n : old;
+}
+// the same for every lane of a wave at once (want: the lane needs its brick's slot): one leader per distinct brick draws, the
+// lanes that share the brick take its answer.  Every lane of the wave must call it.
+__device__ __forceinline__ unsigned wave_slots(unsigned *table, unsigned *cursor, unsigned cap, unsigned brick, bool want) {
+    unsigned slot = want ? brick_slot(table, brick) : 0u;          // the common case: every brick has its slot already
+    unsigned long long todo = __ballot(want && slot == SLOT_EMPTY);
+    while (todo) {
+        const int leader = __builtin_ctzll(todo);
+        const unsigned b = (unsigned)__builtin_amdgcn_readlane((int)brick, leader);
+        unsigned s = 0;
+        if ((threadIdx.x & 63) == leader) s = brick_slot_ensure(table, cursor, cap, b);
+        s = (unsigned)__builtin_amdgcn_readlane((int)s, leader);
+        const bool mine = want && slot == SLOT_EMPTY && brick == b;
+        todo &= ~__ballot(mine);
+        if (mine) slot = s;
+    }
+    return slot;
+}
+// TSDF record of virtual record index idx as a reader must see it: the stored sums plus the brick's pending free-space count
+// (count x (32767, 1)); a brick without records reads as free space only
+__device__ __forceinline__ int2 tsdf_record(const Grid &g, const int2 *__restrict__ pool, size_t idx) {
+    const unsigned brick = (unsigned)(idx >> 9);
+    const unsigned s = brick_slot(g.tsdf_tab, brick);
+    int2 r = make_int2(0, 0);
+    if (s < SLOT_FULL) r = pool[((size_t)s << 9) | (idx & 511)];
+    if (g.free_cnt) {
+        const unsigned c = g.free_cnt[brick];
+        r.x += (int)(c * 32767u);
+        r.y += (int)c;
+    }
+    return r;
+}
+// centroid record (4 words) of virtual record index idx, nullptr when its brick has none
+__device__ __forceinline__ const unsigned long long *cen_record(const Grid &g, const unsigned long long *__restrict__ pool, size_t idx) {
+    const unsigned s = brick_slot(g.cen_tab, (unsigned)(idx >> 9));
+    return s < SLOT_FULL ? pool + 4 * (((size_t)s << 9) | (idx & 511)) : nullptr;
+}
+
 // ---- kernel launchers (one per .hip file) -----------------------------------------------------
 // frames
 int launch_u16_to_f32(hipStream_t s, const uint16_t *in, float *out, size_t n);
@@ -298,9 +368,11 @@ int launch_extract_write(hipStream_t s, const Grid &g, int mode, int min_count, 
                          const int2 *tsdf, const unsigned long long *cen, const unsigned long long *offsets, int nblocks,
                          float *xyz, uint8_t *rgb, unsigned long long cap);
 // grids
-int launch_max_weight(hipStream_t s, const int2 *grid, size_t nvox, int *d_out);
-int launch_touched_bricks(hipStream_t s, const int2 *tsdf, const unsigned long long *cen, unsigned nbricks, unsigned char *map);
-int launch_brick_rows(hipStream_t s, bool pack, void *grid, const unsigned *idx, long long n, unsigned bytes_per_brick, void *packed);
+int launch_max_weight(hipStream_t s, const Grid &g, const int2 *pool, int *d_out);
+int launch_max_weight_dense(hipStream_t s, const int2 *grid, size_t nvox, int *d_out);
+int launch_touched_bricks(hipStream_t s, const Grid &g, const int2 *tsdf, const unsigned long long *cen, unsigned nbricks, unsigned char *map);
+int launch_brick_rows(hipStream_t s, const Grid &g, int mode, bool is_tsdf, void *pool, const unsigned *idx, long long n, void *rows, bool add_free);
+int launch_iota(hipStream_t s, unsigned *t, unsigned n);
 int probe_hw_queues(int n_streams, double spin_ms, double *elapsed_ms);
 int launch_add_i32(hipStream_t s, int *dst, const int *src, size_t n);
 int launch_add_u64(hipStream_t s, unsigned long long *dst, const unsigned long long *src, size_t n);

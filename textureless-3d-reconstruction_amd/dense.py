@@ -107,13 +107,22 @@ class _DeviceDense:
         dims = np.floor((mx - origin) / v).astype(np.int64) + 1
         dims = ((dims + 7) // 8) * 8
         nvox = int(dims[0]) * int(dims[1]) * int(dims[2])
-        if nvox * 32 > MERGE_GRID_BUDGET_BYTES or nvox > (1 << 32):
-            raise MemoryError(f"merge_pointclouds: extent {mx - mn} m at voxel {v} m needs a {tuple(int(d) for d in dims)} grid "
-                              f"({nvox * 32 / 2**30:.0f} GiB); raise voxel_size or fuse through a bounded GridSpec")
-        spec = GridSpec(tuple(int(d) for d in dims), tuple(float(o) for o in origin), v, 4 * v, abi.CH_CENTROID)
+        if nvox > (1 << 32):
+            raise MemoryError(f"merge_pointclouds: extent {mx - mn} m at voxel {v} m needs a {tuple(int(d) for d in dims)} grid: more than "
+                              "2^32 voxels (the brick tables index 32 bits); raise voxel_size")
+        # Open3D's hash map holds the occupied voxels only (D2R:404-410): so does a sparse grid.  A cloud of n points occupies
+        # at most n voxels, i.e. at most n bricks; the pool is what the points can need, capped by the memory budget.
+        n_points = int(sum(len(p) for p in pts))
+        pool = 0
+        if nvox * 32 > MERGE_GRID_BUDGET_BYTES // 4:
+            pool = int(min(nvox // 512, max(4096, min(n_points, MERGE_GRID_BUDGET_BYTES // 16384))))
+        spec = GridSpec(tuple(int(d) for d in dims), tuple(float(o) for o in origin), v, 4 * v, abi.CH_CENTROID, pool_centroid=pool)
         with FusionContext(8, 8, 1.0, 1.0, 0.0, 0.0, n_slots=1, grid=spec, device=self._device) as ctx:
             for p, c in zip(pts, col):
                 ctx.accumulate_points(p, c)
+            if pool and ctx.stats()["pool_refused"]:
+                raise MemoryError(f"merge_pointclouds: the cloud occupies more than {pool} bricks of 8^3 voxels at voxel {v} m "
+                                  f"({pool * 16384 / 2**30:.0f} GiB of records): raise voxel_size")
             xyz, rgb = ctx.extract(abi.EXTRACT_CENTROID)
             if sor and len(xyz) > 0:
                 keep = ctx.statistical_outlier(xyz, nb_neighbors, std_ratio, cell_size=2.0 * v)

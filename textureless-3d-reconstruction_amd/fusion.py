@@ -21,6 +21,22 @@ class GridSpec:
     voxel_size: float = 0.005          # depth_to_reconstruction.py:64
     sdf_trunc: float = 0.02            # 4 voxels at the reference voxel size
     channels: int = abi.CH_TSDF | abi.CH_CENTROID
+    # SPARSE grid: the channel keeps records for at most this many 8^3 bricks (4 KB / 16 KB each), handed out on first touch
+    # through a brick table; 0 = dense.  dims may then describe a volume far larger than memory (what the reference's hash-map
+    # merge gives for free, D2R:404-410).
+    pool_tsdf: int = 0
+    pool_centroid: int = 0
+
+    @property
+    def sparse(self) -> bool:
+        return bool(self.pool_tsdf or self.pool_centroid)
+
+    def device_bytes(self) -> int:
+        """HBM the grid takes: record pools + brick tables + free-space counters."""
+        nbr = self.nvox // 512
+        t = (min(self.pool_tsdf, nbr) if self.pool_tsdf else nbr) * 4096 if self.channels & abi.CH_TSDF else 0
+        c = (min(self.pool_centroid, nbr) if self.pool_centroid else nbr) * 16384 if self.channels & abi.CH_CENTROID else 0
+        return t + c + 12 * nbr
 
     @property
     def nvox(self) -> int:
@@ -79,6 +95,7 @@ class FusionContext:
             cfg.origin = (C.c_double * 3)(*[float(o) for o in grid.origin])
             cfg.voxel_size = float(grid.voxel_size)
             cfg.sdf_trunc = float(grid.sdf_trunc)
+            cfg.pool_bricks_tsdf, cfg.pool_bricks_centroid = int(grid.pool_tsdf), int(grid.pool_centroid)
         cfg.ext_tsdf = abi.ptr(ext_tsdf)
         cfg.ext_centroid = abi.ptr(ext_centroid)
         cfg.stream = abi.ptr(stream)
@@ -154,6 +171,7 @@ class FusionContext:
         cfg.nx, cfg.ny, cfg.nz = (int(d) for d in grid.dims)
         cfg.origin = (C.c_double * 3)(*[float(o) for o in grid.origin])
         cfg.voxel_size, cfg.sdf_trunc = float(grid.voxel_size), float(grid.sdf_trunc)
+        cfg.pool_bricks_tsdf, cfg.pool_bricks_centroid = int(grid.pool_tsdf), int(grid.pool_centroid)
         cfg.ext_tsdf, cfg.ext_centroid = abi.ptr(ext_tsdf), abi.ptr(ext_centroid)
         abi.check(self._lib.tl3d_attach_grid(self._h, C.byref(cfg)))
         self._keep = (ext_tsdf, ext_centroid)
@@ -355,8 +373,12 @@ class FusionContext:
         abi.check(self._lib.tl3d_grid_device_ptr(self._h, int(channel), C.byref(p), C.byref(nb)))
         return p.value, nb.value
 
+    def _channel_bytes(self, channel: int) -> int:
+        return self.grid.nvox * (8 if channel == abi.CH_TSDF else 32)
+
     def download_grid(self, channel: int) -> np.ndarray:
-        _, nb = self.grid_ptr(channel)
+        """The channel as a dense array in record order (a sparse grid is gathered through its brick table: the same image)."""
+        nb = self._channel_bytes(channel)
         if channel == abi.CH_TSDF:
             out = np.empty((nb // 8, 2), np.int32)
         else:
@@ -365,14 +387,14 @@ class FusionContext:
         return out
 
     def upload_grid(self, channel: int, arr):
-        _, nb = self.grid_ptr(channel)
+        nb = self._channel_bytes(channel)
         if isinstance(arr, np.ndarray):
             arr = np.ascontiguousarray(arr)
             assert arr.nbytes == nb
         abi.check(self._lib.tl3d_grid_upload(self._h, int(channel), abi.ptr(arr), nb))
 
     def add_grid(self, channel: int, arr):
-        _, nb = self.grid_ptr(channel)
+        nb = self._channel_bytes(channel)
         if isinstance(arr, np.ndarray):
             arr = np.ascontiguousarray(arr)
             assert arr.nbytes == nb

@@ -32,13 +32,14 @@ def compose(r_rel, t_rel, r_prev, t_prev):
 
 
 def plan_grid(bounds_min, bounds_max, voxel_size, grid_dim, channels=abi.CH_TSDF | abi.CH_CENTROID, trunc_voxels=4.0,
-              max_voxels=None):
+              max_voxels=None, sparse_bytes=None):
     """Grid with Open3D's voxel origin (min_bound - voxel/2) covering the bounds.
 
-    The cap is a voxel BUDGET (default grid_dim^3 voxels in total, never more than the library's 2^32), not a cube: a
-    2 m x 2.4 m x 12 m corridor at 5 mm becomes 400 x 480 x 2400 voxels.  Only when the bounds need more than the budget
-    is the grid shrunk about the scene centre -- longest axis first -- and `clipped` returned True (points outside are
-    dropped and counted by the accumulation kernels; the caller prints the warning)."""
+    Up to a voxel BUDGET (default grid_dim^3 voxels in total; not a cube: a 2 m x 2.4 m x 12 m corridor at 5 mm becomes
+    400 x 480 x 2400 voxels) the grid is dense.  Beyond it the grid is SPARSE, as the reference's hash-map merge is
+    (D2R:404-410): the same dims, records only for the bricks the data touches, pools sized by sparse_bytes (default: the dense
+    budget's bytes).  Only a scene of more than 2^32 voxels is shrunk about its centre -- longest axis first -- and `clipped`
+    returned True (points outside are dropped and counted by the accumulation kernels; the caller prints the warning)."""
     v = float(voxel_size)
     mn, mx = np.asarray(bounds_min, np.float64), np.asarray(bounds_max, np.float64)
     origin = mn - 0.5 * v
@@ -48,7 +49,7 @@ def plan_grid(bounds_min, bounds_max, voxel_size, grid_dim, channels=abi.CH_TSDF
     budget = max(512, min(budget, 1 << 32))
     clipped = False
     want = dims.copy()
-    while int(dims[0]) * int(dims[1]) * int(dims[2]) > budget:       # shave the (currently) longest axis, 8 voxels at a time
+    while int(dims[0]) * int(dims[1]) * int(dims[2]) > (1 << 32):    # shave the (currently) longest axis, 8 voxels at a time
         a = int(np.argmax(dims))
         if dims[a] <= 8:
             break
@@ -57,7 +58,18 @@ def plan_grid(bounds_min, bounds_max, voxel_size, grid_dim, channels=abi.CH_TSDF
     for a in range(3):
         if dims[a] < want[a]:
             origin[a] = 0.5 * (mn[a] + mx[a]) - 0.5 * dims[a] * v
-    return GridSpec(tuple(int(d) for d in dims), tuple(float(o) for o in origin), v, trunc_voxels * v, channels), clipped
+    nvox = int(dims[0]) * int(dims[1]) * int(dims[2])
+    pool_t = pool_c = 0
+    if nvox > budget:
+        per_vox = (8 if channels & abi.CH_TSDF else 0) + (32 if channels & abi.CH_CENTROID else 0)
+        mem = int(sparse_bytes) if sparse_bytes is not None else budget * per_vox
+        # surfaces: the TSDF band is ~3 bricks thick where the centroid channel holds one layer: 12 KB + 16 KB per surface brick
+        unit = (3 * 4096 if channels & abi.CH_TSDF else 0) + (16384 if channels & abi.CH_CENTROID else 0)
+        surf = max(4096, mem // unit)
+        pool_t = int(min(nvox // 512, 3 * surf)) if channels & abi.CH_TSDF else 0
+        pool_c = int(min(nvox // 512, surf)) if channels & abi.CH_CENTROID else 0
+    return GridSpec(tuple(int(d) for d in dims), tuple(float(o) for o in origin), v, trunc_voxels * v, channels,
+                    pool_tsdf=pool_t, pool_centroid=pool_c), clipped
 
 
 class ScaleTracker:
@@ -389,7 +401,14 @@ class DepthToReconstructionPipeline:
                 keep = ctx.statistical_outlier(xyz, cfg.outlier_nb_neighbors, cfg.outlier_std_ratio, cell_size=2.0 * grid.voxel_size)
                 xyz, rgb = xyz[keep], rgb[keep]
             self.stats = dict(points_accumulated=st["centroid_points"], points_dropped=st["centroid_dropped"],
-                              voxels=n_vox, after_outlier_filter=len(xyz))
+                              voxels=n_vox, after_outlier_filter=len(xyz), sparse=bool(grid.sparse),
+                              bricks_tsdf=st["pool_slots_tsdf"], bricks_centroid=st["pool_slots_centroid"], pool_refused=st["pool_refused"])
+            if grid.sparse:
+                print(f"  Sparse volume: {st['pool_slots_tsdf']} TSDF bricks and {st['pool_slots_centroid']} centroid bricks hold records "
+                      f"(of {grid.nvox // 512}); {grid.device_bytes() / 2**30:.2f} GiB")
+                if st["pool_refused"]:
+                    print(f"  Warning: {st['pool_refused']} bricks found the record pool full and are missing from the result "
+                          "(raise --grid, the memory budget of the volume)")
             marks.append(("extract_and_filter", clock()))
             # wall time of each stage of this call (host clock; stages end at a point where the host has the stage's result)
             self.timings = {name + "_s": round(t1 - t0, 4) for (name, t1), (_, t0) in zip(marks[1:], marks[:-1])}
