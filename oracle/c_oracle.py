@@ -167,6 +167,15 @@ class Oracle:
         lib().orc_normals(C.byref(self.cfg), _p(d), C.c_double(scale), C.c_double(depth_jump), _p(nmap))
         return nmap
 
+    def normals_smooth(self, depth, radius=2, scale=1.0, depth_jump=0.05):
+        """(smoothed depth [H,W] in the units of `depth`, nmap [H,W,4]): window mean over valid pixels within depth_jump of the
+        centre, normals from it with a `radius`-pixel step (orc_normals_smooth)."""
+        d = self._depth(depth)
+        sd = np.empty((self.cfg.height, self.cfg.width), np.float32)
+        nmap = np.empty((self.cfg.height, self.cfg.width, 4), np.float32)
+        lib().orc_normals_smooth(C.byref(self.cfg), _p(d), C.c_double(scale), C.c_double(depth_jump), C.c_int(int(radius)), _p(sd), _p(nmap))
+        return sd, nmap
+
     def icp(self, depth_src, nmap_tgt, T_init=None, iters=10, stride=4, max_dist=0.05, damping=1e-6, eps=1e-9,
             scale_src=1.0, eig_rel=1e-4, estimate_scale=False):
         d = self._depth(depth_src)

@@ -27,7 +27,7 @@ SYMBOLS = [
     "tl3d_accumulate_points", "tl3d_points_bounds", "tl3d_integrate", "tl3d_build_normals",
     "tl3d_download_normals", "tl3d_icp_p2plane", "tl3d_icp_enqueue", "tl3d_icp_collect", "tl3d_icp_batch_enqueue", "tl3d_icp_batch_collect", "tl3d_host_pack_bgr_rows", "tl3d_host_copy_rows", "tl3d_build_normals_many", "tl3d_fuse_frames", "tl3d_grid_reset", "tl3d_grid_device_ptr",
     "tl3d_grid_download", "tl3d_grid_upload", "tl3d_grid_add", "tl3d_grid_touched_bricks", "tl3d_grid_pack_bricks", "tl3d_grid_unpack_bricks", "tl3d_rccl_unique_id", "tl3d_rccl_init", "tl3d_allreduce_grid", "tl3d_extract", "tl3d_statistical_outlier",
-    "tl3d_set_profile", "tl3d_set_tsdf_pairing", "tl3d_get_stats", "tl3d_reset_stats", "tl3d_event_record", "tl3d_event_elapsed_ms",
+    "tl3d_set_profile", "tl3d_set_normal_smoothing", "tl3d_set_tsdf_pairing", "tl3d_get_stats", "tl3d_reset_stats", "tl3d_event_record", "tl3d_event_elapsed_ms",
 ]
 
 

@@ -41,6 +41,7 @@ class ReconstructionConfig:
     icp_damping: float = 1e-6
     icp_eps: float = 1e-7               # a level stops once the largest component of its pose update is below this (rad / m)
     icp_eig_rel: float = 1e-4           # relative eigenvalue cutoff: unobservable DOFs keep the motion prior
+    icp_smooth_radius: int = 1          # normals (and the registration's source depth) from the depth averaged over a (2 r + 1)^2 window; 0 = raw
     scale_update_weight: float = 0.3    # estimate_scale runs: avg = (1 - w) avg + w scale_i (D2R:650 uses 0.3); 1 = each view's own estimate
     tsdf_min_weight: int = 0            # > 0: gate the emitted centroids by the TSDF (outlier suppression)
     tsdf_max_abs: float = 1.0

@@ -30,19 +30,53 @@ __device__ __forceinline__ bool load_vertex(const Cam &cam, const float *__restr
     return true;
 }
 
+// Noise-robust normals, first half (oracle: orc_normals_smooth): the depth averaged over the (2 radius + 1)^2 window of every pixel
+// -- over the pixels that are valid and within `jump` of the centre pixel, summed in row-major order in f32 (the oracle's order);
+// out stays in the units of `depth`, 0 = invalid centre.  1 mm of depth noise turns central differences over one pixel (0.6 mm
+// apart at 1 m, f = 1719) into noise; normals_kernel then takes its tangent vectors `radius` pixels to either side of this map.
+__global__ __launch_bounds__(256) void smooth_depth_kernel(Cam cam, const float *__restrict__ depth, float sc, float mind, float maxd, float jump,
+                                                           int radius, float *__restrict__ out) {
+    const int u = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int v = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (u >= cam.W || v >= cam.H) return;
+    const float d0 = depth[(size_t)v * cam.W + u] * sc;
+    float res = 0.0f;
+    if (d0 > mind && d0 < maxd) {
+        float sum = 0.0f;
+        int n = 0;
+        for (int dv = -radius; dv <= radius; ++dv) {
+            const int vv = v + dv;
+            if (vv < 0 || vv >= cam.H) continue;
+            for (int du = -radius; du <= radius; ++du) {
+                const int uu = u + du;
+                if (uu < 0 || uu >= cam.W) continue;
+                const float dr = depth[(size_t)vv * cam.W + uu];
+                const float d = dr * sc;
+                if (!(d > mind && d < maxd)) continue;
+                if (!(fabsf(d - d0) <= jump)) continue;
+                sum += dr;
+                ++n;
+            }
+        }
+        res = sum / (float)n;
+    }
+    out[(size_t)v * cam.W + u] = res;
+}
+
+// step: the tangent vectors come from the pixels `step` to either side (1: plain central differences)
 __global__ __launch_bounds__(256) void normals_kernel(Cam cam, const float *__restrict__ depth, float sc, float mind,
-                                                      float maxd, float jump, float4 *__restrict__ nmap) {
+                                                      float maxd, float jump, int step, float4 *__restrict__ nmap) {
     const int u = blockIdx.x * 64 + (threadIdx.x & 63);
     const int v = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (u >= cam.W || v >= cam.H) return;
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
     float p[3], l[3], r[3], up[3], dn[3];
-    bool ok = (u >= 1 && v >= 1 && u <= cam.W - 2 && v <= cam.H - 2);
+    bool ok = (u >= step && v >= step && u <= cam.W - 1 - step && v <= cam.H - 1 - step);
     ok = ok && load_vertex(cam, depth, u, v, sc, mind, maxd, p);
-    ok = ok && load_vertex(cam, depth, u - 1, v, sc, mind, maxd, l);
-    ok = ok && load_vertex(cam, depth, u + 1, v, sc, mind, maxd, r);
-    ok = ok && load_vertex(cam, depth, u, v - 1, sc, mind, maxd, up);
-    ok = ok && load_vertex(cam, depth, u, v + 1, sc, mind, maxd, dn);
+    ok = ok && load_vertex(cam, depth, u - step, v, sc, mind, maxd, l);
+    ok = ok && load_vertex(cam, depth, u + step, v, sc, mind, maxd, r);
+    ok = ok && load_vertex(cam, depth, u, v - step, sc, mind, maxd, up);
+    ok = ok && load_vertex(cam, depth, u, v + step, sc, mind, maxd, dn);
     if (ok) {
         ok = fabsf(l[2] - p[2]) <= jump && fabsf(r[2] - p[2]) <= jump && fabsf(up[2] - p[2]) <= jump &&
              fabsf(dn[2] - p[2]) <= jump;
@@ -841,10 +875,18 @@ int launch_icp_batch(hipStream_t s, const Cam &cam, const IcpBatchArgs &a) {
     return TL3D_OK;
 }
 
-int launch_normals(hipStream_t s, const Cam &cam, const float *depth, float scale, float mind, float maxd, float jump,
+// radius 0: central differences of the depth image itself; radius >= 1: the window-averaged depth goes to `sdepth` first and the
+// normals come from it with a `radius`-pixel step
+int launch_normals(hipStream_t s, const Cam &cam, const float *depth, float scale, float mind, float maxd, float jump, int radius, float *sdepth,
                    float4 *nmap) {
     dim3 grid((cam.W + 63) / 64, (cam.H + 3) / 4);
-    hipLaunchKernelGGL(normals_kernel, grid, dim3(256), 0, s, cam, depth, scale, mind, maxd, jump, nmap);
+    if (radius >= 1) {
+        hipLaunchKernelGGL(smooth_depth_kernel, grid, dim3(256), 0, s, cam, depth, scale, mind, maxd, jump, radius, sdepth);
+        TL3D_HIP(hipGetLastError());
+        hipLaunchKernelGGL(normals_kernel, grid, dim3(256), 0, s, cam, sdepth, scale, mind, maxd, jump, radius, nmap);
+    } else {
+        hipLaunchKernelGGL(normals_kernel, grid, dim3(256), 0, s, cam, depth, scale, mind, maxd, jump, 1, nmap);
+    }
     TL3D_HIP(hipGetLastError());
     return TL3D_OK;
 }

@@ -413,9 +413,9 @@ int tl3d_create(const tl3d_config *cfg, int device, tl3d_ctx **out) {
     if (!ctx->slots) { delete ctx; return set_err(TL3D_E_NOMEM, "host allocation failed"); }
     {
         const size_t npx = (size_t)cfg->width * cfg->height;
-        const size_t bytes[4] = {npx * sizeof(float), npx * sizeof(uint16_t), npx * 3, npx * sizeof(float4)};
-        FramePool *pools[4] = {&ctx->pool_depth, &ctx->pool_u16, &ctx->pool_bgr, &ctx->pool_nmap};
-        for (int k = 0; k < 4; ++k) {
+        const size_t bytes[5] = {npx * sizeof(float), npx * sizeof(uint16_t), npx * 3, npx * sizeof(float4), npx * sizeof(float)};
+        FramePool *pools[5] = {&ctx->pool_depth, &ctx->pool_u16, &ctx->pool_bgr, &ctx->pool_nmap, &ctx->pool_sdepth};
+        for (int k = 0; k < 5; ++k) {
             FramePool &fp = *pools[k];
             fp.block = (bytes[k] + 16 + 255) & ~(size_t)255;      // 16 B of slack: a pixel's 3 colour bytes are read as one 4-byte word
             fp.remaining = cfg->n_slots;
@@ -508,6 +508,7 @@ int tl3d_destroy(tl3d_ctx *ctx) {
     pool_release(ctx->pool_u16);
     pool_release(ctx->pool_bgr);
     pool_release(ctx->pool_nmap);
+    pool_release(ctx->pool_sdepth);
     if (ctx->brick_tabs) (void)hipFree(ctx->brick_tabs);
     if (ctx->own_tsdf && ctx->tsdf) (void)hipFree(ctx->tsdf);
     if (ctx->own_centroid && ctx->centroid) (void)hipFree(ctx->centroid);
@@ -612,6 +613,7 @@ static int upload_impl(tl3d_ctx *ctx, int slot, const void *depth_hd, int depth_
     }
     s.loaded = true;
     s.has_normals = false;
+    s.smooth_radius = 0;                                 // (the averaged depth belongs to the previous frame of this slot)
     if (!s.ev_upload) TL3D_HIP(hipEventCreateWithFlags(&s.ev_upload, hipEventDisableTiming));
     TL3D_HIP(hipEventRecord(s.ev_upload, ctx->stream));       // the prep stream waits on this, not on the whole main stream
     // pageable host sources are consumed before hipMemcpyAsync returns only for small copies; make the hand-over explicit
@@ -1069,9 +1071,16 @@ int tl3d_build_normals(tl3d_ctx *ctx, int slot, double scale, double depth_jump)
     if (!s.nmap && !(s.nmap = (float4 *)pool_take(ctx->pool_nmap))) return set_err(TL3D_E_NOMEM, "normal map alloc failed");
     rc = order_after_lanes(ctx, slot, false, true);     // an uncollected ICP run may still read this slot's normal map
     if (rc) return rc;
+    const int radius = ctx->normal_radius;
+    if (radius > 0 && !s.sdepth && !(s.sdepth = (float *)pool_take(ctx->pool_sdepth))) return set_err(TL3D_E_NOMEM, "smoothed depth alloc failed");
+    if (radius > 0 || s.smooth_radius > 0) {
+        rc = order_after_lanes(ctx, slot, true, false);  // ... or this slot's (smoothed) depth as its source
+        if (rc) return rc;
+    }
     rc = launch_normals(ctx->stream, ctx->cam, s.depth, (float)scale, (float)ctx->cfg.min_depth, (float)ctx->cfg.max_depth,
-                        (float)depth_jump, s.nmap);
+                        (float)depth_jump, radius, s.sdepth, s.nmap);
     if (rc) return rc;
+    s.smooth_radius = radius;
     s.has_normals = true;
     if (!s.ev_normals) TL3D_HIP(hipEventCreateWithFlags(&s.ev_normals, hipEventDisableTiming));
     TL3D_HIP(hipEventRecord(s.ev_normals, ctx->stream));      // ICP lanes wait on this, not on the whole main stream
@@ -1166,7 +1175,7 @@ int tl3d_icp_enqueue(tl3d_ctx *ctx, int lane, int slot_src, double scale_src, in
         h->T[0] = h->T[5] = h->T[10] = h->T[15] = 1.0;
     }
     IcpRun *r = ln.run_host;
-    r->depth_src = ss.depth;
+    r->depth_src = ss.smooth_radius > 0 ? ss.sdepth : ss.depth;      // the window-averaged depth when the slot's normals were built smoothed
     r->nmap_tgt = st.nmap;
     r->scale = (float)scale_src;
     r->md2 = (float)prm->max_dist * (float)prm->max_dist;
@@ -1389,7 +1398,7 @@ int tl3d_icp_batch_enqueue(tl3d_ctx *ctx, const tl3d_icp_pair *pairs, int n_pair
     b.req_n_levels = n_levels;
     for (int i = 0; i < n_pairs; ++i) {
         const Slot &ss = ctx->slots[pairs[i].slot_src], &st = ctx->slots[pairs[i].slot_tgt];
-        b.pairs_host[i].depth_src = ss.depth;
+        b.pairs_host[i].depth_src = ss.smooth_radius > 0 ? ss.sdepth : ss.depth;
         b.pairs_host[i].nmap_tgt = st.nmap;
         b.pairs_host[i].scale = (float)pairs[i].scale_src;
         b.pairs_host[i].pad = 0;
@@ -1996,6 +2005,13 @@ int tl3d_set_profile(tl3d_ctx *ctx, int count_records, int time_kernels) {
     FLUSH_UPDATES(ctx);
     ctx->count_records = count_records != 0;
     ctx->time_kernels = time_kernels != 0;
+    return TL3D_OK;
+}
+
+int tl3d_set_normal_smoothing(tl3d_ctx *ctx, int radius) {
+    REQUIRE(ctx != nullptr, TL3D_E_INVALID, "null ctx");
+    REQUIRE(radius >= 0 && radius <= 8, TL3D_E_INVALID, "smoothing radius %d out of range [0, 8]", radius);
+    ctx->normal_radius = radius;
     return TL3D_OK;
 }
 

@@ -111,6 +111,8 @@ struct Slot {
     bool has_u16 = false;
     uint8_t *bgr = nullptr;      // [H][W][3]
     float4 *nmap = nullptr;      // [H][W] (nx,ny,nz,d), lazily allocated
+    float *sdepth = nullptr;     // [H][W] window-averaged depth the normal map was taken from (tl3d_set_normal_smoothing > 0); registration reads it as the source depth too
+    int smooth_radius = 0;       // radius sdepth / nmap were built with (0: nmap from the depth image itself)
     hipEvent_t ev_upload = nullptr;   // recorded on the main stream after the slot's last upload
     hipEvent_t ev_normals = nullptr;  // recorded on the main stream after the slot's normal map was built
     bool has_color = false;
@@ -137,7 +139,8 @@ struct tl3d_ctx {
     tl3d::Grid grid;
     size_t nvox;
     tl3d::Slot *slots;
-    tl3d::FramePool pool_depth, pool_u16, pool_bgr, pool_nmap;
+    tl3d::FramePool pool_depth, pool_u16, pool_bgr, pool_nmap, pool_sdepth;
+    int normal_radius;           // tl3d_set_normal_smoothing: window radius of the next normal maps (0: none)
     int2 *tsdf;                  // record pool of the TSDF channel: [tsdf_cap bricks][512] {sum_q, weight}; a dense grid's pool is the grid
     unsigned long long *centroid;// record pool of the centroid channel: [cen_cap bricks][512][4]
     bool own_tsdf, own_centroid;
@@ -357,7 +360,8 @@ int launch_tsdf_update(hipStream_t s, const Cam &cam, const Grid &g, int n, int 
                        unsigned long long *counters, bool count, int max_blocks, int xcd_group);
 int launch_fold_free(hipStream_t s, const Grid &g, int2 *grid, unsigned *free_cnt);
 // normals + icp
-int launch_normals(hipStream_t s, const Cam &cam, const float *depth, float scale, float mind, float maxd, float jump, float4 *nmap);
+int launch_normals(hipStream_t s, const Cam &cam, const float *depth, float scale, float mind, float maxd, float jump, int radius, float *sdepth,
+                   float4 *nmap);
 int launch_icp_batch(hipStream_t s, const Cam &cam, const IcpBatchArgs &a);
 int launch_icp_iteration(hipStream_t s, const Cam &cam, const IcpRun *run, int final_pass, double *slab, IcpState *state, int nblocks,
                          unsigned *ticket);

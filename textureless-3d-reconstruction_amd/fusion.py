@@ -297,6 +297,11 @@ class FusionContext:
         sc = None if scales is None else np.ascontiguousarray(np.asarray(scales, np.float64))
         abi.check(self._lib.tl3d_build_normals_many(self._h, n, abi.ptr(sl), None if sc is None else abi.ptr(sc), float(depth_jump)))
 
+    def set_normal_smoothing(self, radius: int):
+        """Normal maps built from now on use the window-averaged depth (radius 1 = 3 x 3), and registrations read it as their
+        source depth: robust to depth noise (tl3d.h: tl3d_set_normal_smoothing); 0 = off."""
+        abi.check(self._lib.tl3d_set_normal_smoothing(self._h, int(radius)))
+
     def build_normals(self, slot: int, scale=1.0, depth_jump=0.05):
         abi.check(self._lib.tl3d_build_normals(self._h, int(slot), float(scale), float(depth_jump)))
 

@@ -338,6 +338,7 @@ class DepthToReconstructionPipeline:
         clock, marks = time.perf_counter, [("start", time.perf_counter())]
         ctx = FusionContext(w, h, cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.min_depth, cfg.max_depth, n_slots=n, grid=None,
                             device=cfg.device)
+        ctx.set_normal_smoothing(int(getattr(cfg, "icp_smooth_radius", 0)))
         try:
             if streaming:
                 pre = fileio.FramePrefetcher(ctx, [f for f, _ in self._files], [d for _, d in self._files])
@@ -485,6 +486,7 @@ class DepthToReconstructionPipeline:
         spare = len(resident)                                       # one more slot for out-of-range sources of repairs
         ctx = FusionContext(w, h, cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.min_depth, cfg.max_depth, n_slots=len(resident) + 1, grid=None,
                             device=cfg.device)
+        ctx.set_normal_smoothing(int(getattr(cfg, "icp_smooth_radius", 0)))
         try:
             for g in resident:
                 ctx.upload(slot_of[g], self.depths[g], self.images[g])
