@@ -44,8 +44,13 @@ class DepthImageLoader:
                         arr = np.array(im)
             except Exception:
                 return None
-            if arr.ndim == 3:                       # cv2.IMREAD_ANYDEPTH yields one channel
-                arr = arr[..., 0]
+            if arr.ndim == 3:
+                # cv2.imread(path, IMREAD_ANYDEPTH) (D2R:87) has no ANYCOLOR flag: a colour PNG comes back as ONE gray channel,
+                # 0.299 R + 0.587 G + 0.114 B (alpha dropped) at the file's bit depth.  Restated, not pinned (no cv2 here): libpng
+                # does that sum in fixed point, so a value may differ by 1 from this rounding.
+                rgb = arr[..., :3].astype(np.float64)
+                gray = np.rint(0.299 * rgb[..., 0] + 0.587 * rgb[..., 1] + 0.114 * rgb[..., 2])
+                arr = gray.astype(arr.dtype)
             if raw_u16 and arr.dtype == np.uint16:
                 return arr
             return arr.astype(np.float32) / 1000.0
@@ -151,6 +156,12 @@ def _pil_row_pointers(im, width: int, height: int, pixelsize: int):
     tobytes().  What it buys: the pixels never pass through a Python bytes object under the interpreter lock."""
     import ctypes
     try:
+        import PIL
+        # The struct is private to Pillow: only the releases whose layout was checked (12.x: mode id, type, depth, bands, xsize,
+        # ysize as ints 0..5; pixelsize / linesize as ints 18, 19; row pointers at byte 48) take the fast path, every other
+        # release decodes through tobytes().
+        if not PIL.__version__.startswith("12."):
+            return None
         cap = im.getim()
         api = ctypes.pythonapi
         api.PyCapsule_GetName.restype, api.PyCapsule_GetName.argtypes = ctypes.c_char_p, [ctypes.py_object]
@@ -162,8 +173,8 @@ def _pil_row_pointers(im, width: int, height: int, pixelsize: int):
         if not base:
             return None
         ints = (ctypes.c_int32 * 20).from_address(base)
-        xs, ys, px, ls = ints[4], ints[5], ints[18], ints[19]
-        if (xs, ys, px, ls) != (width, height, pixelsize, width * pixelsize):
+        bands, xs, ys, px, ls = ints[3], ints[4], ints[5], ints[18], ints[19]
+        if (xs, ys, px, ls) != (width, height, pixelsize, width * pixelsize) or bands != len(im.getbands()):
             return None
         rows = ctypes.c_void_p.from_address(base + 48).value
         return rows or None

@@ -1,123 +1,37 @@
-"""Summarise rocprofv3 csv output (kernel stats + PMC per tl3d kernel); emit pmc_traffic.json for bench.py."""
-import csv
-import glob
+"""pmc_traffic.json for bench.py from the --pmc passes of tools/pmc_quick.sh:  python3 tools/prof_summary.py <out dir> <pmc dir>.
+
+traffic = (FETCH_SIZE + WRITE_SIZE) x 1024 per dispatch of tsdf_update_kernel, at face value: the kernel has no 16-B-per-lane
+streaming reads (the case in which gfx950's FETCH_SIZE reports half the bytes); its 8-B-per-lane record runs and 4-B gathers are
+calibrated on known byte counts by tools/ubench_fetch.hip (pmc_calibration.txt beside this file)."""
 import json
 import os
+import re
 import sys
-from collections import defaultdict
 
-out = sys.argv[1]
-
-
-def rows(pattern):
-    for f in glob.glob(os.path.join(out, pattern), recursive=True):
-        with open(f) as fh:
-            for r in csv.DictReader(fh):
-                yield r
-
-
-print("== kernel stats (tl3d kernels + top 3 others), rocprofv3 --kernel-trace --stats ==")
-n = 0
-stats_rows = []
-for r in rows("trace/**/*kernel_stats.csv"):
-    keep = "tl3d" in r.get("Name", "") or n < 3
-    if keep:
-        stats_rows.append(r)
-        print(f"{r.get('Name','')[:72]:72s} calls={r.get('Calls'):>6s} avg_ns={float(r.get('AverageNs',0)):11.1f} "
-              f"min={r.get('MinNs')} max={r.get('MaxNs')} pct={r.get('Percentage')}")
-    n += 1
-for f in glob.glob(os.path.join(out, "bench_trace.log")):
-    for line in open(f):
-        if line.startswith("{"):
-            print("== bench line of the traced run ==")
-            print(line.strip())
-
-print("== kernel stats of the per-row run (registration in the loop, centroid channel, back-projection, extraction, filter) ==")
-for r in rows("trace_rows/**/*kernel_stats.csv"):
-    if "tl3d" in r.get("Name", ""):
-        print(f"{r.get('Name','')[:72]:72s} calls={r.get('Calls'):>6s} avg_ns={float(r.get('AverageNs',0)):11.1f} "
-              f"min={r.get('MinNs')} max={r.get('MaxNs')} pct={r.get('Percentage')}")
-for f in glob.glob(os.path.join(out, "bench_trace_rows.log")):
-    for line in open(f):
-        if line.startswith("{"):
-            print("== rows of that run ==")
-            print(json.dumps(json.loads(line).get("rows")))
-
-agg = defaultdict(lambda: defaultdict(float))
-cnt = defaultdict(lambda: defaultdict(int))
-for r in rows("pmc_*/**/*counter_collection.csv"):
-    k = r.get("Kernel_Name", "")
-    if "tl3d" not in k:
+out, pmc = sys.argv[1], sys.argv[2]
+vals = {}
+cur = None
+for line in open(os.path.join(pmc, "summary.txt")):
+    if not line.startswith(" "):
+        cur = line.strip()
         continue
-    k = k.split("(")[0].replace("void ", "")
-    c = r.get("Counter_Name")
-    agg[k][c] += float(r.get("Counter_Value", 0))
-    cnt[k][c] += 1
-print("== PMC, mean per dispatch (separate --pmc passes) ==")
-for k in sorted(agg):
-    print(k)
-    for c in sorted(agg[k]):
-        print(f"    {c:36s} {agg[k][c] / max(1, cnt[k][c]):18.1f}  (n={cnt[k][c]})")
-
-def mean_of(pattern, counter, kernel_tag):
-    tot, n = 0.0, 0
-    for r in rows(pattern):
-        if kernel_tag in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter:
-            tot += float(r.get("Counter_Value", 0))
-            n += 1
-    return tot / n if n else None
-
-
-def bench_json(name):
-    for f in glob.glob(os.path.join(out, name)):
-        for line in open(f):
-            if line.startswith("{"):
-                return json.loads(line)
-    return None
-
-
-key = [k for k in agg if "tsdf_pair_kernel<false" in k]                                                   # production: two overlapping frames per launch
-if not key:
-    key = [k for k in agg if "tsdf_integrate_kernel<false, 0" in k and k.rstrip(">").endswith("false")]  # one frame per launch, free space counted (any lane map)
-if key and "FETCH_SIZE" in agg[key[0]] and "WRITE_SIZE" in agg[key[0]]:
-    k = key[0]
-    fetch_kb = agg[k]["FETCH_SIZE"] / cnt[k]["FETCH_SIZE"]
-    write_kb = agg[k]["WRITE_SIZE"] / cnt[k]["WRITE_SIZE"]
-    b1 = bench_json("bench_pmc1.log")
-    alg = b1["roofline"]["bytes_per_launch"] if b1 else None
-    counted = bool(b1 and b1["roofline"].get("free_space_bricks_counted_per_launch", 0) > 0)
-    # Calibration of FETCH_SIZE on THIS kernel's access patterns (the guide: FETCH_SIZE reports exactly half the bytes of
-    # 16-B-per-lane streaming reads on gfx950; other widths must be calibrated on a known byte count):
-    #   variant 2 reads all 512 records of every listed brick with 8-B-per-lane loads -> known bytes = 4096 x listed bricks
-    cal = None
-    f_v2 = mean_of("cal_v2/**/*counter_collection.csv", "FETCH_SIZE", "tsdf_integrate_kernel<false, 0")
-    b_v2 = bench_json("bench_cal_v2.log")
-    if f_v2 and b_v2:
-        r2 = b_v2["roofline"]
-        listed = r2["bricks_visited_per_launch"] - r2["free_space_bricks_counted_per_launch"]
-        known = 4096.0 * listed                                  # record bytes read; the depth image (mostly cache hits) comes on top
-        cal = {"variant2_fetch_size_kb": round(f_v2, 1), "variant2_known_record_bytes_read": int(known),
-               "factor_8B_per_lane_reads": round(f_v2 * 1024.0 / known, 3)}
-    traffic = (fetch_kb + write_kb) * 1024.0                      # 8-B-per-lane loads, 4-B gathers and stores at face value (factor above ~1.0)
-    j = {"grid": 512, "width": 1080, "height": 1920, "depth_format": "f32", "free_space_counters": counted,
-         "kernel": k.split("<")[0].replace("tl3d::", ""), "frames_per_sweep": int(round(b1["roofline"].get("frames_per_sweep", 1))) if b1 else 1, "fetch_size_kb": round(fetch_kb, 1), "write_size_kb": round(write_kb, 1),
-         "hbm_bytes_per_launch": int(traffic), "algorithmic_bytes_per_launch": alg, "calibration": cal,
-         "note": "traffic = (FETCH_SIZE + WRITE_SIZE) * 1024 from separate --pmc passes.  The guide's gfx950 correction (FETCH_SIZE "
-                 "reports half the bytes of 16-B-per-lane streaming reads) does not apply to this kernel since free-space bricks are "
-                 "counted instead of streamed: its reads are 8-B-per-lane predicated loads and 4-B gathers, calibrated at face value "
-                 "on a known byte count (calibration.factor_8B_per_lane_reads)."}
-    # the round-1 formulation (free-space bricks streamed), for the second roofline object of bench.py
-    f_s = mean_of("str_1/**/*counter_collection.csv", "FETCH_SIZE", "tsdf_integrate_kernel<false, 0")
-    w_s = mean_of("str_2/**/*counter_collection.csv", "WRITE_SIZE", "tsdf_integrate_kernel<false, 0")
-    f_free = mean_of("str_free/**/*counter_collection.csv", "FETCH_SIZE", "tsdf_integrate_kernel<false, 2")
-    b_s = bench_json("bench_str1.log")
-    if f_s and w_s and f_free and b_s:
-        j["free_space_streamed"] = {"fetch_size_kb": round(f_s, 1), "fetch_size_free_bricks_only_kb": round(f_free, 1), "write_size_kb": round(w_s, 1),
-                                    "hbm_bytes_per_launch": int((f_s + f_free + w_s) * 1024.0),
-                                    "algorithmic_bytes_per_launch": b_s["roofline"]["bytes_per_launch"],
-                                    "note": "FETCH_SIZE + one more copy of what the free-space bricks alone fetch (16 B per lane: reported at "
-                                            "half their bytes) + WRITE_SIZE"}
-    with open(os.path.join(out, "pmc_traffic.json"), "w") as f:
-        json.dump(j, f, indent=1)
-    print("== traffic ==")
+    m = re.match(r"\s+(\S+)\s+mean\s+([0-9.]+)", line)
+    if m and cur and "tsdf_update_kernel<false" in cur:
+        vals[m.group(1)] = float(m.group(2))
+bench = None
+for line in open(os.path.join(pmc, "bench1.log")):
+    if line.startswith("{"):
+        bench = json.loads(line)
+if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals and bench:
+    r = bench["roofline"]
+    j = {"grid": bench["config"]["grid"], "width": 1080, "height": 1920, "depth_format": bench["config"]["depth_format"], "free_space_counters": True,
+         "kernel": "tsdf_update_kernel", "frames_per_sweep": int(round(r["frames_per_sweep"])), "fetch_size_kb": round(vals["FETCH_SIZE"], 1),
+         "write_size_kb": round(vals["WRITE_SIZE"], 1), "hbm_bytes_per_launch": int((vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0),
+         "algorithmic_bytes_per_launch": r["bytes_per_launch"],
+         "l2_hit_rate": round(vals["TCC_HIT_sum"] / (vals["TCC_HIT_sum"] + vals["TCC_MISS_sum"]), 3) if "TCC_HIT_sum" in vals else None,
+         "note": "(FETCH_SIZE + WRITE_SIZE) x 1024 per dispatch from separate --pmc passes, at face value (no 16-B-per-lane streaming reads "
+                 "in this kernel; calibration of its access widths: pmc_calibration.txt)"}
+    json.dump(j, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
     print(json.dumps(j))
+else:
+    print("no traffic figures found", vals.keys())
