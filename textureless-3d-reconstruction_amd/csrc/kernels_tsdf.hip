@@ -65,6 +65,7 @@ struct FrameDesc {
     unsigned *list;                      // its listed (MIXED) bricks, for the sub-brick classification
     unsigned *counts;                    // [0] listed bricks, [1] free-space bricks (counted)
     unsigned short *sub;                 // [nbricks] sub-brick masks of its listed bricks: bits 0-7 mixed, bits 8-15 free
+    float2 *vtile;                       // level-0 tiles once more, 8 B each, as the update kernel's per-voxel test wants them (below)
 };
 
 // what all frames of a batch share
@@ -131,6 +132,7 @@ __global__ __launch_bounds__(256) void depth_tiles_kernel(Cam cam, BatchBufs B, 
     const TsdfConst c = desc_const(F);
     const DT *__restrict__ depth = static_cast<const DT *>(F->depth);
     float4 *__restrict__ tiles = F->tiles;
+    float2 *__restrict__ vtile = F->vtile;
     __shared__ float s_mn[4][4], s_mx[4][4];
     __shared__ int s_bad[4][4];
     if (blockIdx.x == 0 && threadIdx.x < 2) F->counts[threadIdx.x] = 0u;        // reset the frame's list cursors
@@ -140,19 +142,31 @@ __global__ __launch_bounds__(256) void depth_tiles_kernel(Cam cam, BatchBufs B, 
     }
     const int q4 = threadIdx.x & 7, row = threadIdx.x >> 3, wid = threadIdx.x >> 6;
     const bool vec = (cam.W & 3) == 0;                              // rows are 16-B aligned
+    // the thread's four pixels of a region; the next region's are requested before this one's are looked at
+    auto fetch = [&](int region, float dd[4]) {
+        const int rx = region % nrx, ry = region / nrx;
+        const int u0 = rx * REGION + q4 * 4, v = ry * REGION + row;
+        dd[0] = dd[1] = dd[2] = dd[3] = 0.0f;
+        if (region < nrx * nry && v < cam.H && u0 < cam.W) {
+            if (vec) {
+                ld_depth4(depth, (size_t)v * cam.W + u0, dd);
+            } else {
+                const int nv = min(4, cam.W - u0);
+                for (int k = 0; k < 4; ++k) dd[k] = (k < nv) ? ld_depth(depth, (size_t)v * cam.W + u0 + k) : 0.0f;
+            }
+        }
+    };
+    float dn[4];
+    fetch(blockIdx.x, dn);
     for (int region = blockIdx.x; region < nrx * nry; region += gridDim.x) {
         const int rx = region % nrx, ry = region / nrx;
         float mn = INFINITY, mx = -INFINITY;
         int bad = 0;
         const int u0 = rx * REGION + q4 * 4, v = ry * REGION + row;
+        float dd[4] = {dn[0], dn[1], dn[2], dn[3]};
+        fetch(region + (int)gridDim.x, dn);
         if (v < cam.H && u0 < cam.W) {
-            float dd[4];
-            int nv = min(4, cam.W - u0);
-            if (vec) {
-                ld_depth4(depth, (size_t)v * cam.W + u0, dd);
-            } else {
-                for (int k = 0; k < 4; ++k) dd[k] = (k < nv) ? ld_depth(depth, (size_t)v * cam.W + u0 + k) : 0.0f;
-            }
+            const int nv = min(4, cam.W - u0);
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (k < nv) {
@@ -176,7 +190,11 @@ __global__ __launch_bounds__(256) void depth_tiles_kernel(Cam cam, BatchBufs B, 
         if ((lane & 0x39) == 0) {                                   // lanes 0, 2, 4, 6: one per level-0 tile of this wave
             const int ax = lane >> 1;
             const int tx = rx * 4 + ax, ty = ry * 4 + wid;
-            if (tx < py.ntx[0] && ty < py.nty[0]) tiles[py.off[0] + ty * py.ntx[0] + tx] = make_float4(mn, mx, bad ? 0.0f : 1.0f, 0.0f);
+            if (tx < py.ntx[0] && ty < py.nty[0]) {
+                tiles[py.off[0] + ty * py.ntx[0] + tx] = make_float4(mn, mx, bad ? 0.0f : 1.0f, 0.0f);
+                // (lowest depth if EVERY pixel is valid, else -inf: "never surely free"; highest valid depth, -inf if none: "skip")
+                vtile[ty * py.ntx[0] + tx] = make_float2(bad ? -INFINITY : mn, mx);
+            }
             s_mn[wid][ax] = mn; s_mx[wid][ax] = mx; s_bad[wid][ax] = bad;
         }
         __syncthreads();
@@ -201,8 +219,27 @@ __global__ __launch_bounds__(256) void depth_tiles_kernel(Cam cam, BatchBufs B, 
 }
 
 // ---- 2. pyramid: levels 3 .. from level 2 ------------------------------------------------------------------
-__global__ __launch_bounds__(256) void tile_pyramid_kernel(Pyramid py, BatchBufs B) {
+// Also finds ONE PIXEL OF THE FRAME THAT IS VALID (the top-left pixel of an all-valid tile; counts[VALID_PIXEL]): where the update
+// kernel sends the lanes whose depth value cannot matter (below).
+constexpr int VALID_PIXEL = 32;          // word of a frame's counts block
+__global__ __launch_bounds__(256) void tile_pyramid_kernel(Cam cam, Pyramid py, BatchBufs B) {
     float4 *__restrict__ tiles = const_descs(B)[blockIdx.x].tiles;
+    __shared__ unsigned s_found;
+    if (threadIdx.x == 0) s_found = 0xffffffffu;
+    __syncthreads();
+    for (int L = min(2, py.nlev - 1); L >= 0; L -= 2) {           // 32-pixel tiles first; only a frame full of holes needs the 8-pixel ones
+        const int n = py.ntx[L] * py.nty[L];
+        for (int i = threadIdx.x; i < n; i += 256)
+            if (tiles[py.off[L] + i].z > 0.5f) {
+                const unsigned x = (unsigned)(i % py.ntx[L]) << (TILE0_SHIFT + L), y = (unsigned)(i / py.ntx[L]) << (TILE0_SHIFT + L);
+                atomicMin(&s_found, y * (unsigned)cam.W + x);
+                break;
+            }
+        __syncthreads();
+        if (s_found != 0xffffffffu) break;                        // (uniform: read after the barrier)
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) const_descs(B)[blockIdx.x].counts[VALID_PIXEL] = s_found == 0xffffffffu ? 0u : s_found;
     for (int L = 3; L < py.nlev; ++L) {
         const int n = py.ntx[L] * py.nty[L];
         const float4 *__restrict__ src = tiles + py.off[L - 1];
@@ -390,7 +427,12 @@ __global__ __launch_bounds__(256) void fold_free_kernel(Grid g, int2 *__restrict
 // Per-voxel rule, split in two so that a wave can issue all its depth gathers before it needs any of them.
 // project(): camera-space voxel centre -> clamped pixel address + "could update" flag (no memory access).
 // finish():  depth value -> quantised tsdf + final flag.  Together they are exactly orc_tsdf_integrate's sequence.
-__device__ __forceinline__ bool tsdf_project(const Cam &cam, const TsdfConst &c, float xc, float yc, float zc, int &pix) {
+__device__ __forceinline__ unsigned mad_u24(unsigned a, unsigned b_uniform, unsigned c) {
+    unsigned r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_uniform), "v"(c));
+    return r;
+}
+__device__ __forceinline__ bool tsdf_project(const Cam &cam, const TsdfConst &c, float xc, float yc, float zc, int ntx0, int pix_bytes, unsigned &pix, unsigned &tix) {
     bool ok = zc > 0.0f;
     // 1 / zc.  v_rcp_f32 + one Newton step equals the IEEE quotient for EVERY float with 2^-126 <= zc < 2^126 (exhaustive:
     // tools/ubench_rcp.hip, profiles/r03_ubench_rcp.txt); the division proper (~10 instructions) runs only for lanes outside
@@ -404,13 +446,19 @@ __device__ __forceinline__ bool tsdf_project(const Cam &cam, const TsdfConst &c,
     int u = (int)floorf(uf + 0.5f), v = (int)floorf(vf + 0.5f);
     u = min(max(u, 0), cam.W - 1);          // always a legal address, so the gather needs no branch
     v = min(max(v, 0), cam.H - 1);
-    pix = v * cam.W + u;
+    // (u, v, W < 2^16: 24-bit multiplies are exact and full rate)
+    // BYTE offsets of the pixel in the image and of the 8-B record of the 8x8-pixel tile that holds it
+    // (v_mad_u32_u24 spelled out: every operand is below 2^24, the instruction is full rate, and the optimiser, left to
+    // itself, folds these into 64-bit multiply-adds of the address; as opaque 32-bit values they become the 32-bit offset of a
+    // load from a wave-uniform base)
+    pix = mad_u24((unsigned)v, (unsigned)(cam.W * pix_bytes), (unsigned)u * (unsigned)pix_bytes);
+    tix = mad_u24((unsigned)v >> TILE0_SHIFT, (unsigned)ntx0 << 3, (unsigned)u & ~7u);
     return ok;
 }
 
-__device__ __forceinline__ bool tsdf_finish(const Grid &g, const TsdfConst &c, bool ok, float draw, float zc, int &q) {
-    const float d = draw * c.sc;
-    ok = ok && (d > c.mind && d < c.maxd);
+__device__ __forceinline__ bool tsdf_finish(const Grid &g, float sc, float mind, float maxd, float draw, float zc, int &q) {
+    const float d = draw * sc;
+    bool ok = d > mind && d < maxd;
     const float sdf = d - zc;
     ok = ok && (sdf >= -g.trunc);
     const float tsdf = fminf(1.0f, sdf * g.inv_trunc);
@@ -516,26 +564,48 @@ __global__ __launch_bounds__(256) void subbrick_classify_kernel(Cam cam, Grid g,
 
 // ---- 5. the update: one launch per batch ---------------------------------------------------------------------------------
 // A wave takes one brick of the batch list per trip.  For every frame whose bit is set in the brick's frame mask it projects the
-// lane's voxel of each MIXED sub-brick, gathers the depth values (all gathers of a frame back to back) and adds the quantised
-// tsdf to the lane's eight running sums; FREE sub-bricks add (32767, 1).  The frame loop is software-pipelined two deep: the
-// gathers of the next frame are in flight while the current frame's values are turned into increments.  After the last frame
-// the records that changed are read, added to and written: once per batch, whatever the number of frames.
-// EXP (experiments flavour of the library only; results incomplete): bit 0 no depth gathers, bit 1 no record accesses.
+// lane's voxel of each MIXED sub-brick and adds the quantised tsdf to the lane's eight running sums; FREE sub-bricks add
+// (32767, 1).  After the last frame the records that changed are read, added to and written: once per batch, whatever the
+// number of frames.
+//
+// What bounds this kernel is the RATE OF SCATTERED DEPTH READS the memory system sustains (56 G 64-B requests per second that
+// miss the L2, whatever the occupancy: tools/ubench_gather.hip), so a voxel asks for its depth pixel only when the answer is
+// open.  Per voxel and frame, in three pipelined stages:
+//   A  project (the oracle's sequence) -> pixel, and load the 8-B record of the 8x8-PIXEL TILE that holds the pixel
+//      (lowest depth if all 64 pixels are valid, highest valid depth; 260 KB per frame: these loads hit the L2);
+//   B  the tile decides most voxels: highest - zc < -trunc  => sdf < -trunc whatever the pixel says: no update;
+//                                    lowest - zc >= 1.001 trunc => tsdf == 1 exactly: (+32767, +1);
+//      (rounding is monotone: d >= lowest => fl(d - zc) >= fl(lowest - zc), so both decisions are the per-voxel rule's own);
+//      only the voxels in between -- a third of the lanes of a MIXED sub-brick -- gather their depth pixel, the others read
+//      pixel 0 (one shared line);
+//   C  depth value -> increment.
+// Stage A of frame k+2, B of k+1 and C of k are issued back to back: every load has a stage or two of arithmetic to hide behind.
+// ALWAYS eight loads per stage, so that the number of loads in flight is known wherever a value is awaited (a count that depended
+// on the masks would turn every wait into "all loads", the newest included).
+// EXP (experiments flavour of the library only; results incomplete): bit 0 no tile / depth loads, bit 1 no record accesses,
+// bit 2 no software pipeline.
 template <typename DT> struct RawDepth { typedef float type; };
 template <> struct RawDepth<uint16_t> { typedef unsigned short type; };
 __device__ __forceinline__ float depth_value(float raw) { return raw; }
 __device__ __forceinline__ float depth_value(unsigned short raw) { return mm_to_m(raw); }
 
 template <typename DT>
-struct GatherState {            // one frame's gathers of one brick, in flight
+struct FrameStage {             // one frame's pass over one brick, in flight
     float zc[8];
-    typename RawDepth<DT>::type dv[8];   // as loaded: nothing touches a value before finish() (the gathers stay in flight)
-    unsigned okm, m, fr;        // lanes' "could update" bits per sub-brick; the frame's MIXED and FREE sub-brick masks (wave-uniform)
-    TsdfConst c;
+    unsigned pix[8];            // A -> B: byte offset of the pixel in the frame's image
+    float2 tl[8];               // A -> B, as loaded
+    typename RawDepth<DT>::type dv[8];   // B -> C, as loaded: nothing touches a value before its stage (the loads stay in flight)
+    unsigned m, fr;             // the frame's MIXED and FREE sub-brick masks of this brick (wave-uniform)
+    unsigned valid_pix;         // byte offset of a pixel of the frame that is valid (wave-uniform)
+    float sc, mind, maxd;       // of the frame (wave-uniform)
+    const char *depth;
 };
 
 template <bool COUNT, typename DT, int EXP = 0>
-__global__ __launch_bounds__(256) void tsdf_update_kernel(Cam cam, Grid g, BatchBufs B, int xcd_group, int2 *__restrict__ grid,
+#ifndef TL3D_UPD_WAVES
+#define TL3D_UPD_WAVES 4
+#endif
+__global__ __launch_bounds__(256, TL3D_UPD_WAVES) void tsdf_update_kernel(Cam cam, Grid g, BatchBufs B, int xcd_group, int2 *__restrict__ grid,
                                                           unsigned long long *__restrict__ counters) {
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // wave-uniform, and known to be
     const unsigned nbricks = (unsigned)(g.nbx * g.nby * g.nbz);
@@ -561,6 +631,8 @@ __global__ __launch_bounds__(256) void tsdf_update_kernel(Cam cam, Grid g, Batch
         return ((k / chunk) * ngrp + grp) * chunk + k % chunk;
     };
     const DescPtr frames = const_descs(B);
+    const int ntx0 = (cam.W + TILE0 - 1) >> TILE0_SHIFT;
+    const float trunc_free = g.trunc * 1.001f;
 
     // the next brick of this wave, its frame mask and (lane f) its sub-brick masks in frame f: fetched one trip ahead
     auto fetch = [&](unsigned t, unsigned &brick, unsigned &fm, unsigned &subv, unsigned &slot) {
@@ -608,17 +680,17 @@ __global__ __launch_bounds__(256) void tsdf_update_kernel(Cam cam, Grid g, Batch
         for (int s = 0; s < 8; ++s) acc[s] = 0u;
         unsigned touched = 0u;                                      // sub-bricks any frame adds to (wave-uniform)
 
-        // project the lane's voxel of every MIXED sub-brick of frame f and issue the depth gathers
-        // -- ALWAYS eight loads, so that the number of loads in flight is known where the previous frame's values are awaited
-        // (a count that depended on the masks would turn every wait into "all loads", the new gathers included); a sub-brick
-        // that is not MIXED loads pixel 0 in every lane: one cache line, one tag look-up per quad
-        auto issue = [&](int f, GatherState<DT> &S) {
+        // stage A: project the lane's voxel of every MIXED sub-brick of frame f, load the tiles of the pixels
+        auto stage_a = [&](int f, FrameStage<DT> &S) {
             const unsigned sm = (unsigned)__builtin_amdgcn_readlane((int)subv, f);
-            S.m = sm & 0xffu; S.fr = sm >> 8; S.okm = 0u;
+            S.m = sm & 0xffu; S.fr = sm >> 8;
             touched |= S.m | S.fr;
             const PoseF pose = desc_pose(frames + f);
-            S.c = desc_const(frames + f);
-            const DT *__restrict__ depth = static_cast<const DT *>(frames[f].depth);
+            const TsdfConst c = desc_const(frames + f);
+            S.sc = c.sc; S.mind = c.mind; S.maxd = c.maxd;
+            S.depth = static_cast<const char *>(frames[f].depth);
+            const char *__restrict__ vt = reinterpret_cast<const char *>(frames[f].vtile);
+            S.valid_pix = ((const unsigned __attribute__((address_space(4))) *)(frames[f].counts))[VALID_PIXEL] * (unsigned)sizeof(DT);
             float ax[2][2], ay[2][2], az[2][2];                    // [z half][y half]: the two inner fma levels of the position chain
 #pragma unroll
             for (int hz = 0; hz < 2; ++hz)
@@ -630,50 +702,73 @@ __global__ __launch_bounds__(256) void tsdf_update_kernel(Cam cam, Grid g, Batch
                 }
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
-                int pix = 0;
-                S.zc[s] = 0.0f;
+                unsigned pix = 0u, tix = 0u;
+                S.zc[s] = INFINITY;
                 if ((S.m >> s) & 1u) {
                     const float xc = fmaf(pose.r[0], wx[s & 1], ax[s >> 2][(s >> 1) & 1]);
                     const float yc = fmaf(pose.r[3], wx[s & 1], ay[s >> 2][(s >> 1) & 1]);
-                    S.zc[s] = fmaf(pose.r[6], wx[s & 1], az[s >> 2][(s >> 1) & 1]);
-                    if (tsdf_project(cam, S.c, xc, yc, S.zc[s], pix)) S.okm |= 1u << s;
+                    const float zc = fmaf(pose.r[6], wx[s & 1], az[s >> 2][(s >> 1) & 1]);
+                    // a voxel that does not project into the image: zc = +inf, "behind everything" for stages B and C
+                    S.zc[s] = tsdf_project(cam, c, xc, yc, zc, ntx0, (int)sizeof(DT), pix, tix) ? zc : INFINITY;
                 }
-                if (EXP & 1) S.dv[s] = (typename RawDepth<DT>::type)(1 + (pix & 1023));
-                else S.dv[s] = depth[pix];
+                S.pix[s] = pix;                                        // (32-bit byte offsets from a wave-uniform base: one address register per load)
+                if (EXP & 1) S.tl[s] = make_float2(-INFINITY, INFINITY);
+                else S.tl[s] = *reinterpret_cast<const float2 *>(vt + tix);
             }
         };
-        // depth values -> increments
-        auto finish = [&](const GatherState<DT> &S) {
+        // stage B: what the tile leaves open gathers its depth pixel.  The decided lanes read the frame's valid pixel (one shared
+        // line) and carry their decision in zc: +inf = behind everything (sdf = -inf: no update), -inf = in front of everything
+        // (sdf = +inf: tsdf = 1 exactly, and the depth read IS valid) -- stage C needs no flags.
+        auto stage_b = [&](FrameStage<DT> &S) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                unsigned pix = S.valid_pix;
+                if ((S.m >> s) & 1u) {
+                    const float zc = S.zc[s];
+                    const bool fre = S.tl[s].x - zc >= trunc_free;
+                    const bool skp = S.tl[s].y - zc < -g.trunc;
+                    S.zc[s] = fre ? -INFINITY : (skp ? INFINITY : zc);
+                    pix = (fre || skp) ? pix : S.pix[s];
+                }
+                if (EXP & 1) S.dv[s] = (typename RawDepth<DT>::type)(1 + (pix & 1023));
+                else S.dv[s] = *reinterpret_cast<const typename RawDepth<DT>::type *>(S.depth + pix);
+            }
+        };
+        // stage C: depth values -> increments
+        auto stage_c = [&](const FrameStage<DT> &S) {
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 if ((S.m >> s) & 1u) {
                     int q;
-                    if (tsdf_finish(g, S.c, (S.okm >> s) & 1u, depth_value(S.dv[s]), S.zc[s], q)) acc[s] += (unsigned)(q + 32768) + (1u << 21);
+                    if (tsdf_finish(g, S.sc, S.mind, S.maxd, depth_value(S.dv[s]), S.zc[s], q)) acc[s] += (unsigned)(q + 32768) + (1u << 21);
                 } else if ((S.fr >> s) & 1u) {
                     acc[s] += 65535u + (1u << 21);
                 }
             }
         };
         if (EXP & 4) {                                          // experiments: one frame at a time, no software pipeline
-            GatherState<DT> S0;
+            FrameStage<DT> S0;
             for (unsigned rest = fm; rest; rest &= rest - 1u) {
-                issue(__builtin_ctz(rest), S0);
-                finish(S0);
+                stage_a(__builtin_ctz(rest), S0);
+                stage_b(S0);
+                stage_c(S0);
             }
-        } else {
-            GatherState<DT> S0, S1;
+        } else if (fm) {
+            // Steady state of a trip: A(k+1) issues its tile loads, C(k) awaits the depth values of frame k (issued a trip ago; the
+            // new tile loads are younger and stay in flight), B(k+1) awaits the tiles and issues the gathers.
+            // The loop body is written out twice so that every stage names its registers.
+            FrameStage<DT> S0, S1;
             unsigned rest = fm;
-            if (rest) {
-                int f = __builtin_ctz(rest);
-                rest &= rest - 1u;
-                issue(f, S0);
-                for (;;) {
-                    if (rest) { f = __builtin_ctz(rest); rest &= rest - 1u; issue(f, S1); } else { finish(S0); break; }
-                    finish(S0);
-                    if (rest) { f = __builtin_ctz(rest); rest &= rest - 1u; issue(f, S0); } else { finish(S1); break; }
-                    finish(S1);
-                }
+#define TL3D_POP(f_) const int f_ = __builtin_ctz(rest); rest &= rest - 1u
+            TL3D_POP(f0);
+            stage_a(f0, S0); stage_b(S0);
+            for (;;) {
+                if (!rest) { stage_c(S0); break; }
+                { TL3D_POP(f); stage_a(f, S1); stage_c(S0); stage_b(S1); }
+                if (!rest) { stage_c(S1); break; }
+                { TL3D_POP(f); stage_a(f, S0); stage_c(S1); stage_b(S0); }
             }
+#undef TL3D_POP
         }
         if (touched == 0u) continue;
         // load the records that change (8 B per lane, a sub-brick = one 512-B run), add, store
@@ -739,9 +834,9 @@ static size_t pyramid_tiles(const Pyramid &p) { return (size_t)p.off[p.nlev - 1]
 static size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // Scratch of ONE batch in flight (the context keeps two and alternates):
-//   [descriptors (max_frames)] [header 256 B] [batch list] [frame masks] then per frame [counts 256 B] [tile pyramid] [list] [sub-brick masks]
+//   [descriptors (max_frames)] [header 256 B] [batch list] [frame masks] then per frame [counts 256 B] [tile pyramid] [list] [sub-brick masks] [8-B level-0 tiles]
 struct BatchLayout {
-    size_t off_desc, off_hdr, off_list, off_mask, off_frames, per_frame, f_counts, f_tiles, f_list, f_sub, total;
+    size_t off_desc, off_hdr, off_list, off_mask, off_frames, per_frame, f_counts, f_tiles, f_list, f_sub, f_vt, total;
 };
 static BatchLayout batch_layout(const Cam &cam, const Grid &g, int max_frames) {
     const Pyramid p = make_pyramid(cam);
@@ -756,7 +851,8 @@ static BatchLayout batch_layout(const Cam &cam, const Grid &g, int max_frames) {
     L.f_tiles = 256;
     L.f_list = L.f_tiles + up256(pyramid_tiles(p) * sizeof(float4));
     L.f_sub = L.f_list + up256((nbricks + 64) * sizeof(unsigned));
-    L.per_frame = L.f_sub + up256(nbricks * sizeof(unsigned short));
+    L.f_vt = L.f_sub + up256(nbricks * sizeof(unsigned short));
+    L.per_frame = L.f_vt + up256((size_t)p.ntx[0] * p.nty[0] * sizeof(float2));
     L.total = L.off_frames + L.per_frame * (size_t)max_frames;
     return L;
 }
@@ -810,6 +906,7 @@ int launch_tsdf_prepare(hipStream_t s, const Cam &cam, const Grid &g, int n, int
         d[i].tiles = reinterpret_cast<float4 *>(fb + L.f_tiles);
         d[i].list = reinterpret_cast<unsigned *>(fb + L.f_list);
         d[i].sub = reinterpret_cast<unsigned short *>(fb + L.f_sub);
+        d[i].vtile = reinterpret_cast<float2 *>(fb + L.f_vt);
     }
     for (int i0 = 0; i0 < n; i0 += 16) {
         DescChunk ch;
@@ -823,14 +920,12 @@ int launch_tsdf_prepare(hipStream_t s, const Cam &cam, const Grid &g, int n, int
     const int nrx = (cam.W + REGION - 1) / REGION, nry = (cam.H + REGION - 1) / REGION;
     const int nreg = nrx * nry;
     if (depth_u16)
-        hipLaunchKernelGGL(depth_tiles_kernel<uint16_t>, dim3(nreg < 1024 ? nreg : 1024, n), dim3(256), 0, s, cam, B, py, nrx, nry);
+        hipLaunchKernelGGL(depth_tiles_kernel<uint16_t>, dim3(nreg < 512 ? nreg : 512, n), dim3(256), 0, s, cam, B, py, nrx, nry);
     else
-        hipLaunchKernelGGL(depth_tiles_kernel<float>, dim3(nreg < 1024 ? nreg : 1024, n), dim3(256), 0, s, cam, B, py, nrx, nry);
+        hipLaunchKernelGGL(depth_tiles_kernel<float>, dim3(nreg < 512 ? nreg : 512, n), dim3(256), 0, s, cam, B, py, nrx, nry);
     TL3D_HIP(hipGetLastError());
-    if (py.nlev > 3) {
-        hipLaunchKernelGGL(tile_pyramid_kernel, dim3(n), dim3(256), 0, s, py, B);
-        TL3D_HIP(hipGetLastError());
-    }
+    hipLaunchKernelGGL(tile_pyramid_kernel, dim3(n), dim3(256), 0, s, cam, py, B);
+    TL3D_HIP(hipGetLastError());
     const int ncells = ((g.nbx + 3) / 4) * ((g.nby + 3) / 4) * ((g.nbz + 3) / 4);
     hipLaunchKernelGGL(brick_cull_kernel, dim3((ncells + 3) / 4, n), dim3(256), 0, s, cam, g, B, fr, py, free_cnt);
     TL3D_HIP(hipGetLastError());
@@ -858,19 +953,19 @@ int launch_tsdf_update(hipStream_t s, const Cam &cam, const Grid &g, int n, int 
     const BatchLayout L = batch_layout(cam, g, max_frames);
     const BatchBufs B = batch_bufs(L, scratch, n);
     const int nbricks = g.nbx * g.nby * g.nbz;
-    // 6 workgroups per CU by default
     int nblk = (nbricks + 3) / 4;
     if (nblk > max_blocks) nblk = max_blocks;
 #define TL3D_LAUNCH_UPD(C_, T_, E_) \
-    hipLaunchKernelGGL((tsdf_update_kernel<C_, T_, E_>), dim3(nblk), dim3(256), 0, s, cam, g, B, xcd_group, grid, counters)
+    hipLaunchKernelGGL((tsdf_update_kernel<C_, T_, E_>), dim3(nblk), dim3(256), upd_lds, s, cam, g, B, xcd_group, grid, counters)
 #define TL3D_LAUNCH_UPD_E(E_)                                                                          \
     do {                                                                                               \
         if (depth_u16) TL3D_LAUNCH_UPD(false, uint16_t, E_); else TL3D_LAUNCH_UPD(false, float, E_);   \
     } while (0)
 #ifdef TL3D_EXPERIMENTS
     static const int exp_mode = getenv("TL3D_TSDF_EXP") ? atoi(getenv("TL3D_TSDF_EXP")) : 0;     // timing ablations: results incomplete
+    static const int upd_lds = getenv("TL3D_UPD_LDS") ? atoi(getenv("TL3D_UPD_LDS")) : 0;        // unused LDS per workgroup: caps the waves per SIMD
 #else
-    constexpr int exp_mode = 0;
+    constexpr int exp_mode = 0, upd_lds = 0;
 #endif
     if (count) {
         if (depth_u16) TL3D_LAUNCH_UPD(true, uint16_t, 0); else TL3D_LAUNCH_UPD(true, float, 0);

@@ -280,14 +280,10 @@ static int alloc_grid(tl3d_ctx *ctx, const tl3d_config *cfg) {
             ctx->own_tsdf = true;
             if (hipMemsetAsync(ctx->tsdf, 0, pool_b, ctx->stream) != hipSuccess) return set_err(TL3D_E_HIP, "memset failed");
         }
-        {   // side streams for the per-frame prep chains (tiles, pyramid, classification): a chain is three small dependent
-            // kernels that crawl beside the update kernels (~45-75 us).  TWO by default.  Measured: on the 1080p bench three
-            // chains in flight keep ahead of the 31 us two-frame update (28.9-29.3k frames/s against 26.4k with two, 18.4k with
-            // four), but the pipeline's fusion stage on 720p frames (TSDF + centroid kernels interleaved on the main stream) takes
-            // 63-82 ms per 1000 frames with three against 30 with two; TL3D_PREP_STREAMS=1..4 overrides.  Folding the pyramid into
-            // the tiles kernel (last workgroup by ticket) was tried to shorten the chain: its 1024 release fences per frame write
-            // the update kernel's dirty lines back under it (53 us per frame) -- reverted.  Default priority: a priority
-            ctx->n_prep_streams = env_int("TL3D_PREP_STREAMS", 2);
+        {   // Side streams for the prep chains of the batches (descriptors, tiles, pyramid, brick and sub-brick classification):
+            // the chains of batches k+1 and k+2 run beside the update kernel of batch k.  Three streams, taken in turn (one per batch scratch).
+            // (A higher stream priority for the chains changes nothing measurable: 55.4k against 55.3k frames/s.)
+            ctx->n_prep_streams = env_int("TL3D_PREP_STREAMS", 3);
             if (ctx->n_prep_streams < 1) ctx->n_prep_streams = 1;
             if (ctx->n_prep_streams > 4) ctx->n_prep_streams = 4;
             for (int q = 0; q < ctx->n_prep_streams; ++q)
@@ -308,25 +304,31 @@ static int alloc_grid(tl3d_ctx *ctx, const tl3d_config *cfg) {
         ctx->tsdf_batch = env_int("TL3D_TSDF_BATCH", 32);
         if (ctx->tsdf_batch < 1) ctx->tsdf_batch = 1;
         if (ctx->tsdf_batch > TL3D_TSDF_MAXBATCH) ctx->tsdf_batch = TL3D_TSDF_MAXBATCH;
-        ctx->tsdf_max_blocks = env_int("TL3D_UPDATE_BLOCKS", 2048);
+        {   // Workgroups of the update kernel: THREE per CU.  Four fit (127 VGPRs) and the kernel alone is fastest with exactly
+            // four (0.41 ms per 32 frames against 0.46), but the prep chains of the next two batches run beside it and need
+            // wave slots: 61.4k frames/s with 768 workgroups, 59.5k with 1024, 58.2k with 2048 (256 CUs).
+            int cus = 0;
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || cus < 1) cus = 256;
+            ctx->tsdf_max_blocks = env_int("TL3D_UPDATE_BLOCKS", 3 * cus);
+        }
         if (ctx->tsdf_max_blocks < 8) ctx->tsdf_max_blocks = 8;
         ctx->tsdf_xcd_group = env_int("TL3D_XCD_GROUP", 1);       // consecutive list entries per ticket chunk (1: best balance; 16: 41.8k against 43.8k frames/s)
         ctx->tsdf_single_stream = env_int("TL3D_SINGLE_STREAM", 0) != 0;
-        {   // the scratch of the two batches in flight: one allocation; the frame masks start out zero (the update re-arms them)
+        {   // the scratch of the three batches in flight: one allocation; the frame masks start out zero (the update re-arms them)
             const size_t each = (tsdf_batch_scratch_bytes(ctx->cam, g, ctx->tsdf_batch) + 255) & ~(size_t)255;
             void *slab = nullptr;
-            if (hipMalloc(&slab, each * 2) != hipSuccess) return set_err(TL3D_E_NOMEM, "TSDF scratch alloc (%zu B) failed", each * 2);
+            if (hipMalloc(&slab, each * TSDF_SCRATCHES) != hipSuccess) return set_err(TL3D_E_NOMEM, "TSDF scratch alloc (%zu B) failed", each * TSDF_SCRATCHES);
             ctx->tsdf_scratch_slab = slab;
             size_t zoff = 0, zbytes = 0;
             tsdf_batch_scratch_zero_range(ctx->cam, g, ctx->tsdf_batch, &zoff, &zbytes);
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < TSDF_SCRATCHES; ++h) {
                 ctx->tsdf_scratch[h] = (char *)slab + each * (size_t)h;
                 if (hipMemsetAsync((char *)ctx->tsdf_scratch[h] + zoff, 0, zbytes, ctx->stream) != hipSuccess) return set_err(TL3D_E_HIP, "memset failed");
                 if (!ctx->ev_prep[h] && hipEventCreateWithFlags(&ctx->ev_prep[h], hipEventDisableTiming) != hipSuccess) return set_err(TL3D_E_HIP, "event create failed");
             }
             if (hipStreamSynchronize(ctx->stream) != hipSuccess) return set_err(TL3D_E_HIP, "sync failed");     // the prep streams do not wait for this memset
         }
-        for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < TSDF_SCRATCHES; ++h)
             if (hipEventCreateWithFlags(&ctx->ev_upd[h], hipEventDisableTiming) != hipSuccess) return set_err(TL3D_E_HIP, "event create failed");
     }
     if (cfg->channels & TL3D_CH_CENTROID) {
@@ -515,8 +517,10 @@ int tl3d_destroy(tl3d_ctx *ctx) {
     for (int q = 0; q < 4; ++q)
         if (ctx->prep_stream[q]) (void)hipStreamSynchronize(ctx->prep_stream[q]);
     if (ctx->tsdf_scratch_slab) (void)hipFree(ctx->tsdf_scratch_slab);
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < TSDF_SCRATCHES; ++b) {
         if (ctx->ev_prep[b]) (void)hipEventDestroy(ctx->ev_prep[b]);
+        if (ctx->ev_upd[b]) (void)hipEventDestroy(ctx->ev_upd[b]);
+    }
     for (int q = 0; q < 4; ++q)
         if (ctx->prep_stream[q]) (void)hipStreamDestroy(ctx->prep_stream[q]);
     if (ctx->block_counts) (void)hipFree(ctx->block_counts);
@@ -962,7 +966,7 @@ static int ktimer_begin(tl3d_ctx *ctx) {
 }
 
 // Issues the pending batch: its prep chain on a side stream (it needs the frames' uploads, the batch scratch whose previous
-// user -- two batches ago -- has been updated, and the last clear / fold of the free-space counters), then ONE update launch on
+// user -- three batches ago -- has been updated, and the last clear / fold of the free-space counters), then ONE update launch on
 // the main stream behind it.  Results never depend on where the batch boundaries fall (integer sums).
 static int flush_updates(tl3d_ctx *ctx) {
     if (ctx->n_pend == 0) return TL3D_OK;
@@ -972,7 +976,7 @@ static int flush_updates(tl3d_ctx *ctx) {
     const Frustum fr = make_frustum(ctx->cam);
     const int n = ctx->n_pend;
     ctx->n_pend = 0;                                    // whatever happens below, the batch is consumed
-    const int half = (int)(ctx->tsdf_batch_no & 1u);
+    const int half = (int)(ctx->tsdf_batch_no % (unsigned)TSDF_SCRATCHES);
     const bool u16 = ctx->pend_u16;
     hipStream_t ps = ctx->tsdf_single_stream ? ctx->stream : ctx->prep_stream[ctx->tsdf_batch_no % (unsigned)ctx->n_prep_streams];
     PoseF poses[TL3D_TSDF_MAXBATCH];

@@ -130,6 +130,8 @@ constexpr int ICP_SLAB = 40;     // doubles per block partial: 30 sums of the po
 // every touched record once per batch.  Two batch scratch buffers alternate, so the prep of batch k+1 runs beside the update
 // of batch k.
 #define TL3D_TSDF_MAXBATCH 32
+constexpr int TSDF_SCRATCHES = 3;
+
 struct tl3d_ctx {
     tl3d_config cfg;
     int device;
@@ -151,13 +153,14 @@ struct tl3d_ctx {
     // prep_stream while the update kernel of frame i streams the grid on the main stream.
     hipStream_t prep_stream[4];  // consecutive frames take them in turn, so that many prep chains are in flight
     int n_prep_streams;
-    void *tsdf_scratch[2];                // batch scratch (descriptors, tile pyramids, brick lists, frame masks, sub-brick masks): two batches in flight
+    void *tsdf_scratch[TSDF_SCRATCHES];   // batch scratch (descriptors, tile pyramids, brick lists, frame masks, sub-brick masks): three batches in flight
+                                          // (the update of batch k, the prep chains of batches k+1 and k+2)
     void *tsdf_scratch_slab;              // the one allocation they are carved from
     bool tsdf_pairing;                    // frames of a batch share ONE update launch (tl3d_set_tsdf_pairing(ctx, 0): one frame per launch)
     bool pend_u16;                        // depth kind of the pending batch (a batch holds one kind)
-    hipEvent_t ev_prep[2];                // prep of the batch using scratch h is done (recorded on its prep stream)
-    hipEvent_t ev_upd[2];                 // the update of the last batch that used scratch h is done (main stream)
-    bool upd_recorded[2];
+    hipEvent_t ev_prep[TSDF_SCRATCHES];                // prep of the batch using scratch h is done (recorded on its prep stream)
+    hipEvent_t ev_upd[TSDF_SCRATCHES];                 // the update of the last batch that used scratch h is done (main stream)
+    bool upd_recorded[TSDF_SCRATCHES];
     bool tsdf_use_u16;                    // gather from the millimetre image when the slot has one (env TL3D_U16_GATHER=0: never)
     int tsdf_batch;                       // frames per batch (env TL3D_TSDF_BATCH, default 32; 1 = no deferral)
     unsigned tsdf_seq, tsdf_batch_no;

@@ -1,7 +1,8 @@
 #!/usr/bin/env bash
 # usage (GPU box, repo root):  bash tools/prof_round.sh r03
-# 1. rocprofv3 --kernel-trace --stats of the DEFAULT bench command (roofline.ms_per_launch must agree with its average duration
-#    of tsdf_update_kernel);
+# 1. rocprofv3 --kernel-trace --stats of (a) the timed loop alone (`bench.py --no-cpu-baseline --no-rows --no-single`: every
+#    tsdf_update_kernel dispatch is a 32-frame launch of the headline workload, so its average duration must agree with
+#    roofline.ms_per_launch) and (b) the DEFAULT command (all rows; the update kernel's dispatches broken down by launch shape);
 # 2. separate --pmc passes (never combined with tracing; FETCH_SIZE and WRITE_SIZE cannot share a pass on gfx950) over ONE step of
 #    64 frames (two update launches of 32 frames) of the same workload -> per-dispatch means for every tl3d kernel, pmc_traffic.json;
 # 3. FETCH_SIZE calibrated on known byte counts in the kernel's own access patterns (tools/ubench_fetch.hip);
@@ -12,10 +13,29 @@ TAG="${1:-r03}"
 export TMPDIR=/tmp
 OUT="$PWD/gpurun_out/prof_${TAG}"
 rm -rf "$OUT"; mkdir -p "$OUT"
-echo "[prof] kernel trace of: python3 bench.py"
-timeout -k 5 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py > "$OUT/bench_traced.json" 2> "$OUT/bench_traced.err"
+echo "[prof] kernel trace 1 (timed loop only): python3 bench.py --no-cpu-baseline --no-rows --no-single"
+timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace1" -- python3 bench.py --no-cpu-baseline --no-rows --no-single > "$OUT/bench_traced.json" 2> "$OUT/bench_traced.err"
 echo "rc=$?"
-f=$(find "$OUT/trace" -name "*kernel_stats.csv" | head -1); [[ -n "$f" ]] && grep -E "^\"Name\"|tl3d" "$f" > "$OUT/kernel_stats.csv"
+f=$(find "$OUT/trace1" -name "*kernel_stats.csv" | head -1); [[ -n "$f" ]] && grep -E "^\"Name\"|tl3d" "$f" > "$OUT/kernel_stats.csv"
+echo "[prof] kernel trace 2 (the default command, rows and the one-frame-per-launch section included): python3 bench.py"
+timeout -k 5 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace2" -- python3 bench.py > "$OUT/bench_rows_traced.json" 2> "$OUT/bench_rows_traced.err"
+echo "rc=$?"
+f=$(find "$OUT/trace2" -name "*kernel_stats.csv" | head -1); [[ -n "$f" ]] && grep -E "^\"Name\"|tl3d" "$f" > "$OUT/rows_kernel_stats.csv"
+python3 - "$OUT" <<'PY' > "$OUT/update_by_launch_shape.txt"
+# the update kernel's dispatches of the DEFAULT command grouped by launch shape (32-frame batches use the full grid of workgroups,
+# the one-frame-per-launch section a grid the size of its brick list)
+import csv, glob, os, sys, collections
+out = sys.argv[1]
+g = collections.defaultdict(list)
+for f in glob.glob(os.path.join(out, "trace2", "**", "*kernel_trace.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "tsdf_update_kernel" in r["Kernel_Name"]:
+            g[(r.get("Grid_Size_X") or r.get("Grid_Size"), r.get("Workgroup_Size_X") or r.get("Workgroup_Size"))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+print("tsdf_update_kernel dispatches of `python3 bench.py` by launch shape (grid threads, workgroup): n, mean us, min us, max us")
+for k, v in sorted(g.items(), key=lambda kv: -len(kv[1])):
+    print(f"  grid {k[0]:>8s} wg {k[1]:>4s}: n {len(v):6d}  mean {sum(v) / len(v):9.1f}  min {min(v):9.1f}  max {max(v):9.1f}")
+PY
+cat "$OUT/update_by_launch_shape.txt"
 bash tools/pmc_quick.sh "${TAG}" > "$OUT/pmc.log" 2>&1
 cp "gpurun_out/pmc_${TAG}/summary.txt" "$OUT/pmc_summary.txt" 2>/dev/null
 cp "gpurun_out/pmc_${TAG}/bench1.log" "$OUT/bench_pmc.log" 2>/dev/null
@@ -41,5 +61,5 @@ timeout -k 5 300 python3 bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_def
 timeout -k 5 300 python3 bench.py --depth-format u16 --no-rows --no-cpu-baseline > "$OUT/bench_u16_frames.json" 2>/dev/null; echo "rc=$?"
 timeout -k 5 300 python3 bench.py --width 3840 --height 2160 --grid 1024 --voxel 0.002 --resident-frames 256 --frames-per-step 256 --steps 4 --no-rows --no-cpu-baseline > "$OUT/bench_config5_size.json" 2>/dev/null; echo "rc=$?"
 find "$OUT" -name "*kernel_trace.csv" -delete; find "$OUT" -name "*counter_collection.csv" -delete; find "$OUT" -name "*agent_info.csv" -delete
-rm -rf "$OUT/trace" "$OUT/cal"
+rm -rf "$OUT/trace1" "$OUT/trace2" "$OUT/cal"
 du -sh "$OUT"

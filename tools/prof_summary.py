@@ -24,13 +24,22 @@ for line in open(os.path.join(pmc, "bench1.log")):
         bench = json.loads(line)
 if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals and bench:
     r = bench["roofline"]
+    # gfx950: FETCH_SIZE tallies the 128-B requests of a coalesced 8- or 16-B-per-lane read at 64 B (MI355X guide, HBM section; confirmed
+    # for 8 B per lane in pmc_calibration.txt) and the 64-B requests of scattered 4-B gathers at face value.  This kernel reads its
+    # records 8 B per lane (coalesced; as many as it writes: WRITE_SIZE is exact) and gathers depth 4 B per lane: the records' half
+    # that FETCH_SIZE misses is added back.
+    rec_read = min(vals["WRITE_SIZE"], 2.0 * vals["FETCH_SIZE"]) * 1024.0
     j = {"grid": bench["config"]["grid"], "width": 1080, "height": 1920, "depth_format": bench["config"]["depth_format"], "free_space_counters": True,
          "kernel": "tsdf_update_kernel", "frames_per_sweep": int(round(r["frames_per_sweep"])), "fetch_size_kb": round(vals["FETCH_SIZE"], 1),
-         "write_size_kb": round(vals["WRITE_SIZE"], 1), "hbm_bytes_per_launch": int((vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0),
+         "write_size_kb": round(vals["WRITE_SIZE"], 1),
+         "hbm_bytes_per_launch": int((vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0 + 0.5 * rec_read),
+         "record_read_bytes_added_back": int(0.5 * rec_read),
+         "depth_gather_bytes_per_launch": int(vals["FETCH_SIZE"] * 1024.0 - 0.5 * rec_read),
          "algorithmic_bytes_per_launch": r["bytes_per_launch"],
          "l2_hit_rate": round(vals["TCC_HIT_sum"] / (vals["TCC_HIT_sum"] + vals["TCC_MISS_sum"]), 3) if "TCC_HIT_sum" in vals else None,
-         "note": "(FETCH_SIZE + WRITE_SIZE) x 1024 per dispatch from separate --pmc passes, at face value (no 16-B-per-lane streaming reads "
-                 "in this kernel; calibration of its access widths: pmc_calibration.txt)"}
+         "note": "FETCH_SIZE + WRITE_SIZE (x 1024) per dispatch from separate --pmc passes, plus the half of the coalesced 8-B-per-lane "
+                 "record reads that FETCH_SIZE does not tally on gfx950 (record bytes read = bytes written = WRITE_SIZE); L2-side requests: "
+                 "Infinity-Cache hits are included, so this is an upper bound on HBM bytes"}
     json.dump(j, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
     print(json.dumps(j))
 else:
