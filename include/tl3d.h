@@ -319,15 +319,16 @@ int tl3d_statistical_outlier(tl3d_ctx *ctx, const float *xyz_hd, int64_t n, int 
 /* measurement */
 int tl3d_set_profile(tl3d_ctx *ctx, int count_records, int time_kernels);
 /* Noise-robust registration: normal maps built after this call come from the depth averaged over a (2 radius + 1)^2 window
- * (valid pixels within depth_jump of the centre pixel only: no average runs across a depth edge), with the tangent vectors
+ * -- the HARMONIC mean (mean of 1 / z, which is linear in the pixel coordinates on any plane) over the centre pixel and the
+ * pixel pairs (u + du, v + dv), (u - du, v - dv) that are both valid and within depth_jump of the centre (a symmetric set: no
+ * average runs across a depth edge, and none is pulled to one side at the edge of a surface) -- with the tangent vectors
  * `radius` pixels to either side; registrations then read that averaged depth as their SOURCE too (tl3d_icp_*: a slot whose
  * normal map was built smoothed).  0 (default) = central differences of the depth image itself.  With 1 mm of depth noise the
  * frame-to-frame chain of config 2 drifts 7 x less at radius 1 (tests/test_gpu_baseline_configs.py). */
 int tl3d_set_normal_smoothing(tl3d_ctx *ctx, int radius);
 
-/* tl3d_integrate updates two consecutive frames in one launch (the bricks both see near a surface are read and written
- * once for both; the grid is the same bit for bit).  on = 0: one frame per launch.  Default: on (environment
- * TL3D_TSDF_PAIR=0: off). */
+/* tl3d_integrate collects up to 32 frames per update launch (the bricks they see are read and written once for all of them;
+ * the grid is the same bit for bit).  on = 0: one frame per launch.  Default: on. */
 int tl3d_set_tsdf_pairing(tl3d_ctx *ctx, int on);
 int tl3d_get_stats(tl3d_ctx *ctx, tl3d_stats *out);
 int tl3d_reset_stats(tl3d_ctx *ctx);

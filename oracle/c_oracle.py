@@ -168,7 +168,7 @@ class Oracle:
         return nmap
 
     def normals_smooth(self, depth, radius=2, scale=1.0, depth_jump=0.05):
-        """(smoothed depth [H,W] in the units of `depth`, nmap [H,W,4]): window mean over valid pixels within depth_jump of the
+        """(smoothed depth [H,W] in the units of `depth`, nmap [H,W,4]): harmonic window mean (mean of 1/z over the centre and the symmetric pixel pairs that are valid and within depth_jump of the
         centre, normals from it with a `radius`-pixel step (orc_normals_smooth)."""
         d = self._depth(depth)
         sd = np.empty((self.cfg.height, self.cfg.width), np.float32)

@@ -373,23 +373,24 @@ void orc_normals_smooth(const orc_cfg *c, const float *depth, double scale, doub
             const float d0 = depth[(size_t)v * W + u] * sc;
             float out = 0.0f;
             if (d0 > mind && d0 < maxd) {
-                float sum = 0.0f;
-                int n = 0;
-                for (int dv = -radius; dv <= radius; ++dv) {
-                    const int vv = v + dv;
-                    if (vv < 0 || vv >= H) continue;
-                    for (int du = -radius; du <= radius; ++du) {
-                        const int uu = u + du;
-                        if (uu < 0 || uu >= W) continue;
-                        const float dr = depth[(size_t)vv * W + uu];
-                        const float d = dr * sc;
-                        if (!(d > mind && d < maxd)) continue;
-                        if (!(fabsf(d - d0) <= jump)) continue;
-                        sum += dr;
-                        ++n;
+                /* mean of the INVERSE depth (linear in the pixel coordinates on a plane, however oblique) over the centre and the
+                   pixel PAIRS (u + du, v + dv), (u - du, v - dv) that are both in the image, valid and within the jump of the
+                   centre (a symmetric set: the mean of a linear function over it is its centre value) */
+                float sum = 1.0f / depth[(size_t)v * W + u];
+                int n = 1;
+                for (int dv = 0; dv <= radius; ++dv)
+                    for (int du = (dv == 0 ? 1 : -radius); du <= radius; ++du) {
+                        const int ua = u + du, va = v + dv, ub = u - du, vb = v - dv;
+                        if (ua < 0 || ua >= W || va < 0 || va >= H || ub < 0 || ub >= W || vb < 0 || vb >= H) continue;
+                        const float ra = depth[(size_t)va * W + ua], rb = depth[(size_t)vb * W + ub];
+                        const float da = ra * sc, db = rb * sc;
+                        if (!(da > mind && da < maxd) || !(db > mind && db < maxd)) continue;
+                        if (!(fabsf(da - d0) <= jump) || !(fabsf(db - d0) <= jump)) continue;
+                        sum += 1.0f / ra;
+                        sum += 1.0f / rb;
+                        n += 2;
                     }
-                }
-                out = sum / (float)n;
+                out = (float)n / sum;
             }
             sdepth[(size_t)v * W + u] = out;
         }

@@ -42,23 +42,25 @@ __global__ __launch_bounds__(256) void smooth_depth_kernel(Cam cam, const float 
     const float d0 = depth[(size_t)v * cam.W + u] * sc;
     float res = 0.0f;
     if (d0 > mind && d0 < maxd) {
-        float sum = 0.0f;
-        int n = 0;
-        for (int dv = -radius; dv <= radius; ++dv) {
-            const int vv = v + dv;
-            if (vv < 0 || vv >= cam.H) continue;
-            for (int du = -radius; du <= radius; ++du) {
-                const int uu = u + du;
-                if (uu < 0 || uu >= cam.W) continue;
-                const float dr = depth[(size_t)vv * cam.W + uu];
-                const float d = dr * sc;
-                if (!(d > mind && d < maxd)) continue;
-                if (!(fabsf(d - d0) <= jump)) continue;
-                sum += dr;
-                ++n;
+        // mean of the INVERSE depth (linear in the pixel coordinates on a plane, however oblique: a plain mean of the depth is
+        // biased on a floor seen at a grazing angle, 0.06 mm per frame of drift on config 4) over the centre and the pixel PAIRS
+        // (u + du, v + dv), (u - du, v - dv) that are both in the image, valid and within the jump of the centre -- a symmetric
+        // set: the mean of a linear function over it is its centre value, at the edge of a surface too.  The oracle's order.
+        float sum = 1.0f / depth[(size_t)v * cam.W + u];
+        int n = 1;
+        for (int dv = 0; dv <= radius; ++dv)
+            for (int du = (dv == 0 ? 1 : -radius); du <= radius; ++du) {
+                const int ua = u + du, va = v + dv, ub = u - du, vb = v - dv;
+                if (ua < 0 || ua >= cam.W || va < 0 || va >= cam.H || ub < 0 || ub >= cam.W || vb < 0 || vb >= cam.H) continue;
+                const float ra = depth[(size_t)va * cam.W + ua], rb = depth[(size_t)vb * cam.W + ub];
+                const float da = ra * sc, db = rb * sc;
+                if (!(da > mind && da < maxd) || !(db > mind && db < maxd)) continue;
+                if (!(fabsf(da - d0) <= jump) || !(fabsf(db - d0) <= jump)) continue;
+                sum += 1.0f / ra;
+                sum += 1.0f / rb;
+                n += 2;
             }
-        }
-        res = sum / (float)n;
+        res = (float)n / sum;
     }
     out[(size_t)v * cam.W + u] = res;
 }
@@ -722,10 +724,15 @@ __global__ __launch_bounds__(256) void icp_iter_kernel(Cam cam, const IcpRun *__
 // members of a pair stuck, the 25 on the publisher's XCD gone ahead), whatever the allocation flags.  A long first sleep,
 // then short ones: polls of one line from a hundred CUs at full rate saturate its channel and starve the arrivals.
 // Arrival counter and generation line of a pair are different lines; consecutive pairs' lines are > 4 KB apart.
-// Waiting needs the pair's other workgroups to be running: workgroups therefore take their (pair, member) from a ticket
-// counter as they START, so the members of every pair but the newest are all resident (or done) whatever the dispatch
-// order, and the newest pair gets the slots the older ones free -- the grid always drains (members <= 64 workgroups
-// against >= 256 resident ones).  Every wait is bounded in time; a time-out raises the error word and ends the launch.
+// Waiting needs the pair's other workgroups to be running.  The launch is therefore PERSISTENT: at most as many workgroups as
+// the chip holds at once, each taking (pair, member) TICKETS in a loop -- one when it starts, the next when its pair is through
+// all its passes.  The tickets handed out at any moment form a window of consecutive (pair, member) slots held by running
+// workgroups: every pair that lies wholly inside the window completes, its workgroups come back for tickets, and the pair at
+// the window's upper end gets its missing members from them (members <= 64 against >= 256 running workgroups).  Nothing
+// depends on WHEN the hardware starts a workgroup.  (Until round 3 the grid was one workgroup per slot, tickets taken at
+// the start: the last pair of a 128-pair batch of 720p frames then waited for the grid's last two or three workgroups, which
+// the dispatcher now and then -- one batch in eight -- started seconds late: the in-kernel time-out of config 4.)
+// Every wait is bounded in time; a time-out raises the error word and ends the launch.
 constexpr unsigned long long ICP_WAIT_LIMIT_TICKS = 200000000ull;          // 2 s of the 100 MHz wall clock
 __device__ __forceinline__ size_t icp_sync_line(int pair, int rows) {        // 16-word line of `pair`: neighbours are rows*64 B (> 4 KB) apart
     return ((size_t)(pair & 63) * (size_t)rows + (size_t)(pair >> 6)) * 16;
@@ -736,11 +743,12 @@ __global__ __launch_bounds__(256) void icp_batch_kernel(Cam cam, IcpBatchArgs a)
     __shared__ float sT[13];                               // the pose as 12 floats + the source depth's scale
     __shared__ int s_flag[4];                              // [0] ticket, [1] last arriver, [2] generation word seen, [3] wait failed
     const int tid = threadIdx.x;
+    for (;;) {                                             // one (pair, member) slot per trip
     if (tid == 0) s_flag[0] = (int)__hip_atomic_fetch_add(a.ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     const int ticket = s_flag[0];
     const int pair = ticket / a.members, member = ticket - pair * a.members;
-    if (pair >= a.n_pairs) return;                         // (grid = n_pairs * members: never)
+    if (pair >= a.n_pairs) return;                         // every slot has been handed out
     const IcpBatchPair pr = a.pairs[pair];
     IcpState *st = a.states + pair;
     unsigned *stage = a.stage ? a.stage + (size_t)ticket * 4 : nullptr;      // experiments: how far this workgroup got
@@ -865,12 +873,22 @@ __global__ __launch_bounds__(256) void icp_batch_kernel(Cam cam, IcpBatchArgs a)
             if (failed) return;                            // a wait timed out: the error word is set, the host reports it
             if (final_pass) break;
         }
-        if (over) return;
+        if (over) break;
+    }
+#undef ICP_STAMP
+    __syncthreads();                                       // shared state is rewritten by the next slot
     }
 }
 
 int launch_icp_batch(hipStream_t s, const Cam &cam, const IcpBatchArgs &a) {
-    hipLaunchKernelGGL(icp_batch_kernel, dim3((unsigned)a.n_pairs * (unsigned)a.members), dim3(256), 0, s, cam, a);
+    static int resident = 0;                               // workgroups of 256 threads the chip holds at once (8 per CU)
+    if (!resident) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        resident = 8 * cus;
+    }
+    const unsigned slots = (unsigned)a.n_pairs * (unsigned)a.members;
+    hipLaunchKernelGGL(icp_batch_kernel, dim3(slots < (unsigned)resident ? slots : (unsigned)resident), dim3(256), 0, s, cam, a);
     TL3D_HIP(hipGetLastError());
     return TL3D_OK;
 }

@@ -7,8 +7,9 @@
 // arguments (pose, depth image, scratch pointers) of all its frames sit in one descriptor array in device memory and
 // blockIdx.y / a bit index picks the frame:
 //   1. depth_tiles_kernel     (min, max, all-valid) of the valid scaled depth over 8x8-, 16x16- and 32x32-pixel tiles
-//                             (pyramid levels 0-2) of every frame, 4 B/pixel read
-//   2. tile_pyramid_kernel    1 workgroup per frame: 2x2 reductions of level 2 up to a single tile
+//                             (pyramid levels 0-2) of every frame, 4 B/pixel read; the 8x8 level once more as 8-B records
+//                             for the update kernel's per-voxel test
+//   2. tile_pyramid_kernel    1 workgroup per frame: 2x2 reductions of level 2 up to a single tile; one valid pixel of the frame
 //   3. brick_cull_kernel      per frame, one lane per 8^3 brick (one wave per 4x4x4-brick cell) classifies it from <= 16
 //                             pyramid lookups:
 //        SKIP   outside the view, no valid depth under it, or more than trunc behind every surface it can see
@@ -21,10 +22,11 @@
 //        (8 lanes per sub-brick: one extreme voxel centre each, <= 8 pyramid lookups) -> a (mixed, free) bit mask.  On the
 //        headline sequence 3.4 of the 8 sub-bricks of a listed brick stay MIXED.
 //   5. tsdf_update_kernel     ONE launch per batch, one 64-lane wave per brick of the batch list: for every frame that lists
-//        the brick (frame mask), the voxels of its MIXED sub-bricks are projected and gather a depth value, FREE sub-bricks
-//        add (32767, 1); the increments of all frames are summed in registers and the brick's records are read and written
-//        ONCE per batch (integer sums commute: the grid is the one-frame-at-a-time grid bit for bit).  A sub-brick's 64
-//        records are contiguous (tl3d_internal.h: in_brick_index): every record access of a wave is one 512-B run.
+//        the brick (frame mask), the voxels of its MIXED sub-bricks are projected; the 8x8-pixel tile under a voxel's pixel
+//        decides most of them (free / behind everything), the rest gather their depth value; FREE sub-bricks add (32767, 1);
+//        the increments of all frames are summed in registers and the brick's records are read and written ONCE per batch
+//        (integer sums commute: the grid is the one-frame-at-a-time grid bit for bit).  A sub-brick's 64 records are
+//        contiguous (tl3d_internal.h: in_brick_index): every record access of a wave is one 512-B run.
 // Every classification is conservative with respect to the per-voxel rule, so the result is the oracle's bit
 // for bit whatever the view.
 // Algorithmic bytes per launch = 8 B x (records read + written), counted by the kernel in counting mode

@@ -62,6 +62,8 @@ def main():
     ap.add_argument("--frames", type=int, default=0, help="override the sequence length")
     ap.add_argument("--ref-frames", type=int, default=0, help="frames of the restated reference CPU path to compare with (0 = config default)")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--smooth-radius", type=int, default=-1, help="icp_smooth_radius (default: the configuration's)")
+    ap.add_argument("--depth-noise-mm", type=float, default=0.0, help="Gaussian depth noise added to every frame")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     if args.config == "2":
@@ -82,11 +84,19 @@ def main():
         ref_n = args.ref_frames or 100
         name = ("config 4: cylinder + ground orbit" if args.config == "4" else "config 4b: PURE cylinder orbit (degenerate)") + \
             f", {n} x 1280x720, 0.36 deg per frame, ICP every frame, 10 mm"
+    if args.smooth_radius >= 0:
+        cfg.icp_smooth_radius = args.smooth_radius
+        name += f", icp_smooth_radius {args.smooth_radius}"
+    if args.depth_noise_mm > 0:
+        name += f", {args.depth_noise_mm} mm depth noise"
     rel = rel_to_first(poses)
+    gen = torch.Generator(device=dev).manual_seed(7)
     t0 = time.perf_counter()
     images, depths, host = [], [], []
     for i, p in enumerate(poses):
         d, c = synth.render(scene, p, W, H, cfg.fx, cfg.fy, cfg.cx, cfg.cy, xp=torch, device=dev)
+        if args.depth_noise_mm > 0:
+            d = torch.where(d > 0, d + 1e-3 * args.depth_noise_mm * torch.randn(d.shape, device=dev, generator=gen, dtype=d.dtype), d)
         depths.append(d.contiguous())
         images.append(c.contiguous())
         if i < ref_n:
