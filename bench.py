@@ -292,6 +292,7 @@ def main():
         region_ms = dev_ms / launches
         counters_on = m["free_space_bricks_counted_per_launch"] > 0
         traffic = None
+        pmc_extra = {}
         pj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pj):
             try:
@@ -302,6 +303,7 @@ def main():
                         and bool(tj.get("free_space_counters", False)) == counters_on
                         and int(tj.get("frames_per_sweep", 1)) == int(round(m["frames_per_sweep"]))):
                     traffic = tj.get("hbm_bytes_per_launch")
+                    pmc_extra = {k: tj.get(k) for k in ("l2_read_requests_per_launch", "scattered_read_roof_requests_per_s", "valu_instructions_per_launch")}
             except Exception:
                 traffic = None
         paired = m["frames_per_sweep"] > 1.01
@@ -313,6 +315,18 @@ def main():
                 "free_space_bricks_counted_per_launch": m["free_space_bricks_counted_per_launch"],
                 "ms_per_launch": m["ms_per_launch"], "us_per_frame": m["us_per_frame"], "ms_per_frame_all_kernels": round(region_ms, 4),
                 "launches": int(round(launches / m["frames_per_sweep"])), "frames_per_sweep": m["frames_per_sweep"]}
+        if pmc_extra.get("l2_read_requests_per_launch") and m["ms_per_launch"] > 0:
+            # what the kernel is really bound by, from the committed PMC passes of this workload and this run's timing:
+            # 64-B read requests that leave the L2 per second against the chip's measured rate for scattered 4-B reads, and the share
+            # of the launch the vector ALU needs at full issue rate (4 cycles per instruction, 4 SIMDs on each of 256 CUs, 2.4 GHz)
+            rate = pmc_extra["l2_read_requests_per_launch"] / (m["ms_per_launch"] * 1e-3)
+            roof["scattered_reads"] = {"l2_read_requests_per_launch": pmc_extra["l2_read_requests_per_launch"],
+                                       "achieved_G_per_s": round(rate * 1e-9, 2), "roof_G_per_s": round(pmc_extra["scattered_read_roof_requests_per_s"] * 1e-9, 2),
+                                       "frac": round(rate / pmc_extra["scattered_read_roof_requests_per_s"], 4)}
+            if pmc_extra.get("valu_instructions_per_launch"):
+                valu_ms = pmc_extra["valu_instructions_per_launch"] * 4.0 / (1024 * 2.4e9) * 1e3
+                roof["vector_alu"] = {"instructions_per_launch": pmc_extra["valu_instructions_per_launch"], "ms_at_full_issue_rate": round(valu_ms, 4),
+                                      "frac_of_launch": round(valu_ms / m["ms_per_launch"], 4)}
         if paired and not args.no_single:
             # the same frames, one per launch (F = 1: what the fraction was quoted on before), same context, same buffers
             ctx.set_tsdf_pairing(False)

@@ -121,6 +121,27 @@ def test_randomised_shapes_strides_and_limits_match_pinned_oracle():
             assert ulp_diff(p, rp).max() <= 1, (case, ulp_diff(p, rp).max())
 
 
+def test_full_hd_all_valid_stride_1_repeated_keeps_order_and_values():
+    """1080 x 1920, every pixel valid, stride 1: 1013 tiles of 2048 samples, more than the chip holds at once (dynamic tile
+    order, look-back over many windows, every staging pass full).  The case in which a development build of round 2 copied a
+    wave's part of the LDS staging slab out before it was written; repeated, because that depended on timing."""
+    rng = np.random.default_rng(77)
+    h, w = 1920, 1080
+    depth = (0.5 + 2.0 * rng.random((h, w))).astype(np.float32)
+    color = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    pose = gi.pose(5)
+    rp, rc = rn.backproject(depth, color, 1719.0, 1719.0, 540.0, 960.0, pose=pose, scale=1.0, subsample=1, min_depth=0.1, max_depth=50.0)
+    assert len(rp) == h * w
+    with tl3d.FusionContext(w, h, 1719.0, 1719.0, 540.0, 960.0, 0.1, 50.0, n_slots=1) as ctx:
+        ctx.upload(0, depth, color)
+        for rep in range(6):
+            p, c = ctx.backproject(0, pose=pose, scale=1.0, subsample=1)
+            assert len(p) == h * w, rep
+            assert np.array_equal(c, rc), rep
+            assert ulp_diff(p, rp).max() <= 1, rep
+        assert ctx.stats()["bp_lookback_retries"] == 0
+
+
 def test_u16_millimetre_conversion_is_exact_for_every_value():
     """uint16 mm -> float32 m on device == numpy's `.astype(float32) / 1000.0` (D2R:90) for all 65 536 inputs."""
     import tl3d

@@ -2,7 +2,7 @@
 # usage (GPU box, repo root):  bash tools/prof_round.sh r03
 # 1. rocprofv3 --kernel-trace --stats of (a) the timed loop alone (`bench.py --no-cpu-baseline --no-rows --no-single`: every
 #    tsdf_update_kernel dispatch is a 32-frame launch of the headline workload, so its average duration must agree with
-#    roofline.ms_per_launch) and (b) the DEFAULT command (all rows; the update kernel's dispatches broken down by launch shape);
+#    roofline.ms_per_launch) and (b) the DEFAULT command (all rows; the update kernel's dispatches split by the phase of bench.py they belong to);
 # 2. separate --pmc passes (never combined with tracing; FETCH_SIZE and WRITE_SIZE cannot share a pass on gfx950) over ONE step of
 #    64 frames (two update launches of 32 frames) of the same workload -> per-dispatch means for every tl3d kernel, pmc_traffic.json;
 # 3. FETCH_SIZE calibrated on known byte counts in the kernel's own access patterns (tools/ubench_fetch.hip);
@@ -21,21 +21,32 @@ echo "[prof] kernel trace 2 (the default command, rows and the one-frame-per-lau
 timeout -k 5 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace2" -- python3 bench.py > "$OUT/bench_rows_traced.json" 2> "$OUT/bench_rows_traced.err"
 echo "rc=$?"
 f=$(find "$OUT/trace2" -name "*kernel_stats.csv" | head -1); [[ -n "$f" ]] && grep -E "^\"Name\"|tl3d" "$f" > "$OUT/rows_kernel_stats.csv"
-python3 - "$OUT" <<'PY' > "$OUT/update_by_launch_shape.txt"
-# the update kernel's dispatches of the DEFAULT command grouped by launch shape (32-frame batches use the full grid of workgroups,
-# the one-frame-per-launch section a grid the size of its brick list)
-import csv, glob, os, sys, collections
+python3 - "$OUT" <<'PY' > "$OUT/update_by_phase.txt"
+# The update kernel's dispatches of the DEFAULT command, split by the phase of bench.py they belong to.  bench.py runs, in this
+# order: warm-up + timed steps + the profiled re-run of the timed steps (all 32-frame launches of the headline workload), then the
+# one-frame-per-launch section and the rows.  The first (warmup + 2 steps) x frames_per_step / 32 dispatches of the non-counting
+# instantiation are therefore the launches roofline.ms_per_launch averages over (its hipEvent pairs cover the re-run).
+import csv, glob, json, os, sys
 out = sys.argv[1]
-g = collections.defaultdict(list)
+b = None
+for l in open(os.path.join(out, "bench_rows_traced.json")):
+    if l.startswith("{"): b = json.loads(l)
+rows = []
 for f in glob.glob(os.path.join(out, "trace2", "**", "*kernel_trace.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        if "tsdf_update_kernel" in r["Kernel_Name"]:
-            g[(r.get("Grid_Size_X") or r.get("Grid_Size"), r.get("Workgroup_Size_X") or r.get("Workgroup_Size"))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-print("tsdf_update_kernel dispatches of `python3 bench.py` by launch shape (grid threads, workgroup): n, mean us, min us, max us")
-for k, v in sorted(g.items(), key=lambda kv: -len(kv[1])):
-    print(f"  grid {k[0]:>8s} wg {k[1]:>4s}: n {len(v):6d}  mean {sum(v) / len(v):9.1f}  min {min(v):9.1f}  max {max(v):9.1f}")
+        if "tsdf_update_kernel<false" in r["Kernel_Name"]:
+            rows.append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+rows.sort()
+if b and rows:
+    per_step = 512 // 32
+    n_head = (b["warmup"] + 2 * b["steps"]) * per_step
+    head, rest = [d for _, d in rows[:n_head]], [d for _, d in rows[n_head:]]
+    print(f"tsdf_update_kernel<false, ...> dispatches of `python3 bench.py`: {len(rows)}")
+    print(f"  first {len(head)} (warm-up, timed region, profiled re-run: 32 frames per launch): mean {sum(head) / len(head):.1f} us  min {min(head):.1f}  max {max(head):.1f}")
+    print(f"  last {len(head) - b['warmup'] * per_step - b['steps'] * per_step} of those (the profiled re-run): mean {sum(head[-b['steps'] * per_step:]) / (b['steps'] * per_step):.1f} us;  bench.py's hipEvent figure: {1e3 * b['roofline']['ms_per_launch']:.1f} us")
+    if rest: print(f"  the other {len(rest)} (one frame per launch, rows): mean {sum(rest) / len(rest):.1f} us  min {min(rest):.1f}  max {max(rest):.1f}")
 PY
-cat "$OUT/update_by_launch_shape.txt"
+cat "$OUT/update_by_phase.txt"
 bash tools/pmc_quick.sh "${TAG}" > "$OUT/pmc.log" 2>&1
 cp "gpurun_out/pmc_${TAG}/summary.txt" "$OUT/pmc_summary.txt" 2>/dev/null
 cp "gpurun_out/pmc_${TAG}/bench1.log" "$OUT/bench_pmc.log" 2>/dev/null

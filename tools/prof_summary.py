@@ -37,6 +37,11 @@ if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals and bench:
          "depth_gather_bytes_per_launch": int(vals["FETCH_SIZE"] * 1024.0 - 0.5 * rec_read),
          "algorithmic_bytes_per_launch": r["bytes_per_launch"],
          "l2_hit_rate": round(vals["TCC_HIT_sum"] / (vals["TCC_HIT_sum"] + vals["TCC_MISS_sum"]), 3) if "TCC_HIT_sum" in vals else None,
+         # what the kernel is actually bound by: 64-B requests that leave the L2, against the chip's measured rate for
+         # scattered 4-B reads (tools/ubench_gather.hip: 55.4 G/s), and vector-ALU instructions (4 cycles each on 1024 SIMDs)
+         "l2_read_requests_per_launch": int(vals["TCC_EA0_RDREQ_sum"]) if "TCC_EA0_RDREQ_sum" in vals else None,
+         "scattered_read_roof_requests_per_s": 55.4e9,
+         "valu_instructions_per_launch": int(vals["SQ_INSTS_VALU"]) if "SQ_INSTS_VALU" in vals else None,
          "note": "FETCH_SIZE + WRITE_SIZE (x 1024) per dispatch from separate --pmc passes, plus the half of the coalesced 8-B-per-lane "
                  "record reads that FETCH_SIZE does not tally on gfx950 (record bytes read = bytes written = WRITE_SIZE); L2-side requests: "
                  "Infinity-Cache hits are included, so this is an upper bound on HBM bytes"}
