@@ -728,7 +728,8 @@ __global__ __launch_bounds__(256) void icp_iter_kernel(Cam cam, const IcpRun *__
 // the chip holds at once, each taking (pair, member) TICKETS in a loop -- one when it starts, the next when its pair is through
 // all its passes.  The tickets handed out at any moment form a window of consecutive (pair, member) slots held by running
 // workgroups: every pair that lies wholly inside the window completes, its workgroups come back for tickets, and the pair at
-// the window's upper end gets its missing members from them (members <= 64 against >= 256 running workgroups).  Nothing
+// the window's upper end gets its missing members from them (members <= 64 against >= 256 running workgroups: the grid is
+// what the occupancy query says the chip holds, never less than one workgroup per CU).  Nothing
 // depends on WHEN the hardware starts a workgroup.  (Until round 3 the grid was one workgroup per slot, tickets taken at
 // the start: the last pair of a 128-pair batch of 720p frames then waited for the grid's last two or three workgroups, which
 // the dispatcher now and then -- one batch in eight -- started seconds late: the in-kernel time-out of config 4.)
@@ -737,7 +738,11 @@ constexpr unsigned long long ICP_WAIT_LIMIT_TICKS = 200000000ull;          // 2 
 __device__ __forceinline__ size_t icp_sync_line(int pair, int rows) {        // 16-word line of `pair`: neighbours are rows*64 B (> 4 KB) apart
     return ((size_t)(pair & 63) * (size_t)rows + (size_t)(pair >> 6)) * 16;
 }
-__global__ __launch_bounds__(256) void icp_batch_kernel(Cam cam, IcpBatchArgs a) {
+// SCALE_OK: the launch may hold levels that estimate the source depth's scale (Sim(3)).  The common instantiation (false) carries
+// neither the scale column's sums nor the 7-unknown solver: 256 registers instead of 512, i.e. TWO workgroups per CU instead of one
+// -- twice the pairs in flight (a waiting member holds its slot).
+template <bool SCALE_OK>
+__global__ __launch_bounds__(256, SCALE_OK ? 1 : 2) void icp_batch_kernel(Cam cam, IcpBatchArgs a) {
     __shared__ double sm[8][ICP_SLAB];
     __shared__ double tot[ICP_SLAB];
     __shared__ float sT[13];                               // the pose as 12 floats + the source depth's scale
@@ -774,7 +779,7 @@ __global__ __launch_bounds__(256) void icp_batch_kernel(Cam cam, IcpBatchArgs a)
             r[3] = sT[4]; r[4] = sT[5]; r[5] = sT[6];  t[1] = sT[7];
             r[6] = sT[8]; r[7] = sT[9]; r[8] = sT[10]; t[2] = sT[11];
             ICP_STAMP(1);
-            const int est = final_pass ? 0 : L.est_scale;
+            const int est = SCALE_OK ? (final_pass ? 0 : L.est_scale) : 0;
             if (est)
                 icp_accumulate_core<true>(cam, pr.depth_src, pr.nmap_tgt, sT[12], a.mind, a.maxd, L.md2, L.stride, L.Ws, L.Hs, r, t, member, a.members, sm, tot,
                                           (dbg && gen < 16u) ? dbg + gen * 8 + 3 : nullptr);
@@ -881,14 +886,21 @@ __global__ __launch_bounds__(256) void icp_batch_kernel(Cam cam, IcpBatchArgs a)
 }
 
 int launch_icp_batch(hipStream_t s, const Cam &cam, const IcpBatchArgs &a) {
-    static int resident = 0;                               // workgroups of 256 threads the chip holds at once (8 per CU)
-    if (!resident) {
-        int dev = 0, cus = 0;
+    bool scale = false;
+    for (int l = 0; l < a.n_levels; ++l) scale = scale || a.lv[l].est_scale != 0;
+    static int resident[2] = {0, 0};                       // workgroups the chip holds at once, per instantiation
+    if (!resident[scale]) {
+        int dev = 0, cus = 0, per_cu = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-        resident = 8 * cus;
+        const hipError_t e = scale ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, icp_batch_kernel<true>, 256, 0)
+                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, icp_batch_kernel<false>, 256, 0);
+        if (e != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 1; }
+        resident[scale] = per_cu * cus;
     }
     const unsigned slots = (unsigned)a.n_pairs * (unsigned)a.members;
-    hipLaunchKernelGGL(icp_batch_kernel, dim3(slots < (unsigned)resident ? slots : (unsigned)resident), dim3(256), 0, s, cam, a);
+    const unsigned grid = slots < (unsigned)resident[scale] ? slots : (unsigned)resident[scale];
+    if (scale) hipLaunchKernelGGL(icp_batch_kernel<true>, dim3(grid), dim3(256), 0, s, cam, a);
+    else hipLaunchKernelGGL(icp_batch_kernel<false>, dim3(grid), dim3(256), 0, s, cam, a);
     TL3D_HIP(hipGetLastError());
     return TL3D_OK;
 }

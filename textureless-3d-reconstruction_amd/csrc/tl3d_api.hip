@@ -1171,6 +1171,7 @@ int tl3d_icp_enqueue(tl3d_ctx *ctx, int lane, int slot_src, double scale_src, in
     if (ss.ev_upload) TL3D_HIP(hipStreamWaitEvent(ln.stream, ss.ev_upload, 0));
     if (st.ev_upload) TL3D_HIP(hipStreamWaitEvent(ln.stream, st.ev_upload, 0));
     if (st.ev_normals) TL3D_HIP(hipStreamWaitEvent(ln.stream, st.ev_normals, 0));
+    if (ss.smooth_radius > 0 && ss.ev_normals) TL3D_HIP(hipStreamWaitEvent(ln.stream, ss.ev_normals, 0));     // the averaged depth is written with the source's normal map
     IcpState *h = ln.host;
     memset(h, 0, sizeof(*h));
     if (T_init) {
