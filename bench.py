@@ -204,7 +204,7 @@ def main():
         # the product's merge: int32-headroom check + RCCL sum all-reduce on the library's own grid memory (zero-copy)
         if dist is not None:
             from tl3d.distributed import allreduce_context_grids, merge_context_grids
-            ctx.sync()
+            torch.cuda.synchronize(dev)                         # (not ctx.sync(): that would fold the free-space counts, which the merge sends as counts)
             tm = time.perf_counter()
             if world == 1:                                      # --force-dist: the RCCL path with one rank
                 info = allreduce_context_grids(ctx, dist)

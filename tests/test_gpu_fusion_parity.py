@@ -578,6 +578,44 @@ def test_icp_batch_matches_oracle_and_the_per_level_calls():
     assert np.linalg.norm(got[0]["T"] - ores["T"]) <= 1e-9 and got[0]["iters_run"] == ores["iters_run"] and got[0]["n_src"] == ores["n_src"]
 
 
+def test_brick_merge_sends_free_space_as_counts_and_records_only_where_there_are_records():
+    """The device form of the multi-GPU merge (tl3d.distributed.allreduce_context_grids) on one rank (gloo, world size 1: every
+    sum is the identity, so the grid must come out as the oracle's bit for bit): the pending free-space counts are summed as 4 bytes
+    per brick and stay pending, only bricks with records travel as records -- far fewer than the bricks a fold-first merge marks --
+    and the int32 headroom check sees the counts without folding them."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from tl3d.distributed import allreduce_context_grids
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    from tl3d import synth
+    poses, frames = small_scene_frames(n=6, deg=4.0, scene=synth.object_scene(with_room=True))     # every pixel valid: whole bricks of free space
+    ctx, orc = make_pair(dims=(128, 128, 128), voxel=0.02, centre=(0.0, -0.1, 0.0), n_slots=6)
+    with ctx:
+        for i, ((depth, bgr), pose) in enumerate(zip(frames, poses)):
+            ctx.upload(i, depth, bgr)
+            ctx.integrate(i, pose)
+            ctx.accumulate_centroid(i, pose, subsample=2)
+            orc.tsdf_integrate(depth, pose[0], pose[1])
+            orc.centroid_accumulate(depth, bgr, pose[0], pose[1], subsample=2)
+        assert ctx.max_weight() == int(orc.tsdf[:, 1].max())          # counts included, nothing folded
+        info = allreduce_context_grids(ctx, dist)
+        dev = torch.device("cuda", ctx.device)
+        folded = torch.zeros(ctx.n_bricks, dtype=torch.uint8, device=dev)
+        g = ctx.download_grid(tl3d.CH_TSDF)                           # (folds)
+        c = ctx.download_grid(tl3d.CH_CENTROID)
+        ctx.touched_bricks(folded, tl3d.CH_TSDF | tl3d.CH_CENTROID)
+        ctx.sync()
+        n_folded = int(folded.sum().item())
+    assert np.array_equal(g, orc.tsdf) and np.array_equal(c, orc.centroid)
+    assert info["bricks_total"] == 16 ** 3 and 0 < info["bricks_sent"] < info["bricks_total"] // 2
+    assert n_folded > info["bricks_sent"], (n_folded, info)           # a fold-first merge would also have packed the bricks that hold nothing but a count
+    assert info["bytes"] == info["bricks_sent"] * (4096 + 16384) + 5 * info["bricks_total"]
+
+
 def test_centroid_runs_of_every_length_and_the_point_list_path():
     """Runs of adjacent samples that share a voxel are summed in the wave (inside 16-lane rows) before the LDS table and
     the grid: voxels of 2 mm ... 40 cm give runs from 1 sample to whole rows (split at row boundaries), invalid pixels cut

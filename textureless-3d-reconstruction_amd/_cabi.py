@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("TL3D_LIB") or os.path.join(_HERE, "libtl3d.so")     #
 
 ABI_VERSION = 4
 OK, E_INVALID, E_HIP, E_NOMEM, E_CAPACITY, E_STATE, E_NODEVICE = 0, -1, -2, -3, -4, -5, -6
-CH_TSDF, CH_CENTROID = 1, 2
+CH_TSDF, CH_CENTROID, CH_FREE = 1, 2, 4
 DEPTH_F32_M, DEPTH_U16_MM = 0, 1
 F_SCALE_F64, F_NO_POSE = 1, 2
 EXTRACT_CENTROID, EXTRACT_TSDF = 0, 1

@@ -8,23 +8,31 @@
 
 namespace tl3d {
 
-// largest record weight over the pool slots in use (16-B loads, two records per lane; wave shuffle, one atomicMax per
-// workgroup) and, for bricks that have no records, their pending free-space count (readers see it as the weight)
-__global__ __launch_bounds__(256) void max_weight_kernel(const int4 *__restrict__ pool2, const unsigned *__restrict__ cursor, unsigned cap,
-                                                         const unsigned *__restrict__ free_cnt, unsigned nbricks, int *__restrict__ out) {
+// Largest weight a reader of the channel would see: per brick, the largest record weight (if the brick has records) PLUS the
+// brick's pending free-space count -- exact whether or not the counts have been folded into the records.  One wave per brick,
+// 16-B loads (two records per lane), wave shuffle, one atomicMax per workgroup.
+__global__ __launch_bounds__(256) void max_weight_kernel(Grid g, const int4 *__restrict__ pool2, const unsigned *__restrict__ free_cnt, unsigned nbricks,
+                                                         int *__restrict__ out) {
     __shared__ int sm[4];
+    const int lane = threadIdx.x & 63;
     int m = 0;
-    const unsigned used = min(cursor[0], cap);
-    const size_t n2 = (size_t)used << 8;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (size_t)gridDim.x * 256) {
-        const int4 r = pool2[i];
-        m = max(m, max(r.y, r.w));
+    for (unsigned b = blockIdx.x * 4u + (threadIdx.x >> 6); b < nbricks; b += gridDim.x * 4u) {
+        const unsigned slot = (unsigned)__builtin_amdgcn_readfirstlane((int)brick_slot(g.tsdf_tab, b));
+        int w = 0;
+        if (slot < SLOT_FULL) {
+            const int4 *r = pool2 + ((size_t)slot << 8);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int4 v = r[k * 64 + lane];
+                w = max(w, max(v.y, v.w));
+            }
+        }
+        if (free_cnt) w += (int)__builtin_amdgcn_readfirstlane((int)free_cnt[b]);
+        m = max(m, w);
     }
-    if (free_cnt)
-        for (unsigned b = blockIdx.x * 256u + threadIdx.x; b < nbricks; b += gridDim.x * 256u) m = max(m, (int)free_cnt[b]);
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) m = max(m, __shfl_down(m, d));
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    if (lane == 0) sm[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) atomicMax(out, max(max(sm[0], sm[1]), max(sm[2], sm[3])));
 }
@@ -32,7 +40,8 @@ __global__ __launch_bounds__(256) void max_weight_kernel(const int4 *__restrict_
 int launch_max_weight(hipStream_t s, const Grid &g, const int2 *pool, int *d_out) {
     TL3D_HIP(hipMemsetAsync(d_out, 0, sizeof(int), s));
     const unsigned nbricks = (unsigned)(g.nbx * g.nby * g.nbz);
-    hipLaunchKernelGGL(max_weight_kernel, dim3(2048), dim3(256), 0, s, reinterpret_cast<const int4 *>(pool), g.cursors, g.tsdf_cap, g.free_cnt, nbricks, d_out);
+    const unsigned nb = (nbricks + 3u) / 4u < 4096u ? (nbricks + 3u) / 4u : 4096u;
+    hipLaunchKernelGGL(max_weight_kernel, dim3(nb ? nb : 1), dim3(256), 0, s, g, reinterpret_cast<const int4 *>(pool), g.free_cnt, nbricks, d_out);
     TL3D_HIP(hipGetLastError());
     return TL3D_OK;
 }

@@ -1606,7 +1606,10 @@ int tl3d_grid_device_ptr(tl3d_ctx *ctx, uint32_t channel, void **ptr, size_t *by
     REQUIRE(ptr && bytes, TL3D_E_INVALID, "null out pointer");
     if (ctx && channel == TL3D_CH_FREE) {
         REQUIRE(ctx->free_cnt != nullptr, TL3D_E_STATE, "TSDF channel not enabled");
-        FLUSH_AND_FOLD(ctx);
+        FLUSH_UPDATES(ctx);                             // the counts as they stand (folded into the records or not: readers add what is pending)
+        ctx->free_dirty = true;                         // the caller may write through the pointer (a merge sums them)
+        ctx->tsdf_w_unknown = true;
+        ctx->grid_epoch++;
         *ptr = ctx->free_cnt;
         *bytes = (ctx->nvox >> 9) * sizeof(unsigned);
         return TL3D_OK;
@@ -1732,13 +1735,16 @@ int tl3d_grid_add(tl3d_ctx *ctx, uint32_t channel, const void *other, size_t byt
 
 int tl3d_grid_touched_bricks(tl3d_ctx *ctx, uint32_t channels, uint8_t *map_dev, int64_t n_bricks) {
     REQUIRE(ctx && map_dev, TL3D_E_INVALID, "null argument");
+    const bool counts_apart = (channels & TL3D_CH_FREE) != 0;      // the free-space counts travel on their own (tl3d.h)
+    channels &= ~TL3D_CH_FREE;
     if (channels == 0) channels = (ctx->tsdf ? TL3D_CH_TSDF : 0u) | (ctx->centroid ? TL3D_CH_CENTROID : 0u);
     REQUIRE((channels & ~(TL3D_CH_TSDF | TL3D_CH_CENTROID)) == 0, TL3D_E_INVALID, "bad channel mask 0x%x", channels);
     if (channels & TL3D_CH_TSDF) REQUIRE(ctx->tsdf != nullptr, TL3D_E_STATE, "TSDF channel not enabled");
     if (channels & TL3D_CH_CENTROID) REQUIRE(ctx->centroid != nullptr, TL3D_E_STATE, "centroid channel not enabled");
     REQUIRE(n_bricks == (int64_t)(ctx->nvox >> 9), TL3D_E_INVALID, "the grid has %zu bricks, the map %lld", ctx->nvox >> 9, (long long)n_bricks);
     REQUIRE(is_device_ptr(map_dev), TL3D_E_INVALID, "the brick map must be device memory");
-    FLUSH_AND_FOLD(ctx);
+    if (counts_apart) FLUSH_UPDATES(ctx);
+    else FLUSH_AND_FOLD(ctx);
     TL3D_HIP(hipSetDevice(ctx->device));
     return launch_touched_bricks(ctx->stream, ctx->grid, (channels & TL3D_CH_TSDF) ? ctx->tsdf : nullptr, (channels & TL3D_CH_CENTROID) ? ctx->centroid : nullptr,
                                  (unsigned)n_bricks, map_dev);
@@ -1747,12 +1753,15 @@ int tl3d_grid_touched_bricks(tl3d_ctx *ctx, uint32_t channels, uint8_t *map_dev,
 static int brick_rows(tl3d_ctx *ctx, uint32_t channel, const uint32_t *bricks_dev, int64_t n, void *packed_dev, bool pack) {
     void *p;
     size_t nb;
+    const bool counts_apart = (channel & TL3D_CH_FREE) != 0;       // records only: pending free-space counts stay pending
+    channel &= ~TL3D_CH_FREE;
     int rc = grid_sel(ctx, channel, &p, &nb);
     if (rc) return rc;
     REQUIRE(n >= 0 && n <= (int64_t)(ctx->nvox >> 9), TL3D_E_INVALID, "brick count %lld out of range", (long long)n);
     if (n == 0) return TL3D_OK;
     REQUIRE(bricks_dev && packed_dev && is_device_ptr(bricks_dev) && is_device_ptr(packed_dev), TL3D_E_INVALID, "brick list and block must be device memory");
-    FLUSH_AND_FOLD(ctx);
+    if (counts_apart) FLUSH_UPDATES(ctx);
+    else FLUSH_AND_FOLD(ctx);
     ctx->grid_epoch++;
     TL3D_HIP(hipSetDevice(ctx->device));
     if (!pack && channel == TL3D_CH_TSDF) ctx->tsdf_w_unknown = true;      // the records now hold what the caller summed
@@ -1770,7 +1779,7 @@ int tl3d_grid_unpack_bricks(tl3d_ctx *ctx, uint32_t channel, const uint32_t *bri
 int tl3d_grid_max_weight(tl3d_ctx *ctx, int64_t *out) {
     REQUIRE(ctx && out, TL3D_E_INVALID, "null argument");
     REQUIRE(ctx->tsdf != nullptr, TL3D_E_STATE, "TSDF channel not enabled");
-    FLUSH_AND_FOLD(ctx);
+    FLUSH_UPDATES(ctx);                                 // (pending free-space counts are added per brick by the kernel: no fold needed)
     TL3D_HIP(hipSetDevice(ctx->device));
     long long w = 0;
     const int rc = measure_max_weight(ctx, ctx->tsdf, &w);

@@ -122,7 +122,9 @@ def allreduce_context_grids(ctx, dist, sparse: bool = True) -> dict:
     import torch
     dev = torch.device("cuda", ctx.device)
     on_device = dist.get_backend() == "nccl"
-    ctx.sync()
+    # (device-wide waits below are torch's: tl3d_sync would fold the pending free-space counts into the records, and from the brick
+    # map to the unpack nothing may do that)
+    wait = torch.cuda.synchronize
     ch = ctx.grid.channels
     if ch & abi.CH_TSDF:
         _headroom_check(ctx, dist)
@@ -139,36 +141,48 @@ def allreduce_context_grids(ctx, dist, sparse: bool = True) -> dict:
         t.copy_(h)
         return t
 
+    # The free-space observations of a frame-sharded run cover most of the volume between the cameras and the surfaces, but they
+    # are ONE count per brick (tl3d.h: TL3D_CH_FREE), pending until something reads the channel.  They travel as what they are --
+    # 4 bytes per brick, summed -- and only bricks with RECORDS (a surface came within the truncation band, or a point fell in)
+    # travel as records.  Folded first (as until round 3), every brick a camera ever looked through would go as 4 KB of records.
     idx = None
+    free_apart = bool(ch & abi.CH_TSDF)
+    fl = abi.CH_FREE if free_apart else 0
     if sparse:
         m = torch.zeros(nbr, dtype=torch.uint8, device=dev)
-        ctx.touched_bricks(m, ch)
-        ctx.sync()
+        ctx.touched_bricks(m, ch | fl)
+        wait()
         reduce_(m, dist.ReduceOp.MAX)
         idx = torch.nonzero(m, as_tuple=False).flatten().to(torch.int32)
         if 2 * idx.numel() >= nbr:
             idx = None
     if idx is None:
         if ch & abi.CH_TSDF:
-            reduce_(ctx.grid_tensor(abi.CH_TSDF))
+            reduce_(ctx.grid_tensor(abi.CH_TSDF))            # (folds the pending counts into the records first)
         if ch & abi.CH_CENTROID:
             reduce_(ctx.grid_tensor(abi.CH_CENTROID))
         torch.cuda.synchronize()
         return dict(bricks_sent=nbr, bricks_total=nbr, bytes=nbr * row_bytes)
     n = int(idx.numel())
+    if free_apart:
+        cnt = ctx.grid_tensor(abi.CH_FREE)
+        wait()
+        reduce_(cnt)                                         # every rank now holds the scan's counts, still pending
+        wait()
     if n:
         for channel, words, dt in ((abi.CH_TSDF, 1024, torch.int32), (abi.CH_CENTROID, 2048, torch.int64)):
             if not ch & channel:
                 continue
             block = torch.empty((n, words), dtype=dt, device=dev)
-            ctx.pack_bricks(channel, idx, block)
-            ctx.sync()
+            ctx.pack_bricks(channel | (fl if channel == abi.CH_TSDF else 0), idx, block)
+            wait()
             reduce_(block)
-            ctx.unpack_bricks(channel, idx, block)
-            ctx.sync()
+            wait()
+            ctx.unpack_bricks(channel | (fl if channel == abi.CH_TSDF else 0), idx, block)
+            wait()
             del block
     torch.cuda.synchronize()
-    return dict(bricks_sent=n, bricks_total=nbr, bytes=n * row_bytes + nbr)
+    return dict(bricks_sent=n, bricks_total=nbr, bytes=n * row_bytes + nbr + (4 * nbr if free_apart else 0))
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -411,7 +411,9 @@ class FusionContext:
         return self.grid.nvox // 512
 
     def touched_bricks(self, map_dev, channels: int = 0):
-        """map_dev[b] |= 1 (uint8, one per brick, device memory, zeroed by the caller) for every brick that holds anything."""
+        """map_dev[b] |= 1 (uint8, one per brick, device memory, zeroed by the caller) for every brick that holds anything.
+        With abi.CH_FREE in `channels` (and in the channel of pack_bricks / unpack_bricks) pending free-space counts stay pending
+        and mark nothing: they travel on their own, as grid_tensor(abi.CH_FREE)."""
         abi.check(self._lib.tl3d_grid_touched_bricks(self._h, int(channels), abi.ptr(map_dev), int(self.n_bricks)))
 
     def pack_bricks(self, channel: int, bricks_dev, packed_dev):
@@ -445,7 +447,7 @@ class FusionContext:
         """Zero-copy torch view of a grid channel (for torch.distributed all_reduce over RCCL)."""
         import torch
         p, nb = self.grid_ptr(channel)
-        dt, item, typestr = (torch.int32, 4, "<i4") if channel == abi.CH_TSDF else (torch.int64, 8, "<i8")
+        dt, item, typestr = (torch.int32, 4, "<i4") if channel in (abi.CH_TSDF, abi.CH_FREE) else (torch.int64, 8, "<i8")
 
         class _Iface:
             __cuda_array_interface__ = {"shape": (nb // item,), "typestr": typestr, "data": (p, False), "version": 2}
