@@ -125,9 +125,10 @@ __device__ __forceinline__ void ld_depth4(const uint16_t *__restrict__ p, size_t
 }
 
 // ---- 1. depth tiles --------------------------------------------------------------------------------------
-// One 32x32-pixel region per workgroup pass: 8 lanes x 16 B cover a region row, 32 rows -> 256 threads.  Wave w holds rows
-// 8w .. 8w+7 = one row of four level-0 tiles (lanes with equal q4 >> 1); the region's level-1 and level-2 tiles are combined
-// through LDS.
+// One 32x32-pixel region per WAVE: 8 lanes x 16 B cover a region row, a wave 8 rows, four passes the region -- a lane's four
+// 16-B loads are issued before the first is looked at.  A pass is one row of four level-0
+// tiles (lanes with equal q4 >> 1); level-1 and level-2 tiles are combined in registers (min / max / or over lane bits: the same
+// values whatever the order).  No LDS, no workgroup barrier.
 template <typename DT>
 __global__ __launch_bounds__(256) void depth_tiles_kernel(Cam cam, BatchBufs B, Pyramid py, int nrx, int nry) {
     const DescPtr F = const_descs(B) + blockIdx.y;
@@ -135,88 +136,86 @@ __global__ __launch_bounds__(256) void depth_tiles_kernel(Cam cam, BatchBufs B, 
     const DT *__restrict__ depth = static_cast<const DT *>(F->depth);
     float4 *__restrict__ tiles = F->tiles;
     float2 *__restrict__ vtile = F->vtile;
-    __shared__ float s_mn[4][4], s_mx[4][4];
-    __shared__ int s_bad[4][4];
     if (blockIdx.x == 0 && threadIdx.x < 2) F->counts[threadIdx.x] = 0u;        // reset the frame's list cursors
     if (blockIdx.x == 0 && blockIdx.y == 0) {                                    // and the batch list's, and the update's ticket counters
         if (threadIdx.x == 2) B.hdr[0] = 0u;
         if (threadIdx.x >= 64 && threadIdx.x < 64 + TICKET_GROUPS) B.hdr[HDR_TICKETS + 16u * (threadIdx.x - 64)] = 0u;
     }
-    const int q4 = threadIdx.x & 7, row = threadIdx.x >> 3, wid = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int q4 = lane & 7, row8 = lane >> 3;
     const bool vec = (cam.W & 3) == 0;                              // rows are 16-B aligned
-    // the thread's four pixels of a region; the next region's are requested before this one's are looked at
-    auto fetch = [&](int region, float dd[4]) {
+    for (int region = blockIdx.x * 4 + wid; region < nrx * nry; region += gridDim.x * 4) {
         const int rx = region % nrx, ry = region / nrx;
-        const int u0 = rx * REGION + q4 * 4, v = ry * REGION + row;
-        dd[0] = dd[1] = dd[2] = dd[3] = 0.0f;
-        if (region < nrx * nry && v < cam.H && u0 < cam.W) {
-            if (vec) {
-                ld_depth4(depth, (size_t)v * cam.W + u0, dd);
-            } else {
-                const int nv = min(4, cam.W - u0);
-                for (int k = 0; k < 4; ++k) dd[k] = (k < nv) ? ld_depth(depth, (size_t)v * cam.W + u0 + k) : 0.0f;
-            }
-        }
-    };
-    float dn[4];
-    fetch(blockIdx.x, dn);
-    for (int region = blockIdx.x; region < nrx * nry; region += gridDim.x) {
-        const int rx = region % nrx, ry = region / nrx;
-        float mn = INFINITY, mx = -INFINITY;
-        int bad = 0;
-        const int u0 = rx * REGION + q4 * 4, v = ry * REGION + row;
-        float dd[4] = {dn[0], dn[1], dn[2], dn[3]};
-        fetch(region + (int)gridDim.x, dn);
-        if (v < cam.H && u0 < cam.W) {
-            const int nv = min(4, cam.W - u0);
+        const int u0 = rx * REGION + q4 * 4;
+        const int nv = min(4, cam.W - u0);
+        float dd[4][4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (k < nv) {
-                    const float d = dd[k] * c.sc;
-                    if (d > c.mind && d < c.maxd) {
-                        mn = fminf(mn, d);
-                        mx = fmaxf(mx, d);
-                    } else {
-                        bad = 1;
-                    }
+        for (int i = 0; i < 4; ++i) {                               // pass i: rows 8 i + row8
+            const int v = ry * REGION + 8 * i + row8;
+            dd[i][0] = dd[i][1] = dd[i][2] = dd[i][3] = 0.0f;
+            if (v < cam.H && u0 < cam.W) {
+                if (vec) {
+                    ld_depth4(depth, (size_t)v * cam.W + u0, dd[i]);
+                } else {
+                    for (int k = 0; k < 4; ++k) dd[i][k] = (k < nv) ? ld_depth(depth, (size_t)v * cam.W + u0 + k) : 0.0f;
                 }
+            }
         }
-        // level 0: lanes (row & 7, q4) with equal q4 >> 1: butterfly over lane bits 0, 3, 4, 5
+        float mn[4], mx[4];
+        int bad[4];
 #pragma unroll
-        for (int d = 1; d <= 32; d = (d == 1 ? 8 : d << 1)) {
-            mn = fminf(mn, __shfl_xor(mn, d));
-            mx = fmaxf(mx, __shfl_xor(mx, d));
-            bad |= __shfl_xor(bad, d);
-        }
-        const int lane = threadIdx.x & 63;
-        if ((lane & 0x39) == 0) {                                   // lanes 0, 2, 4, 6: one per level-0 tile of this wave
-            const int ax = lane >> 1;
-            const int tx = rx * 4 + ax, ty = ry * 4 + wid;
-            if (tx < py.ntx[0] && ty < py.nty[0]) {
-                tiles[py.off[0] + ty * py.ntx[0] + tx] = make_float4(mn, mx, bad ? 0.0f : 1.0f, 0.0f);
-                // (lowest depth if EVERY pixel is valid, else -inf: "never surely free"; highest valid depth, -inf if none: "skip")
-                vtile[ty * py.ntx[0] + tx] = make_float2(bad ? -INFINITY : mn, mx);
+        for (int i = 0; i < 4; ++i) {
+            const int v = ry * REGION + 8 * i + row8;
+            mn[i] = INFINITY; mx[i] = -INFINITY; bad[i] = 0;
+            if (v < cam.H && u0 < cam.W) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < nv) {
+                        const float d = dd[i][k] * c.sc;
+                        if (d > c.mind && d < c.maxd) {
+                            mn[i] = fminf(mn[i], d);
+                            mx[i] = fmaxf(mx[i], d);
+                        } else {
+                            bad[i] = 1;
+                        }
+                    }
             }
-            s_mn[wid][ax] = mn; s_mx[wid][ax] = mx; s_bad[wid][ax] = bad;
-        }
-        __syncthreads();
-        if (threadIdx.x < 5) {
-            // threads 0..3: the region's level-1 tiles; thread 4: its level-2 tile
-            const int l1x = threadIdx.x & 1, l1y = (threadIdx.x >> 1) & 1;
-            const int x0 = threadIdx.x < 4 ? 2 * l1x : 0, x1 = threadIdx.x < 4 ? x0 + 2 : 4;
-            const int y0 = threadIdx.x < 4 ? 2 * l1y : 0, y1 = threadIdx.x < 4 ? y0 + 2 : 4;
-            float a = INFINITY, b = -INFINITY;
-            int bd = 0;
-            for (int y = y0; y < y1; ++y)
-                for (int x = x0; x < x1; ++x) { a = fminf(a, s_mn[y][x]); b = fmaxf(b, s_mx[y][x]); bd |= s_bad[y][x]; }
-            if (threadIdx.x < 4) {
-                const int tx = rx * 2 + l1x, ty = ry * 2 + l1y;
-                if (py.nlev > 1 && tx < py.ntx[1] && ty < py.nty[1]) tiles[py.off[1] + ty * py.ntx[1] + tx] = make_float4(a, b, bd ? 0.0f : 1.0f, 0.0f);
-            } else if (py.nlev > 2) {
-                tiles[py.off[2] + ry * py.ntx[2] + rx] = make_float4(a, b, bd ? 0.0f : 1.0f, 0.0f);
+            // level 0: lanes with equal q4 >> 1: butterfly over lane bits 0, 3, 4, 5
+#pragma unroll
+            for (int d = 1; d <= 32; d = (d == 1 ? 8 : d << 1)) {
+                mn[i] = fminf(mn[i], __shfl_xor(mn[i], d));
+                mx[i] = fmaxf(mx[i], __shfl_xor(mx[i], d));
+                bad[i] |= __shfl_xor(bad[i], d);
+            }
+            if ((lane & 0x39) == 0) {                               // lanes 0, 2, 4, 6: one per level-0 tile of this pass
+                const int tx = rx * 4 + (lane >> 1), ty = ry * 4 + i;
+                if (tx < py.ntx[0] && ty < py.nty[0]) {
+                    tiles[py.off[0] + ty * py.ntx[0] + tx] = make_float4(mn[i], mx[i], bad[i] ? 0.0f : 1.0f, 0.0f);
+                    // (lowest depth if EVERY pixel is valid, else -inf: "never surely free"; highest valid depth, -inf if none: "skip")
+                    vtile[ty * py.ntx[0] + tx] = make_float2(bad[i] ? -INFINITY : mn[i], mx[i]);
+                }
             }
         }
-        __syncthreads();
+        // level 1: 2 x 2 level-0 tiles = passes (2 j, 2 j + 1) and lane bit 1; level 2: all of it
+        float a2 = INFINITY, b2 = -INFINITY;
+        int bd2 = 0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float a = fminf(mn[2 * j], mn[2 * j + 1]), b = fmaxf(mx[2 * j], mx[2 * j + 1]);
+            int bd = bad[2 * j] | bad[2 * j + 1];
+            a = fminf(a, __shfl_xor(a, 2));
+            b = fmaxf(b, __shfl_xor(b, 2));
+            bd |= __shfl_xor(bd, 2);
+            if ((lane & 0x3b) == 0 && py.nlev > 1) {                // lanes 0, 4
+                const int tx = rx * 2 + (lane >> 2), ty = ry * 2 + j;
+                if (tx < py.ntx[1] && ty < py.nty[1]) tiles[py.off[1] + ty * py.ntx[1] + tx] = make_float4(a, b, bd ? 0.0f : 1.0f, 0.0f);
+            }
+            a2 = fminf(a2, a); b2 = fmaxf(b2, b); bd2 |= bd;
+        }
+        a2 = fminf(a2, __shfl_xor(a2, 4));
+        b2 = fmaxf(b2, __shfl_xor(b2, 4));
+        bd2 |= __shfl_xor(bd2, 4);
+        if (lane == 0 && py.nlev > 2) tiles[py.off[2] + ry * py.ntx[2] + rx] = make_float4(a2, b2, bd2 ? 0.0f : 1.0f, 0.0f);
     }
 }
 
@@ -922,9 +921,9 @@ int launch_tsdf_prepare(hipStream_t s, const Cam &cam, const Grid &g, int n, int
     const int nrx = (cam.W + REGION - 1) / REGION, nry = (cam.H + REGION - 1) / REGION;
     const int nreg = nrx * nry;
     if (depth_u16)
-        hipLaunchKernelGGL(depth_tiles_kernel<uint16_t>, dim3(nreg < 512 ? nreg : 512, n), dim3(256), 0, s, cam, B, py, nrx, nry);
+        hipLaunchKernelGGL(depth_tiles_kernel<uint16_t>, dim3((nreg + 3) / 4 < 512 ? (nreg + 3) / 4 : 512, n), dim3(256), 0, s, cam, B, py, nrx, nry);
     else
-        hipLaunchKernelGGL(depth_tiles_kernel<float>, dim3(nreg < 512 ? nreg : 512, n), dim3(256), 0, s, cam, B, py, nrx, nry);
+        hipLaunchKernelGGL(depth_tiles_kernel<float>, dim3((nreg + 3) / 4 < 512 ? (nreg + 3) / 4 : 512, n), dim3(256), 0, s, cam, B, py, nrx, nry);
     TL3D_HIP(hipGetLastError());
     hipLaunchKernelGGL(tile_pyramid_kernel, dim3(n), dim3(256), 0, s, cam, py, B);
     TL3D_HIP(hipGetLastError());
