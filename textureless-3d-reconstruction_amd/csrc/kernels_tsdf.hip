@@ -68,6 +68,7 @@ struct FrameDesc {
     unsigned *counts;                    // [0] listed bricks, [1] free-space bricks (counted)
     unsigned short *sub;                 // [nbricks] sub-brick masks of its listed bricks: bits 0-7 mixed, bits 8-15 free
     float2 *vtile;                       // level-0 tiles once more, 8 B each, as the update kernel's per-voxel test wants them (below)
+    unsigned *cells;                     // the 4x4x4-brick cells whose bounding sphere meets the view (the cull kernel's work list); count: counts[CELL_COUNT]
 };
 
 // what all frames of a batch share
@@ -223,11 +224,46 @@ __global__ __launch_bounds__(256) void depth_tiles_kernel(Cam cam, BatchBufs B, 
 // Also finds ONE PIXEL OF THE FRAME THAT IS VALID (the top-left pixel of an all-valid tile; counts[VALID_PIXEL]): where the update
 // kernel sends the lanes whose depth value cannot matter (below).
 constexpr int VALID_PIXEL = 32;          // word of a frame's counts block
-__global__ __launch_bounds__(256) void tile_pyramid_kernel(Cam cam, Pyramid py, BatchBufs B) {
+constexpr int CELL_COUNT = 48;           // word of a frame's counts block: length of the frame's cell list
+__device__ __forceinline__ bool sphere_in_view(const Frustum &fr, float x, float y, float z, float rad) {
+    return (z + rad > 0.0f) && (fr.lx * x + fr.lz * z >= -rad) && (fr.rx * x + fr.rz * z >= -rad) &&
+           (fr.ty * y + fr.tz * z >= -rad) && (fr.by * y + fr.bz * z >= -rad);
+}
+
+// ... and the frame's CELL LIST: the 4x4x4-brick cells whose bounding sphere meets the view (one in five on the headline orbit), so
+// that the brick classification starts waves only for those.
+__global__ __launch_bounds__(256) void tile_pyramid_kernel(Cam cam, Grid g, Frustum fr, Pyramid py, BatchBufs B) {
     float4 *__restrict__ tiles = const_descs(B)[blockIdx.x].tiles;
-    __shared__ unsigned s_found;
-    if (threadIdx.x == 0) s_found = 0xffffffffu;
+    __shared__ unsigned s_found, s_ncell;
+    if (threadIdx.x == 0) { s_found = 0xffffffffu; s_ncell = 0u; }
     __syncthreads();
+    {
+        const DescPtr F = const_descs(B) + blockIdx.x;
+        const PoseF pose = desc_pose(F);
+        unsigned *__restrict__ cells = F->cells;
+        const int ncx = (g.nbx + 3) >> 2, ncy = (g.nby + 3) >> 2, ncz = (g.nbz + 3) >> 2;
+        const float crad = 27.712812f * g.vs * 1.01f;               // half diagonal of a 32^3-voxel cell, +1 % (the cull kernel's own test)
+        for (int c0 = 0; c0 < ncx * ncy * ncz; c0 += 256) {
+            const int cell = c0 + (int)threadIdx.x;
+            bool in = false;
+            if (cell < ncx * ncy * ncz) {
+                const int ccx = cell % ncx, ccy = (cell / ncx) % ncy, ccz = cell / (ncx * ncy);
+                const float qx = fmaf((float)(ccx * 32 + 16), g.vs, g.ox), qy = fmaf((float)(ccy * 32 + 16), g.vs, g.oy);
+                const float qz = fmaf((float)(ccz * 32 + 16), g.vs, g.oz);
+                const float ex = pose.r[0] * qx + pose.r[1] * qy + pose.r[2] * qz + pose.t[0];
+                const float ey = pose.r[3] * qx + pose.r[4] * qy + pose.r[5] * qz + pose.t[1];
+                const float ez = pose.r[6] * qx + pose.r[7] * qy + pose.r[8] * qz + pose.t[2];
+                in = sphere_in_view(fr, ex, ey, ez, crad);
+            }
+            const unsigned long long m = __ballot(in);
+            unsigned base = 0;
+            if ((threadIdx.x & 63) == 0 && m) base = atomicAdd(&s_ncell, (unsigned)__popcll(m));
+            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+            if (in) cells[base + __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull))] = (unsigned)cell;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) F->counts[CELL_COUNT] = s_ncell;
+    }
     for (int L = min(2, py.nlev - 1); L >= 0; L -= 2) {           // 32-pixel tiles first; only a frame full of holes needs the 8-pixel ones
         const int n = py.ntx[L] * py.nty[L];
         for (int i = threadIdx.x; i < n; i += 256)
@@ -267,15 +303,9 @@ __global__ __launch_bounds__(256) void tile_pyramid_kernel(Cam cam, Pyramid py, 
 }
 
 // ---- 3. brick classification ------------------------------------------------------------------------------
-// One wave per cell of 4x4x4 bricks, one lane per brick.  A cell whose bounding sphere misses the view exits after
-// a handful of instructions (most of the grid); the four waves of a workgroup pool their survivors so the list
+// One wave per LISTED cell of 4x4x4 bricks (the frame's cell list: cells whose bounding sphere meets the view), one lane per brick; the four waves of a workgroup pool their survivors so the list
 // cursors see one atomic per workgroup, not per wave (same-address returning atomics retire at ~90 per microsecond).
 // Margins: 1.5 px on projected bounds, 1 % of a voxel on depths, 0.1 % on the truncation distance.
-__device__ __forceinline__ bool sphere_in_view(const Frustum &fr, float x, float y, float z, float rad) {
-    return (z + rad > 0.0f) && (fr.lx * x + fr.lz * z >= -rad) && (fr.rx * x + fr.rz * z >= -rad) &&
-           (fr.ty * y + fr.tz * z >= -rad) && (fr.by * y + fr.bz * z >= -rad);
-}
-
 // The three rules on one box of voxels, given what the pyramid says about the pixels under it: a = (min, max, all-valid) of
 // the valid scaled depth over a superset of the box's pixel footprint, [zmin, zmax] the camera depths of its voxel centres,
 // inside = the footprint (widened by 1.5 px) lies wholly in the image.  0 skip, 1 mixed, 2 free.
@@ -296,10 +326,15 @@ __global__ __launch_bounds__(256) void brick_cull_kernel(Cam cam, Grid g, BatchB
     __shared__ unsigned s_base[3];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int ncx = (g.nbx + 3) >> 2, ncy = (g.nby + 3) >> 2, ncz = (g.nbz + 3) >> 2;
-    const int cell = blockIdx.x * 4 + wid;
+    // the frame's cell list (tile_pyramid_kernel): four cells per workgroup and trip
+    const unsigned ncell = min(F->counts[CELL_COUNT], (unsigned)(ncx * ncy * ncz));
+    const unsigned *__restrict__ cells = F->cells;
+    for (unsigned quad = blockIdx.x; quad * 4u < ncell; quad += gridDim.x) {
+    const unsigned li = quad * 4u + (unsigned)wid;
+    const int cell = li < ncell ? (int)min(cells[li], (unsigned)(ncx * ncy * ncz - 1)) : -1;
     int cls = 0;                                                  // 0 skip, 1 mixed, 2 free
     int brick = 0;
-    if (cell < ncx * ncy * ncz) {
+    if (cell >= 0) {
         const int ccx = cell % ncx, ccy = (cell / ncx) % ncy, ccz = cell / (ncx * ncy);
         const int bx = ccx * 4 + (lane & 3), by = ccy * 4 + ((lane >> 2) & 3), bz = ccz * 4 + (lane >> 4);
         const bool in_grid = bx < g.nbx && by < g.nby && bz < g.nbz;
@@ -397,6 +432,8 @@ __global__ __launch_bounds__(256) void brick_cull_kernel(Cam cam, Grid g, BatchB
     const unsigned long long below = (1ull << lane) - 1ull;
     if (cls == 1) list[bm + __popcll(mm & below)] = (unsigned)brick;
     if (first) B.list[b1 + __popcll(m1 & below)] = (unsigned)brick;
+    __syncthreads();                                               // s_cnt / s_base are reused by the next trip
+    }
 }
 
 // records += count x (32767, 1) for every brick with a pending free-space count; the count returns to zero (exchanged, so a
@@ -837,7 +874,7 @@ static size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 // Scratch of ONE batch in flight (the context keeps two and alternates):
 //   [descriptors (max_frames)] [header 256 B] [batch list] [frame masks] then per frame [counts 256 B] [tile pyramid] [list] [sub-brick masks] [8-B level-0 tiles]
 struct BatchLayout {
-    size_t off_desc, off_hdr, off_list, off_mask, off_frames, per_frame, f_counts, f_tiles, f_list, f_sub, f_vt, total;
+    size_t off_desc, off_hdr, off_list, off_mask, off_frames, per_frame, f_counts, f_tiles, f_list, f_sub, f_vt, f_cells, total;
 };
 static BatchLayout batch_layout(const Cam &cam, const Grid &g, int max_frames) {
     const Pyramid p = make_pyramid(cam);
@@ -853,7 +890,9 @@ static BatchLayout batch_layout(const Cam &cam, const Grid &g, int max_frames) {
     L.f_list = L.f_tiles + up256(pyramid_tiles(p) * sizeof(float4));
     L.f_sub = L.f_list + up256((nbricks + 64) * sizeof(unsigned));
     L.f_vt = L.f_sub + up256(nbricks * sizeof(unsigned short));
-    L.per_frame = L.f_vt + up256((size_t)p.ntx[0] * p.nty[0] * sizeof(float2));
+    L.f_cells = L.f_vt + up256((size_t)p.ntx[0] * p.nty[0] * sizeof(float2));
+    const size_t ncells = (size_t)((g.nbx + 3) / 4) * ((g.nby + 3) / 4) * ((g.nbz + 3) / 4);
+    L.per_frame = L.f_cells + up256((ncells + 4) * sizeof(unsigned));
     L.total = L.off_frames + L.per_frame * (size_t)max_frames;
     return L;
 }
@@ -908,6 +947,7 @@ int launch_tsdf_prepare(hipStream_t s, const Cam &cam, const Grid &g, int n, int
         d[i].list = reinterpret_cast<unsigned *>(fb + L.f_list);
         d[i].sub = reinterpret_cast<unsigned short *>(fb + L.f_sub);
         d[i].vtile = reinterpret_cast<float2 *>(fb + L.f_vt);
+        d[i].cells = reinterpret_cast<unsigned *>(fb + L.f_cells);
     }
     for (int i0 = 0; i0 < n; i0 += 16) {
         DescChunk ch;
@@ -925,10 +965,11 @@ int launch_tsdf_prepare(hipStream_t s, const Cam &cam, const Grid &g, int n, int
     else
         hipLaunchKernelGGL(depth_tiles_kernel<float>, dim3((nreg + 3) / 4 < 512 ? (nreg + 3) / 4 : 512, n), dim3(256), 0, s, cam, B, py, nrx, nry);
     TL3D_HIP(hipGetLastError());
-    hipLaunchKernelGGL(tile_pyramid_kernel, dim3(n), dim3(256), 0, s, cam, py, B);
+    hipLaunchKernelGGL(tile_pyramid_kernel, dim3(n), dim3(256), 0, s, cam, g, fr, py, B);
     TL3D_HIP(hipGetLastError());
     const int ncells = ((g.nbx + 3) / 4) * ((g.nby + 3) / 4) * ((g.nbz + 3) / 4);
-    hipLaunchKernelGGL(brick_cull_kernel, dim3((ncells + 3) / 4, n), dim3(256), 0, s, cam, g, B, fr, py, free_cnt);
+    const int nquad = (ncells + 3) / 4;                 // the cells in view are known only on the device: a fixed grid strides over each frame's list
+    hipLaunchKernelGGL(brick_cull_kernel, dim3(nquad < 256 ? nquad : 256, n), dim3(256), 0, s, cam, g, B, fr, py, free_cnt);
     TL3D_HIP(hipGetLastError());
     // sub-brick masks of the listed bricks (their number is known only on the device: a fixed grid strides over each list)
     const int nbricks = g.nbx * g.nby * g.nbz;
