@@ -150,17 +150,20 @@ def allreduce_context_grids(ctx, dist, sparse: bool = True) -> dict:
     fl = abi.CH_FREE if free_apart else 0
     if sparse:
         m = torch.zeros(nbr, dtype=torch.uint8, device=dev)
+        wait()                                               # torch fills m on ITS stream; the library marks bricks on the context's
         ctx.touched_bricks(m, ch | fl)
         wait()
         reduce_(m, dist.ReduceOp.MAX)
         idx = torch.nonzero(m, as_tuple=False).flatten().to(torch.int32)
+        wait()                                               # (the conversion, too, runs on torch's stream)
         if 2 * idx.numel() >= nbr:
             idx = None
     if idx is None:
-        if ch & abi.CH_TSDF:
-            reduce_(ctx.grid_tensor(abi.CH_TSDF))            # (folds the pending counts into the records first)
-        if ch & abi.CH_CENTROID:
-            reduce_(ctx.grid_tensor(abi.CH_CENTROID))
+        for channel in (abi.CH_TSDF, abi.CH_CENTROID):
+            if ch & channel:
+                t = ctx.grid_tensor(channel)                 # (TSDF: folds the pending counts into the records first, on the context's stream)
+                wait()
+                reduce_(t)
         torch.cuda.synchronize()
         return dict(bricks_sent=nbr, bricks_total=nbr, bytes=nbr * row_bytes)
     n = int(idx.numel())
