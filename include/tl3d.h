@@ -217,14 +217,14 @@ int tl3d_points_bounds(tl3d_ctx *ctx, const float *xyz_hd, int64_t n, double out
 /* a11: TSDF integration of one frame (no reference code; convention in DESIGN.md).
  * Free space: a brick (8^3 voxels) that lies wholly in front of everything the frame sees would get (+32767, +1) on each
  * of its 512 records; the library adds 1 to a per-brick counter instead and folds the pending counts into the records
- * before anything can read the TSDF channel (tl3d_grid_device_ptr, tl3d_grid_download, tl3d_grid_add, tl3d_extract,
- * tl3d_grid_max_weight, tl3d_sync), so the channel's contents are the same bit for bit.  TL3D_FREE_COUNTERS=0 in the
- * environment streams the records every frame instead (the round-1 behaviour).
- * The frame's classification kernels are enqueued at once on side streams; its grid update is issued together with
- * those of the following calls (batches of up to 32 by default, TL3D_TSDF_BATCH) so that the main stream pays one cross-stream
- * wait per batch.  Every other call that touches the grid or the slot, tl3d_sync, tl3d_event_record and
- * tl3d_grid_device_ptr issue the outstanding updates first, so results never depend on the batching; a caller that
- * works on a grid pointer obtained EARLIER must call tl3d_grid_device_ptr (or tl3d_sync) again before using it. */
+ * before anything reads the TSDF channel's records (tl3d_grid_device_ptr, tl3d_grid_download, tl3d_grid_add, tl3d_extract,
+ * tl3d_sync), so the channel's contents are the same bit for bit (tl3d_grid_max_weight and the TL3D_CH_FREE forms of the merge
+ * calls work on records and counts as they stand).
+ * The frame joins a pending BATCH (up to 32 frames, one depth kind): the batch's classification kernels run on a side stream,
+ * then ONE update kernel on the context's stream reads and writes every touched record once for all its frames.  A batch is
+ * issued when it is full and whenever any other call touches the grid or a slot (tl3d_sync, tl3d_event_record and
+ * tl3d_grid_device_ptr included), so results never depend on the batching; a caller that works on a grid pointer obtained
+ * EARLIER must call tl3d_grid_device_ptr (or tl3d_sync) again before using it. */
 int tl3d_integrate(tl3d_ctx *ctx, int slot, const double R[9], const double t[3], double scale);
 /* The fusion loop of a sequence in one call (replaces D2R:625-659 per view): for i in 0..n-1, tl3d_integrate (when the TSDF
  * channel exists) and, when centroid_subsample >= 1 and the centroid channel exists, tl3d_accumulate_centroid of slots[i] with

@@ -130,8 +130,8 @@ constexpr int ICP_SLAB = 40;     // doubles per block partial: 30 sums of the po
 
 // TSDF updates are issued in batches of up to TL3D_TSDF_MAXBATCH frames (one bit per frame in a brick's frame mask): one prep
 // chain (5 launches) for the whole batch on the side stream, then ONE update launch on the main stream that reads and writes
-// every touched record once per batch.  Two batch scratch buffers alternate, so the prep of batch k+1 runs beside the update
-// of batch k.
+// every touched record once per batch.  Three batch scratch buffers are taken in turn, so the prep chains of batches k+1 and k+2
+// run beside the update of batch k.
 #define TL3D_TSDF_MAXBATCH 32
 constexpr int TSDF_SCRATCHES = 3;
 
@@ -154,7 +154,7 @@ struct tl3d_ctx {
     // scratch
     // TSDF integration is double-buffered over two streams: the tile/pyramid/cull kernels of frame i+1 run on
     // prep_stream while the update kernel of frame i streams the grid on the main stream.
-    hipStream_t prep_stream[4];  // consecutive frames take them in turn, so that many prep chains are in flight
+    hipStream_t prep_stream[4];  // consecutive BATCHES take them in turn (three by default: one per batch scratch)
     int n_prep_streams;
     void *tsdf_scratch[TSDF_SCRATCHES];   // batch scratch (descriptors, tile pyramids, brick lists, frame masks, sub-brick masks): three batches in flight
                                           // (the update of batch k, the prep chains of batches k+1 and k+2)
