@@ -616,6 +616,39 @@ def test_brick_merge_sends_free_space_as_counts_and_records_only_where_there_are
     assert info["bytes"] == info["bricks_sent"] * (4096 + 16384) + 5 * info["bricks_total"]
 
 
+def test_tsdf_on_ragged_image_sizes_is_bit_exact():
+    """Image widths that are not multiples of 4 (scalar loads in the tiles kernel), of 8 (partial level-0 tiles: their 8-B records
+    feed the per-voxel test) or of 32 (partial regions), a one-region image, holes and out-of-range depths: f32 and 16-bit
+    frames, a batch of several frames per launch, against the every-voxel oracle."""
+    from helpers import c_oracle
+    from tl3d import synth
+    scene = synth.object_scene(with_room=True)
+    rng = np.random.default_rng(5)
+    for (w, h) in ((173, 131), (97, 64), (31, 29), (200, 152)):
+        cam = dict(width=w, height=h, fx=0.9 * w, fy=0.9 * w, cx=0.5 * w - 0.5, cy=0.5 * h - 0.5)
+        poses = synth.orbit_poses(5, 1.0, 7.0)
+        frames = [synth.render(scene, p, **cam) for p in poses]
+        for kind in ("f32", "u16"):
+            ctx, orc = make_pair(cam=cam, dims=(96, 96, 96), voxel=0.03, centre=(0.0, -0.1, 0.0), n_slots=5, channels=tl3d.CH_TSDF)
+            with ctx:
+                for i, ((depth, bgr), pose) in enumerate(zip(frames, poses)):
+                    d = depth.copy()
+                    holes = rng.random(d.shape)
+                    d[holes < 0.03] = 0.0
+                    d[(holes > 0.03) & (holes < 0.05)] = 80.0                       # beyond max_depth
+                    if kind == "u16":
+                        mm = np.clip(np.rint(d * 1000.0), 0, 65535).astype(np.uint16)
+                        ctx.upload(i, mm, bgr)
+                        d = mm.astype(np.float32) / np.float32(1000.0)
+                    else:
+                        ctx.upload(i, d, bgr)
+                    ctx.integrate(i, pose)
+                    orc.tsdf_integrate(d, pose[0], pose[1])
+                g = ctx.download_grid(tl3d.CH_TSDF)
+            assert orc.tsdf[:, 1].sum() > 1000, (w, h, kind)
+            assert np.array_equal(g, orc.tsdf), (w, h, kind)
+
+
 def test_centroid_runs_of_every_length_and_the_point_list_path():
     """Runs of adjacent samples that share a voxel are summed in the wave (inside 16-lane rows) before the LDS table and
     the grid: voxels of 2 mm ... 40 cm give runs from 1 sample to whole rows (split at row boundaries), invalid pixels cut
