@@ -75,6 +75,13 @@ class PinnedArray:
             pass
 
 
+# numpy images of tl3d_icp_pair / tl3d_icp_result (include/tl3d.h; sizes checked against the ctypes structures at import)
+_ICP_PAIR_DT = np.dtype([("slot_src", "<i4"), ("slot_tgt", "<i4"), ("scale_src", "<f8"), ("T_init", "<f8", (16,))])
+_ICP_RESULT_DT = np.dtype([("T", "<f8", (16,)), ("fitness", "<f8"), ("rmse", "<f8"), ("n_corr", "<i8"), ("n_src", "<i8"),
+                           ("iters_run", "<i4"), ("status", "<i4"), ("scale", "<f8")])
+assert _ICP_PAIR_DT.itemsize == C.sizeof(abi.IcpPair) and _ICP_RESULT_DT.itemsize == C.sizeof(abi.IcpResult)
+
+
 class FusionContext:
     def __init__(self, width: int, height: int, fx: float, fy: float, cx: float, cy: float,
                  min_depth: float = 0.1, max_depth: float = 50.0, n_slots: int = 2,
@@ -342,28 +349,34 @@ class FusionContext:
         levels: sequence of dicts with the keyword arguments of icp() (iters, stride, max_dist, damping, eps, eig_rel),
         coarse to fine.  T_init: one 4x4 per pair (default identity); scales: metric scale of each pair's source depth."""
         n = len(pairs)
-        arr = (abi.IcpPair * n)()
-        eye = np.eye(4)
-        for i, (a, b_) in enumerate(pairs):
-            arr[i].slot_src, arr[i].slot_tgt = int(a), int(b_)
-            arr[i].scale_src = 1.0 if scales is None else float(scales[i])
-            T0 = eye if T_init is None or T_init[i] is None else np.asarray(T_init[i], np.float64).reshape(4, 4)
-            arr[i].T_init[:] = T0.ravel().tolist()
+        # the request as one numpy record array laid out like tl3d_icp_pair (a Python loop over ctypes fields costs ~10 us per pair:
+        # as much as the registration of a pair inside a large batch)
+        arr = np.zeros(n, _ICP_PAIR_DT)
+        pr = np.asarray(pairs, np.int64).reshape(n, 2)
+        arr["slot_src"], arr["slot_tgt"] = pr[:, 0], pr[:, 1]
+        arr["scale_src"] = 1.0 if scales is None else np.asarray(scales, np.float64)
+        arr["T_init"] = np.eye(4).ravel()
+        if T_init is not None:
+            for i, T0 in enumerate(T_init):
+                if T0 is not None:
+                    arr["T_init"][i] = np.asarray(T0, np.float64).reshape(16)
         lv = (abi.IcpParams * len(levels))()
         for i, kw in enumerate(levels):
             lv[i] = abi.IcpParams(int(kw.get("iters", 10)), int(kw.get("stride", 4)), float(kw.get("max_dist", 0.05)),
                                   float(kw.get("damping", 1e-6)), float(kw.get("eps", 1e-9)), float(kw.get("eig_rel", 1e-4)),
                                   1 if kw.get("estimate_scale", False) else 0, 0)
-        abi.check(self._lib.tl3d_icp_batch_enqueue(self._h, arr, n, lv, len(levels)))
+        abi.check(self._lib.tl3d_icp_batch_enqueue(self._h, arr.ctypes.data_as(C.POINTER(abi.IcpPair)), n, lv, len(levels)))
         self._icp_batch_n = n
 
     def icp_batch_collect(self):
         n = getattr(self, "_icp_batch_n", 0)
-        res = (abi.IcpResult * max(1, n))()
-        abi.check(self._lib.tl3d_icp_batch_collect(self._h, res, n))
+        res = np.zeros(max(1, n), _ICP_RESULT_DT)
+        abi.check(self._lib.tl3d_icp_batch_collect(self._h, res.ctypes.data_as(C.POINTER(abi.IcpResult)), n))
         self._icp_batch_n = 0
-        return [dict(T=np.array(r.T).reshape(4, 4), fitness=r.fitness, rmse=r.rmse, n_corr=r.n_corr, n_src=r.n_src,
-                     iters_run=r.iters_run, status=r.status, scale=r.scale) for r in res[:n]]
+        T = res["T"].reshape(-1, 4, 4)
+        cols = [res[k].tolist() for k in ("fitness", "rmse", "n_corr", "n_src", "iters_run", "status", "scale")]
+        return [dict(T=T[i], fitness=cols[0][i], rmse=cols[1][i], n_corr=cols[2][i], n_src=cols[3][i], iters_run=cols[4][i],
+                     status=cols[5][i], scale=cols[6][i]) for i in range(n)]
 
     def icp_batch(self, pairs, levels, T_init=None, scales=None):
         self.icp_batch_enqueue(pairs, levels, T_init, scales)
