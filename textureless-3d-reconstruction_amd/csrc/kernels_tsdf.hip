@@ -761,10 +761,12 @@ __global__ __launch_bounds__(256, TL3D_UPD_WAVES) void tsdf_update_kernel(Cam ca
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 unsigned pix = S.valid_pix;
-                if ((S.m >> s) & 1u) {
+                {   // (no branch around a sub-brick that is not MIXED -- its zc is +inf, "behind everything", and stays so: 7 instructions
+                    // for all eight sub-bricks cost less than 8 wave-uniform branches, 66.2 k -> 68.2 k frames/s; the same in stage C,
+                    // 13 instructions each, costs more: 65.2 k)
                     const float zc = S.zc[s];
                     const bool fre = S.tl[s].x - zc >= trunc_free;
-                    const bool skp = S.tl[s].y - zc < -g.trunc;
+                    const bool skp = !(S.tl[s].y - zc >= -g.trunc);
                     S.zc[s] = fre ? -INFINITY : (skp ? INFINITY : zc);
                     pix = (fre || skp) ? pix : S.pix[s];
                 }
