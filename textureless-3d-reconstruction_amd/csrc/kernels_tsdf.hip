@@ -781,9 +781,8 @@ __global__ __launch_bounds__(256, TL3D_UPD_WAVES) void tsdf_update_kernel(Cam ca
                 if ((S.m >> s) & 1u) {
                     int q;
                     if (tsdf_finish(g, S.sc, S.mind, S.maxd, depth_value(S.dv[s]), S.zc[s], q)) acc[s] += (unsigned)(q + 32768) + (1u << 21);
-                } else if ((S.fr >> s) & 1u) {
-                    acc[s] += 65535u + (1u << 21);
                 }
+                acc[s] += ((S.fr >> s) & 1u) ? 65535u + (1u << 21) : 0u;      // (a FREE sub-brick: one add of a wave-uniform value, no second branch)
             }
         };
         if (EXP & 4) {                                          // experiments: one frame at a time, no software pipeline
