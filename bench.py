@@ -55,20 +55,20 @@ def parse():
     return ap.parse_args()
 
 
+def load_launcher():
+    """textureless-3d-reconstruction_amd/launch.py by path: the parent of `--gpus N` imports nothing that could load the HIP runtime"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("tl3d_launch", os.path.join(ROOT, "textureless-3d-reconstruction_amd", "launch.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def spawn_ranks(n):
     """--gpus N outside torchrun: start N fresh copies of this command line, one per GPU, BEFORE this process has made any GPU
-    call (the parent only waits and passes rank 0's line through).  Rendezvous on 127.0.0.1."""
-    import socket
-    import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    return max(p.wait() for p in procs)
+    call (the parent only watches its ranks and passes rank 0's line through).  A rank that dies -- by a signal too -- ends the
+    group with a non-zero status instead of leaving the others in a collective; the wait is bounded (TL3D_RANK_TIMEOUT_S)."""
+    return load_launcher().spawn_ranks(os.path.abspath(__file__), sys.argv[1:], n)
 
 
 def main():

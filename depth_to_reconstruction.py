@@ -16,17 +16,14 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 def _spawn_ranks(n, argv):
     """--gpus N outside torchrun: start N copies of this command line, one per GPU, BEFORE anything touches a GPU here
-    (children are fresh processes; the parent only waits).  Rendezvous on 127.0.0.1."""
-    import socket
-    import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
-    return max(p.wait() for p in procs)
+    (children are fresh processes; the parent only watches them: the first rank that fails -- by a signal too -- ends the group
+    with a non-zero status, the wait is bounded).  Rendezvous on 127.0.0.1."""
+    import importlib.util
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("tl3d_launch", os.path.join(here, "textureless-3d-reconstruction_amd", "launch.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.spawn_ranks(os.path.abspath(__file__), list(argv), n)
 
 
 def _init_rank(args):

@@ -303,3 +303,44 @@ def test_decode_bgr_into_equals_the_cv2_imread_contract(tmp_path, monkeypatch):
     with pytest.raises(ValueError):
         fileio.decode_bgr_into(tmp_path / "rgb.png", np.zeros((h + 1, w, 3), np.uint8))
     assert fileio.decode_bgr_into(tmp_path / "missing.png", np.zeros((h, w, 3), np.uint8)) is False
+
+
+# ---- the --gpus N launcher (textureless-3d-reconstruction_amd/launch.py): a dead rank must end the group --------------------------
+def _load_launcher():
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("tl3d_launch_test", os.path.join(root, "textureless-3d-reconstruction_amd", "launch.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+_RANK_SCRIPT = """
+import os, signal, sys, time
+mode, rank = sys.argv[1], int(os.environ["RANK"])
+assert os.environ["WORLD_SIZE"] == "3" and os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["MASTER_PORT"]) > 0
+if mode == "ok":
+    sys.exit(0)
+if mode == "exit3" and rank == 1:
+    sys.exit(3)
+if mode == "signal" and rank == 2:
+    os.kill(os.getpid(), signal.SIGABRT)          # what a GPU fault looks like from outside
+time.sleep(60)                                     # the other ranks "sit in a collective"
+"""
+
+
+def test_launcher_reports_failed_and_signalled_ranks_and_bounds_the_wait(tmp_path):
+    import time
+    launch = _load_launcher()
+    assert launch.exit_code([0, 0, 0]) == 0 and launch.exit_code([0, -6, 0]) == 6 and launch.exit_code([0, 0, 2]) == 2
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT)
+    assert launch.spawn_ranks(str(script), ["ok"], 3, timeout_s=30) == 0
+    t0 = time.monotonic()
+    assert launch.spawn_ranks(str(script), ["exit3"], 3, timeout_s=30, grace_s=2) == 3          # siblings terminated, not waited for
+    assert launch.spawn_ranks(str(script), ["signal"], 3, timeout_s=30, grace_s=2) == 6         # SIGABRT: return code -6, max() said 0
+    assert time.monotonic() - t0 < 20
+    t0 = time.monotonic()
+    assert launch.spawn_ranks(str(script), ["hang"], 3, timeout_s=1.0, grace_s=2) == 124        # nobody fails, nobody returns
+    assert time.monotonic() - t0 < 10
