@@ -197,5 +197,16 @@ class Oracle:
                            C.c_double(max_dist), _p(out), C.byref(cnt), C.byref(nsrc))
         return out, cnt.value, nsrc.value
 
+    def icp_sums_scale(self, depth_src, nmap_tgt, T, stride=4, max_dist=0.05, scale_src=1.0):
+        """icp_sums with the Sim(3) column: 37 doubles = 21 + 6 + e + 0 + c[6] + cc + bc"""
+        d = self._depth(depth_src)
+        nm = np.ascontiguousarray(nmap_tgt, dtype=np.float32)
+        T = np.ascontiguousarray(np.asarray(T, np.float64).reshape(16))
+        out = np.zeros(37, np.float64)
+        cnt, nsrc = C.c_int64(0), C.c_int64(0)
+        lib().orc_icp_sums_scale(C.byref(self.cfg), _p(d), C.c_double(scale_src), _p(nm), _p(T), C.c_int(stride),
+                                 C.c_double(max_dist), _p(out), C.byref(cnt), C.byref(nsrc))
+        return out, cnt.value, nsrc.value
+
     def vox_index(self, i, j, k):
         return lib().orc_vox_index(C.byref(self.cfg), C.c_int(i), C.c_int(j), C.c_int(k))

@@ -820,3 +820,20 @@ void orc_icp_sums(const orc_cfg *c, const float *depth_s, double scale_s, const 
     *cnt = s.cnt;
     *nsrc = s.nsrc;
 }
+
+/* the same pass with the Sim(3) scale column (est_scale = 1): + c[6] = sum J_a J_alpha, cc = sum J_alpha^2, bc = sum J_alpha r;
+ * exposed for tests/test_oracle_second_formulation.py */
+void orc_icp_sums_scale(const orc_cfg *c, const float *depth_s, double scale_s, const float *nmap_t, const double T[16],
+                        int stride, double max_dist, double out37[37], int64_t *cnt, int64_t *nsrc) {
+    icp_sums s;
+    icp_pass(c, depth_s, (float)scale_s, nmap_t, T, stride, (float)max_dist, 1, &s);
+    memcpy(out37, s.a, 21 * sizeof(double));
+    memcpy(out37 + 21, s.b, 6 * sizeof(double));
+    out37[27] = s.e;
+    out37[28] = 0.0;
+    memcpy(out37 + 29, s.c, 6 * sizeof(double));
+    out37[35] = s.cc;
+    out37[36] = s.bc;
+    *cnt = s.cnt;
+    *nsrc = s.nsrc;
+}

@@ -883,15 +883,15 @@ def test_reset_followed_at_once_by_integrate_on_a_large_grid():
 
 def test_sparse_grid_equals_the_dense_grid_bit_for_bit():
     """A sparse grid (records only for the bricks the data touches, handed out on first touch through a brick table; bricks that
-    are only ever free space keep a 4-byte count or nothing) holds what the dense grid holds wherever a surface ever came within
-    the truncation band: centroid channel, both extractions and the merge of two grids equal the oracle's / the dense context's
-    bit for bit, with a fraction of the bricks allocated."""
+    are wholly free space in every frame that sees them keep a 4-byte count) holds what the dense grid holds: both channels, both
+    extractions and the merge of two grids equal the oracle's / the dense context's bit for bit, with a fraction of the bricks
+    allocated."""
     poses, frames = small_scene_frames(n=5, deg=4.0)
     dims, voxel, centre = (96, 96, 96), 0.025, (0.0, -0.2, 0.0)
     nbr = 96 ** 3 // 512
     ctx, orc = make_pair(dims=dims, voxel=voxel, centre=centre, n_slots=5)
     origin = tuple(centre[i] - 0.5 * dims[i] * voxel for i in range(3))
-    spec = tl3d.GridSpec(dims, origin, voxel, 4 * voxel, tl3d.CH_TSDF | tl3d.CH_CENTROID, pool_tsdf=nbr // 2, pool_centroid=nbr // 4)
+    spec = tl3d.GridSpec(dims, origin, voxel, 4 * voxel, tl3d.CH_TSDF | tl3d.CH_CENTROID, pool_tsdf=3 * nbr // 4, pool_centroid=nbr // 4)
     sp = tl3d.FusionContext(SMALL["width"], SMALL["height"], SMALL["fx"], SMALL["fy"], SMALL["cx"], SMALL["cy"], n_slots=5, grid=spec)
     with ctx, sp:
         for c in (ctx, sp):
@@ -904,17 +904,17 @@ def test_sparse_grid_equals_the_dense_grid_bit_for_bit():
             orc.tsdf_integrate(d, poses[i][0], poses[i][1])
             orc.centroid_accumulate(d, col, poses[i][0], poses[i][1], subsample=1)
         st = sp.stats()
-        assert st["pool_refused"] == 0 and 0 < st["pool_slots_tsdf"] < nbr // 2 and 0 < st["pool_slots_centroid"] < nbr // 4
+        assert st["pool_refused"] == 0 and 0 < st["pool_slots_tsdf"] < 3 * nbr // 4 and 0 < st["pool_slots_centroid"] < nbr // 4
         assert ctx.stats()["pool_slots_tsdf"] == nbr                            # dense: every brick has records
         gt, gc = sp.download_grid(tl3d.CH_TSDF), sp.download_grid(tl3d.CH_CENTROID)
         assert np.array_equal(gc, orc.centroid)
-        # TSDF: identical wherever a voxel ever came within the truncation band; the one difference: bricks that saw nothing but
-        # free space through a footprint with holes / beyond the image border get no records in a sparse grid (a dense grid
-        # keeps their (+32767, +1) observations)
-        diff = np.any(gt != orc.tsdf, axis=1)
-        assert diff.mean() < 0.2 and np.all(orc.tsdf[diff, 0] == 32767 * orc.tsdf[diff, 1]) and np.all(gt[diff, 1] < orc.tsdf[diff, 1])
-        band = np.abs(orc.tsdf[:, 0]) < 32767 * np.maximum(orc.tsdf[:, 1], 1)
-        assert band.sum() > 10000 and not diff[band].any()
+        # TSDF: the oracle's grid, every voxel.  (Until round 3 bricks that saw nothing but free space through a footprint with
+        # holes / beyond the image border got no records in a sparse grid: up to a fifth of this scene's voxels differed, and a
+        # band voxel of such a brick lost the free-space observations of the OTHER views.  This scene has both kinds: the object
+        # alone, most rays miss.)
+        seen_free_through_holes = (orc.tsdf[:, 1] > 0) & (orc.tsdf[:, 0] == 32767 * orc.tsdf[:, 1])
+        assert seen_free_through_holes.sum() > 10000
+        assert np.array_equal(gt, orc.tsdf)
         gt_dense = orc.tsdf
         assert np.array_equal(ctx.download_grid(tl3d.CH_TSDF), orc.tsdf)
         assert sp.max_weight() == int(gt[:, 1].max()) and ctx.max_weight() == int(orc.tsdf[:, 1].max())

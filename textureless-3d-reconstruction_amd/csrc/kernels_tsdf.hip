@@ -398,12 +398,10 @@ __global__ __launch_bounds__(256) void brick_cull_kernel(Cam cam, Grid g, BatchB
                                 a.z = fminf(a.z, b.z);
                             }
                         cls = classify_box(g, a, zmin, zmax, inside);
-                        // A SPARSE grid keeps no records for free space.  A brick that every VALID pixel under it puts at
-                        // least trunc in front of the surface, but whose footprint has holes or leaves the image, would get
-                        // (+32767, +1) on some of its voxels and nothing on the others: records for free space only.  It is
-                        // skipped there (the band around the surfaces, the centroids and both extractions do not see the
-                        // difference; a dense grid keeps these observations and equals the oracle voxel for voxel).
-                        if (cls == 1 && g.tsdf_cap < (unsigned)(g.nbx * g.nby * g.nbz) && (a.x - (zmax + 0.01f * g.vs) >= g.trunc * 1.001f)) cls = 0;
+                        // (A SPARSE grid classifies exactly as a dense one.  Until round 3 a brick that every VALID pixel under it
+                        // put in free space, but whose footprint had holes or left the image, was skipped there -- "records for free
+                        // space only" -- and the voxels of such a brick that came within the band in another frame lost those
+                        // observations.  Such bricks take a pool slot now and the sparse grid is the oracle's grid bit for bit.)
                     }
                 }
             }
