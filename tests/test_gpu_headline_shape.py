@@ -58,7 +58,7 @@ def test_headline_shape_32_plus_8_frames_into_512_cube_is_the_oracle_grid(as_u16
     assert st["tsdf_launches"] == 2, st["tsdf_launches"]                        # 32 + 8
     for d, p in zip(host, poses):
         orc.tsdf_integrate(d, p[0], p[1])
-    assert int((orc.tsdf[:, 1] > 0).sum()) > 30_000_000
+    assert int((orc.tsdf[:, 1] > 0).sum()) > 15_000_000
     assert np.array_equal(g, orc.tsdf)
 
 

@@ -49,7 +49,9 @@ constexpr int REGION = 32;               // one workgroup pass of the tiles kern
 constexpr int MAX_LEVELS = 14;           // 8 px << 13 = 65 536 px
 constexpr int TICKET_GROUPS = 64;        // ticket counters of the update kernel (one per group of workgroups)
 constexpr unsigned HDR_TICKETS = 64;     // batch header (unsigned words): [0] batch list length, [64 + 16 g] ticket counter of group g
-constexpr unsigned HDR_WORDS = HDR_TICKETS + 16 * TICKET_GROUPS;
+constexpr unsigned HDR_HIST = HDR_TICKETS + 16 * TICKET_GROUPS;      // [33] bricks of the batch list by the number of frames that list them ...
+constexpr unsigned HDR_CURSOR = HDR_HIST + 64;                       // [33] ... and the cursors of the counting sort (batch_order_kernel)
+constexpr unsigned HDR_WORDS = HDR_CURSOR + 64;
 
 struct Pyramid {
     int nlev;
@@ -59,23 +61,26 @@ struct Pyramid {
 // One frame of a batch.  The array of a batch's descriptors is written by the host and copied to the device in front of the
 // batch's first kernel; every kernel indexes it with a wave-uniform frame number (scalar loads).
 struct FrameDesc {
-    PoseF pose;
-    TsdfConst c;
-    int pad;
-    const void *depth;                   // f32 metres, or the 16-bit millimetre image (one kind per batch)
+    PoseF pose;                          // [0, 48)
+    TsdfConst c;                         // [48, 68)
+    unsigned valid_pix;                  // [68] index of ONE pixel of the frame that is valid (written by tile_pyramid_kernel); the update
+                                         //      kernel sends the lanes whose depth value cannot matter there
+    const void *depth;                   // [72] f32 metres, or the 16-bit millimetre image (one kind per batch)
+    float2 *vtile;                       // [80] level-0 tiles, 8 B each, as the update kernel's per-voxel test wants them (below)
     float4 *tiles;                       // the frame's tile pyramid
     unsigned *list;                      // its listed (MIXED) bricks, for the sub-brick classification
     unsigned *counts;                    // [0] listed bricks, [1] free-space bricks (counted)
     unsigned short *sub;                 // [nbricks] sub-brick masks of its listed bricks: bits 0-7 mixed, bits 8-15 free
-    float2 *vtile;                       // level-0 tiles once more, 8 B each, as the update kernel's per-voxel test wants them (below)
     unsigned *cells;                     // the 4x4x4-brick cells whose bounding sphere meets the view (the cull kernel's work list); count: counts[CELL_COUNT]
 };
+static_assert(sizeof(FrameDesc) == 128, "FrameDesc: 16 of them travel as one kernel argument block");
 
 // what all frames of a batch share
 struct BatchBufs {
     const FrameDesc *frames;             // [n_frames]
     unsigned *hdr;                       // [0] length of the batch list (reset by the tiles kernel)
     unsigned *list;                      // bricks that at least one frame of the batch lists, in order of first listing
+    unsigned *order;                     // the same bricks, dearest first (by the number of frames that list them): what the update walks
     unsigned *framemask;                 // [nbricks] bit f: frame f lists the brick; all zero between batches (the update re-arms it)
     int n_frames;
 };
@@ -141,6 +146,7 @@ __global__ __launch_bounds__(256) void depth_tiles_kernel(Cam cam, BatchBufs B, 
     if (blockIdx.x == 0 && blockIdx.y == 0) {                                    // and the batch list's, and the update's ticket counters
         if (threadIdx.x == 2) B.hdr[0] = 0u;
         if (threadIdx.x >= 64 && threadIdx.x < 64 + TICKET_GROUPS) B.hdr[HDR_TICKETS + 16u * (threadIdx.x - 64)] = 0u;
+        if (threadIdx.x >= 128) B.hdr[HDR_HIST + (threadIdx.x - 128)] = 0u;                      // histogram and cursors of the ordering pass
     }
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int q4 = lane & 7, row8 = lane >> 3;
@@ -276,7 +282,11 @@ __global__ __launch_bounds__(256) void tile_pyramid_kernel(Cam cam, Grid g, Frus
         if (s_found != 0xffffffffu) break;                        // (uniform: read after the barrier)
         __syncthreads();
     }
-    if (threadIdx.x == 0) const_descs(B)[blockIdx.x].counts[VALID_PIXEL] = s_found == 0xffffffffu ? 0u : s_found;
+    if (threadIdx.x == 0) {
+        const unsigned vp = s_found == 0xffffffffu ? 0u : s_found;
+        const_descs(B)[blockIdx.x].counts[VALID_PIXEL] = vp;
+        const_cast<FrameDesc *>(B.frames)[blockIdx.x].valid_pix = vp;      // (the update kernel of this batch reads it as a scalar)
+    }
     for (int L = 3; L < py.nlev; ++L) {
         const int n = py.ntx[L] * py.nty[L];
         const float4 *__restrict__ src = tiles + py.off[L - 1];
@@ -598,6 +608,56 @@ __global__ __launch_bounds__(256) void subbrick_classify_kernel(Cam cam, Grid g,
     }
 }
 
+// ---- 4b. the batch list, dearest bricks first -------------------------------------------------------------------------------
+// A brick costs the update one pipeline step per (frame, MIXED sub-brick): 1 ... 256.  The list comes out of the classification
+// in order of first listing, a wave takes ~5 bricks of it, and the launch lasts as long as its unluckiest wave: the longest wave
+// ran 1.9 x the mean (stamps, experiments flavour), i.e. half of the chip idled through the second half of the launch.  Ordered
+// by cost, dearest first, the tickets hand the cheap bricks out last and the waves end together.  Cost proxy: the number of frames
+// that list the brick (1 ... 32, known from the frame mask); a counting sort in two small launches of the prep chain:
+// histogram, then scatter (every workgroup reserves its range of each bin with one atomic per bin).
+constexpr int ORDER_BLOCKS = 64;
+__device__ __forceinline__ unsigned brick_cost_bin(const unsigned *__restrict__ framemask, unsigned brick) {
+    const unsigned c = (unsigned)__popc(framemask[brick]);
+    return c > 32u ? 32u : c;                                          // bin 0: nobody lists it any more (cannot happen; kept last)
+}
+__global__ __launch_bounds__(256) void batch_hist_kernel(Grid g, BatchBufs B) {
+    __shared__ unsigned h[33];
+    if (threadIdx.x < 33) h[threadIdx.x] = 0u;
+    __syncthreads();
+    const unsigned nbricks = (unsigned)(g.nbx * g.nby * g.nbz);
+    const unsigned n = min(B.hdr[0], nbricks);
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u)
+        atomicAdd(&h[brick_cost_bin(B.framemask, min(B.list[i], nbricks - 1u))], 1u);
+    __syncthreads();
+    if (threadIdx.x < 33 && h[threadIdx.x]) atomicAdd(B.hdr + HDR_HIST + threadIdx.x, h[threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void batch_order_kernel(Grid g, BatchBufs B) {
+    __shared__ unsigned h[33], base[33];
+    if (threadIdx.x < 33) h[threadIdx.x] = 0u;
+    __syncthreads();
+    const unsigned nbricks = (unsigned)(g.nbx * g.nby * g.nbz);
+    const unsigned n = min(B.hdr[0], nbricks);
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u)
+        atomicAdd(&h[brick_cost_bin(B.framemask, min(B.list[i], nbricks - 1u))], 1u);
+    __syncthreads();
+    if (threadIdx.x < 33) {
+        // bins in descending order of cost: 32, 31, ..., 1, then 0; this workgroup's range inside its bins
+        unsigned start = 0;
+        for (unsigned c = 32u; c > threadIdx.x; --c) start += B.hdr[HDR_HIST + c];
+        if (threadIdx.x == 0) { start = 0; for (unsigned c = 1u; c <= 32u; ++c) start += B.hdr[HDR_HIST + c]; }
+        base[threadIdx.x] = start + (h[threadIdx.x] ? atomicAdd(B.hdr + HDR_CURSOR + threadIdx.x, h[threadIdx.x]) : 0u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 33) h[threadIdx.x] = 0u;
+    __syncthreads();
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const unsigned b = min(B.list[i], nbricks - 1u);
+        const unsigned c = brick_cost_bin(B.framemask, b);
+        const unsigned pos = base[c] + atomicAdd(&h[c], 1u);
+        if (pos < nbricks + 64u) B.order[pos] = b;                     // (always: the bins partition the list)
+    }
+}
+
 // ---- 5. the update: one launch per batch ---------------------------------------------------------------------------------
 // A wave takes one brick of the batch list per trip.  For every frame whose bit is set in the brick's frame mask it projects the
 // lane's voxel of each MIXED sub-brick and adds the quantised tsdf to the lane's eight running sums; FREE sub-bricks add
@@ -620,6 +680,7 @@ __global__ __launch_bounds__(256) void subbrick_classify_kernel(Cam cam, Grid g,
 // on the masks would turn every wait into "all loads", the newest included).
 // EXP (experiments flavour of the library only; results incomplete): bit 0 no tile / depth loads, bit 1 no record accesses,
 // bit 2 no software pipeline.
+#ifdef TL3D_EXPERIMENTS        // the frame-major kernel of round 3: kept in the experiments flavour for A/B runs on one box
 template <typename DT> struct RawDepth { typedef float type; };
 template <> struct RawDepth<uint16_t> { typedef unsigned short type; };
 __device__ __forceinline__ float depth_value(float raw) { return raw; }
@@ -850,6 +911,283 @@ __global__ __launch_bounds__(256, TL3D_UPD_WAVES) void tsdf_update_kernel(Cam ca
     }
 }
 
+#endif  // TL3D_EXPERIMENTS
+
+// ---- 5b. the update, PAIR form (what the library launches) -----------------------------------------------------------------
+// Same task as above -- one wave per brick of the batch list, every listed (frame, MIXED sub-brick) of the brick projected, the
+// records read and written once per batch -- in a different shape.  The frame-major kernel above carries eight sub-bricks per lane
+// through every stage, chooses among them with wave-uniform branches (~40 taken or not per frame step: each costs this kernel
+// about five instruction slots, the branches together as much as half of its vector work), keeps the per-sub-brick conditions as
+// sixteen 64-bit lane masks in scalar registers (spilled to vector lanes) and needs 128 vector registers, i.e. three or four
+// waves per SIMD.  Here the unit of the pipeline is ONE PAIR (frame, sub-brick): 64 lanes = the 64 voxels of that sub-brick.
+//   * the brick's pairs are walked in frame-major order (frame f's scalars -- pose, scale, image and tile-record base -- are
+//     loaded when its first pair comes up), sub-brick s of the pair is a scalar: the lane's world coordinates are chosen by
+//     three selects, everything else is straight-line code;
+//   * the running sums live in LDS: acc[s][lane], wave-private, one ds_add per pair (a register array indexed by a scalar would
+//     need eight predicated adds);  FREE sub-bricks are counted per sub-brick over the frames with ballots and enter the sums
+//     once per brick;
+//   * three stages as before -- A project + tile record, B tile test + depth gather, C quantise + add -- software-pipelined
+//     over the pairs: step k runs A(k), C(k-2), B(k-1); a tile record has a full step, a depth value two thirds of one, before
+//     anything waits for it (and seven other waves of the SIMD have work meanwhile).  P pairs take P + 2 steps; the empty slots at either end run with zc = +inf ("behind
+//     everything": no update) and legal addresses, so the steady loop has no branch but its back edge and the frame switch;
+//   * every load of a stage is a scalar base + a 32-bit per-lane offset.
+// About 45 vector registers: eight waves per SIMD hide what the three of the form above could not.
+// The arithmetic of a voxel is tsdf_project / tsdf_finish, as above: the grid is the oracle's bit for bit.
+__device__ __forceinline__ int clamp_i32(int x, int hi_uniform) {        // min(max(x, 0), hi): one instruction (hi >= 0)
+    int r;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "s"(hi_uniform));
+    return r;
+}
+
+// loads from a wave-uniform base + a 32-bit per-lane byte offset (scalar base, vector offset: one address register per load)
+template <typename DT> struct PixLoad;
+template <> struct PixLoad<float> {
+    typedef float raw;
+    static __device__ __forceinline__ raw load(const char *base, unsigned off) { return *reinterpret_cast<const float *>(base + off); }
+    static __device__ __forceinline__ float value(raw v) { return v; }
+};
+template <> struct PixLoad<uint16_t> {
+    typedef unsigned short raw;
+    static __device__ __forceinline__ raw load(const char *base, unsigned off) { return *reinterpret_cast<const unsigned short *>(base + off); }
+    static __device__ __forceinline__ float value(raw v) { return mm_to_m(v); }
+};
+__device__ __forceinline__ int cvt_flr_i32(float x) {                    // (int)floorf(x), one instruction; saturates, NaN -> 0
+    int r;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+__device__ __forceinline__ unsigned keep_scalar(unsigned x) {             // x, wave-uniform, is computed HERE and lives in one scalar register
+    asm volatile("" : "+s"(x));
+    return x;
+}
+
+constexpr int UPD_WAVES = 8;             // waves per SIMD the pair kernel is built for (64 vector registers)
+
+// EXP (experiments flavour only, results incomplete): bit 0 tile records read at lane * 8 (coalesced), bit 1 every lane reads the frame's
+// valid pixel (no scattered depth reads), bit 2 no LDS add, bit 3 no record accesses
+template <bool COUNT, typename DT, int EXP = 0>
+__global__ __launch_bounds__(256, UPD_WAVES) void tsdf_update_pairs_kernel(Cam cam, Grid g, BatchBufs B, float mind, float maxd,
+                                                                           int2 *__restrict__ grid, unsigned long long *__restrict__ counters) {
+    __shared__ unsigned s_acc[4 * 512];                           // per wave: [8 sub-bricks][64 lanes] packed running sums
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    unsigned *const acc = s_acc + wid * 512 + lane;               // + 64 s
+    const unsigned nbricks = (unsigned)(g.nbx * g.nby * g.nbz);
+    const unsigned ntask = min(B.hdr[0], nbricks);                // (clamped: see the kernel above)
+    unsigned nread = 0, nwritten = 0;
+    // tasks by ticket, exactly as above: groups of workgroups, each with its own counter, entries interleaved between the groups
+    const unsigned ngrp = min((unsigned)TICKET_GROUPS, gridDim.x);
+    const unsigned grp = blockIdx.x % ngrp, bi = blockIdx.x / ngrp;
+    const unsigned waves_in_group = ((gridDim.x - grp + ngrp - 1u) / ngrp) * 4u;
+    unsigned *__restrict__ ticket = B.hdr + HDR_TICKETS + 16u * grp;
+    auto entry_of = [&](unsigned k) -> unsigned { return k >= 0x2000000u ? 0xffffffffu : k * ngrp + grp; };
+    const DescPtr frames = const_descs(B);
+    const int ntx0 = (cam.W + TILE0 - 1) >> TILE0_SHIFT;
+    const float trunc_free = g.trunc * 1.001f;
+    const unsigned row_bytes = (unsigned)cam.W * (unsigned)sizeof(DT);
+
+    auto fetch = [&](unsigned t, unsigned &brick, unsigned &fm, unsigned &subv, unsigned &slot) {
+        brick = min((unsigned)__builtin_amdgcn_readfirstlane((int)B.order[t]), nbricks - 1u);
+        fm = (unsigned)__builtin_amdgcn_readfirstlane((int)B.framemask[brick]);
+        slot = (unsigned)__builtin_amdgcn_readfirstlane((int)brick_slot(g.tsdf_tab, brick));
+        subv = 0u;
+        if (lane < B.n_frames && ((fm >> lane) & 1u)) subv = frames[lane].sub[brick];
+    };
+    auto take_ticket = [&]() -> unsigned {
+        unsigned k = 0;
+        if (lane == 0) k = atomicAdd(ticket, 1u);
+        return (unsigned)__builtin_amdgcn_readfirstlane((int)k) + waves_in_group;
+    };
+    unsigned t = entry_of(bi * 4u + (unsigned)wid);
+    unsigned brick_n = 0, fm_n = 0, subv_n = 0, slot_n = 0;
+    if (t < ntask) fetch(t, brick_n, fm_n, subv_n, slot_n);
+    unsigned k_next = t < ntask ? take_ticket() : 0u;
+    unsigned long long pf_t0 = 0, pf_setup = 0, pf_loop = 0, pf_rmw = 0, pf_bricks = 0, pf_steps = 0, pf_a = 0, pf_b = 0;
+    if (EXP & 16) pf_t0 = pf_a = __builtin_readcyclecounter();
+    while (t < ntask) {
+        const unsigned brick = brick_n, slot = slot_n;
+        unsigned subv = subv_n;
+        if (lane == 0) B.framemask[brick] = 0u;                   // re-armed for the next batch that uses this buffer
+        const unsigned t_next = entry_of(k_next);
+        if (t_next < ntask) {
+            fetch(t_next, brick_n, fm_n, subv_n, slot_n);
+            k_next = take_ticket();
+        }
+        t = t_next;
+        if (lane >= B.n_frames) subv = 0u;
+        const int bx = (int)(brick % (unsigned)g.nbx), by = (int)((brick / (unsigned)g.nbx) % (unsigned)g.nby), bz = (int)(brick / (unsigned)(g.nbx * g.nby));
+        // the lane's voxel in sub-brick s is (4 (s & 1) + (lane & 3), 4 (s >> 1 & 1) + (lane >> 2 & 3), 4 (s >> 2) + (lane >> 4)); its
+        // centre along an axis: fma(i + 0.5, voxel, origin) -- two values per axis (named scalars: an array indexed by a bit of s
+        // would be moved to LDS by the compiler)
+        const float wx0 = fmaf((float)(bx * 8 + (lane & 3)) + 0.5f, g.vs, g.ox), wx1 = fmaf((float)(bx * 8 + 4 + (lane & 3)) + 0.5f, g.vs, g.ox);
+        const float wy0 = fmaf((float)(by * 8 + ((lane >> 2) & 3)) + 0.5f, g.vs, g.oy), wy1 = fmaf((float)(by * 8 + 4 + ((lane >> 2) & 3)) + 0.5f, g.vs, g.oy);
+        const float wz0 = fmaf((float)(bz * 8 + (lane >> 4)) + 0.5f, g.vs, g.oz), wz1 = fmaf((float)(bz * 8 + 4 + (lane >> 4)) + 0.5f, g.vs, g.oz);
+        // the brick's pairs: lane f holds frame f's masks.  Pairs = set MIXED bits; FREE sub-bricks are counted per sub-brick over
+        // the frames and start the running sums; touched = sub-bricks anything adds to
+        unsigned npairs = 0, touched = 0;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const unsigned long long bm = __ballot((subv >> s) & 1u), bf = __ballot((subv >> (8 + s)) & 1u);
+            npairs += (unsigned)__popcll(bm);
+            touched |= (bm | bf) ? (1u << s) : 0u;
+            acc[64 * s] = (unsigned)__popcll(bf) * (65535u + (1u << 21));
+        }
+        npairs = keep_scalar(npairs);                                          // (computed now: the sixteen ballots die here)
+        touched = keep_scalar(touched);
+        unsigned rest = (unsigned)__ballot((subv & 0xffu) != 0u);              // frames with at least one MIXED sub-brick (lanes 0..31)
+        if (EXP & 16) { pf_b = __builtin_readcyclecounter(); pf_setup += pf_b - pf_a; pf_bricks += 1; pf_steps += npairs; }
+        if (npairs) {
+            // ---- scalars of the frame stage A works in, of the pair stage B works on, of the three pairs on their way to stage C
+            float r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, r5 = 0, r6 = 0, r7 = 0, r8 = 0, t0 = 0, t1 = 0, t2 = 0, a_sc = 0;
+            unsigned a_vp = 0, m = 0;
+            const char *a_vt = nullptr, *a_img = nullptr;
+            auto switch_frame = [&]() {
+                const int f = __builtin_ctz(rest);
+                rest &= rest - 1u;
+                m = (unsigned)__builtin_amdgcn_readlane((int)subv, f) & 0xffu;
+                const DescPtr F = frames + f;
+                r0 = F->pose.r[0]; r1 = F->pose.r[1]; r2 = F->pose.r[2]; r3 = F->pose.r[3]; r4 = F->pose.r[4]; r5 = F->pose.r[5];
+                r6 = F->pose.r[6]; r7 = F->pose.r[7]; r8 = F->pose.r[8]; t0 = F->pose.t[0]; t1 = F->pose.t[1]; t2 = F->pose.t[2];
+                a_sc = F->c.sc;
+                a_vp = F->valid_pix * (unsigned)sizeof(DT);
+                a_vt = reinterpret_cast<const char *>(F->vtile);
+                a_img = static_cast<const char *>(F->depth);
+            };
+            switch_frame();
+            const char *b_img = a_img;
+            unsigned b_vp = a_vp;
+            float c_sc1 = a_sc, c_sc2 = a_sc;
+            unsigned c_s1 = 0, c_s2 = 0;
+            bool c_open2 = false;                                              // pair k - 2 left some voxel to its depth pixel (wave-uniform)
+            // ---- pipeline registers, by the parity of the pair: A -> B (zc or +inf, pixel offset, tile record), B -> C (zc / +-inf, depth)
+            float zcA[2] = {INFINITY, INFINITY}, zcB[2] = {INFINITY, INFINITY};
+            unsigned pixA[2] = {0u, 0u};
+            float2 tlA[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
+            typename PixLoad<DT>::raw dvB[2] = {0, 0};
+            const unsigned nsteps = npairs + 2u;
+            auto step = [&](unsigned k, const int par) {
+                // ---- A(k): the lane's voxel of sub-brick s in the current frame -> pixel, tile record.  An empty slot (k >= npairs)
+                // runs with the camera plane at infinity: nothing lies in front of it
+                const bool have = k < npairs;
+                const unsigned s = have ? (unsigned)__builtin_ctz(m) : 0u;
+                const float zmin = have ? 0.0f : INFINITY;
+                m &= m - 1u;                                                   // (0 stays 0)
+                {
+                    const float wxs = (s & 1u) ? wx1 : wx0, wys = (s & 2u) ? wy1 : wy0, wzs = (s & 4u) ? wz1 : wz0;
+                    const float xc = fmaf(r0, wxs, fmaf(r1, wys, fmaf(r2, wzs, t0)));
+                    const float yc = fmaf(r3, wxs, fmaf(r4, wys, fmaf(r5, wzs, t1)));
+                    const float zc = fmaf(r6, wxs, fmaf(r7, wys, fmaf(r8, wzs, t2)));
+                    float inv = __builtin_amdgcn_rcpf(zc);                     // + one Newton step == the IEEE quotient (tsdf_project)
+                    inv = fmaf(fmaf(-zc, inv, 1.0f), inv, inv);
+                    if (__builtin_expect(!(zc >= 1.17549435e-38f && zc < 8.5e37f), 0)) inv = 1.0f / zc;
+                    const float uf = fmaf(cam.fx * xc, inv, cam.cx);
+                    const float vf = fmaf(cam.fy * yc, inv, cam.cy);
+                    // nearest pixel floor(uf + 0.5) in ONE conversion (v_cvt_flr_i32_f32 == v_floor_f32 + v_cvt_i32_f32 on every bit
+                    // pattern), and the window  -0.5 <= uf < W - 0.5  as ONE unsigned compare of it  (the same decision for every float
+                    // and every width: tools/ubench_flr.hip, exhaustive)
+                    const int ui = cvt_flr_i32(uf + 0.5f), vi = cvt_flr_i32(vf + 0.5f);
+                    const bool ok = (zc > zmin) & ((unsigned)ui <= (unsigned)(cam.W - 1)) & ((unsigned)vi <= (unsigned)(cam.H - 1));
+                    const int u = clamp_i32(ui, cam.W - 1), v = clamp_i32(vi, cam.H - 1);
+                    pixA[par] = mad_u24((unsigned)v, row_bytes, (unsigned)u * (unsigned)sizeof(DT));
+                    const unsigned tix = mad_u24((unsigned)v >> TILE0_SHIFT, (unsigned)ntx0 << 3, (unsigned)u & ~7u);
+                    zcA[par] = ok ? zc : INFINITY;
+                    tlA[par] = *reinterpret_cast<const float2 *>(a_vt + ((EXP & 1) ? (unsigned)lane * 8u : tix));
+                }
+                // the scalars pair k hands down the pipeline, then -- its frame used up -- the next frame's (the loads have stages C
+                // and B to arrive in)
+                const char *n_img = a_img;
+                const unsigned n_vp = a_vp, n_s = s;
+                const float n_sc = a_sc;
+                if (m == 0u && rest != 0u) switch_frame();
+                // ---- C(k - 2): depth value -> increment of the running sum.  A pair whose every voxel the tiles decided (two in five)
+                // has only "in front of everything" lanes (zc = -inf: tsdf = 1 exactly, and the pixel they read is valid) and "behind
+                // everything" lanes: no arithmetic
+                {
+                    const float zc = zcB[par];
+                    unsigned inc;
+                    if (c_open2) {
+                        const float d = PixLoad<DT>::value(dvB[par]) * c_sc2;
+                        const float sdf = d - zc;
+                        const bool ok = (d > mind && d < maxd) && (sdf >= -g.trunc);
+                        const float tsdf = fminf(1.0f, sdf * g.inv_trunc);
+                        const int q = (int)rintf(tsdf * 32767.0f);
+                        inc = ok ? (unsigned)(q + 32768) + (1u << 21) : 0u;
+                    } else {
+                        inc = (zc < 0.0f) ? 65535u + (1u << 21) : 0u;
+                    }
+                    if (!(EXP & 4) || inc == 0x12345u) (void)__hip_atomic_fetch_add(acc + 64u * c_s2, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                }
+                // ---- B(k - 1): what the tile leaves open gathers its pixel; the decided lanes read the frame's valid pixel
+                bool open1;
+                {
+                    const float zc = zcA[par ^ 1];
+                    const bool fre = tlA[par ^ 1].x - zc >= trunc_free;
+                    const bool skp = !(tlA[par ^ 1].y - zc >= -g.trunc);
+                    zcB[par ^ 1] = fre ? -INFINITY : (skp ? INFINITY : zc);
+                    const unsigned pix = ((EXP & 2) || fre || skp) ? b_vp : pixA[par ^ 1];
+                    dvB[par ^ 1] = PixLoad<DT>::load(b_img, pix);
+                    open1 = __ballot(!(fre || skp)) != 0ull;
+                }
+                b_img = n_img; b_vp = n_vp;
+                c_sc2 = c_sc1; c_s2 = c_s1; c_open2 = open1; c_sc1 = n_sc; c_s1 = n_s;
+            };
+            for (unsigned k = 0; k < nsteps; k += 2u) {                         // (an odd count: one more empty step)
+                step(k, 0);
+                step(k + 1u, 1);
+            }
+        }
+        if (EXP & 16) { pf_a = __builtin_readcyclecounter(); pf_loop += pf_a - pf_b; }
+        if (touched == 0u || slot >= SLOT_FULL) continue;                       // (a full pool: counted when the slot was refused)
+        if ((EXP & 8) && acc[0] != 0x7654321u) continue;
+        // the records that change: read, add, write -- once per batch
+        int2 *__restrict__ recs = grid + ((size_t)slot << 9);
+        unsigned a[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) a[s] = ((touched >> s) & 1u) ? acc[64 * s] : 0u;
+        int2 rec[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+            if (a[s] >> 21) rec[s] = recs[s * 64 + lane];
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+            if (a[s] >> 21) {
+                const int w = (int)(a[s] >> 21);
+                rec[s].x += (int)(a[s] & 0x1fffffu) - 32768 * w;
+                rec[s].y += w;
+                recs[s * 64 + lane] = rec[s];
+                if (COUNT) { nread += 1; nwritten += 1; }
+            }
+        if (EXP & 16) { const unsigned long long now = __builtin_readcyclecounter(); pf_rmw += now - pf_a; pf_a = now; }
+    }
+    if ((EXP & 16) && lane == 0) {                             // experiments: where a wave's time goes (s_memtime ticks)
+        atomicAdd(counters + 8, pf_setup); atomicAdd(counters + 9, pf_loop); atomicAdd(counters + 10, pf_rmw);
+        atomicAdd(counters + 11, __builtin_readcyclecounter() - pf_t0); atomicAdd(counters + 12, pf_bricks); atomicAdd(counters + 13, pf_steps);
+        atomicAdd(counters + 14, 1ull);
+        atomicMax(counters + 15, __builtin_readcyclecounter() - pf_t0);
+    }
+    if (COUNT) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            nread += __shfl_down(nread, d);
+            nwritten += __shfl_down(nwritten, d);
+        }
+        if (lane == 0) {
+            atomicAdd(counters + 2, (unsigned long long)nread);
+            atomicAdd(counters + 3, (unsigned long long)nwritten);
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            unsigned long long vis = 0, fre = 0;
+            for (int f = 0; f < B.n_frames; ++f) {
+                const unsigned l = min(frames[f].counts[0], nbricks), fc = min(frames[f].counts[1], nbricks - l);
+                vis += l + fc; fre += fc;
+            }
+            atomicAdd(counters + 4, vis);
+            atomicAdd(counters + 5, fre);
+            atomicAdd(counters + 6, fre);
+            atomicAdd(counters + 7, (unsigned long long)ntask);
+        }
+    }
+}
+
 static Pyramid make_pyramid(const Cam &cam) {
     Pyramid p;
     memset(&p, 0, sizeof(p));
@@ -873,7 +1211,7 @@ static size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 // Scratch of ONE batch in flight (the context keeps two and alternates):
 //   [descriptors (max_frames)] [header 256 B] [batch list] [frame masks] then per frame [counts 256 B] [tile pyramid] [list] [sub-brick masks] [8-B level-0 tiles]
 struct BatchLayout {
-    size_t off_desc, off_hdr, off_list, off_mask, off_frames, per_frame, f_counts, f_tiles, f_list, f_sub, f_vt, f_cells, total;
+    size_t off_desc, off_hdr, off_list, off_order, off_mask, off_frames, per_frame, f_counts, f_tiles, f_list, f_sub, f_vt, f_cells, total;
 };
 static BatchLayout batch_layout(const Cam &cam, const Grid &g, int max_frames) {
     const Pyramid p = make_pyramid(cam);
@@ -882,7 +1220,8 @@ static BatchLayout batch_layout(const Cam &cam, const Grid &g, int max_frames) {
     L.off_desc = 0;
     L.off_hdr = up256((size_t)max_frames * sizeof(FrameDesc));
     L.off_list = L.off_hdr + up256(HDR_WORDS * sizeof(unsigned));
-    L.off_mask = L.off_list + up256((nbricks + 64) * sizeof(unsigned));
+    L.off_order = L.off_list + up256((nbricks + 64) * sizeof(unsigned));
+    L.off_mask = L.off_order + up256((nbricks + 64) * sizeof(unsigned));
     L.off_frames = L.off_mask + up256(nbricks * sizeof(unsigned));
     L.f_counts = 0;
     L.f_tiles = 256;
@@ -921,6 +1260,7 @@ static BatchBufs batch_bufs(const BatchLayout &L, void *scratch, int n) {
     B.frames = reinterpret_cast<const FrameDesc *>(base + L.off_desc);
     B.hdr = reinterpret_cast<unsigned *>(base + L.off_hdr);
     B.list = reinterpret_cast<unsigned *>(base + L.off_list);
+    B.order = reinterpret_cast<unsigned *>(base + L.off_order);
     B.framemask = reinterpret_cast<unsigned *>(base + L.off_mask);
     B.n_frames = n;
     return B;
@@ -977,6 +1317,11 @@ int launch_tsdf_prepare(hipStream_t s, const Cam &cam, const Grid &g, int n, int
     if (ncb > cap) ncb = cap;
     hipLaunchKernelGGL(subbrick_classify_kernel, dim3(ncb, n), dim3(256), 0, s, cam, g, py, B);
     TL3D_HIP(hipGetLastError());
+    if (n > 1) {                                         // dearest bricks first (a one-frame batch: every brick costs the same; the update walks the list)
+        hipLaunchKernelGGL(batch_hist_kernel, dim3(ORDER_BLOCKS), dim3(256), 0, s, g, B);
+        hipLaunchKernelGGL(batch_order_kernel, dim3(ORDER_BLOCKS), dim3(256), 0, s, g, B);
+        TL3D_HIP(hipGetLastError());
+    }
     return TL3D_OK;
 }
 
@@ -989,39 +1334,73 @@ int launch_fold_free(hipStream_t s, const Grid &g, int2 *grid, unsigned *free_cn
 }
 
 // the dominant kernel: ONE read-modify-write pass over the bricks the n prepared frames of the batch list
-int launch_tsdf_update(hipStream_t s, const Cam &cam, const Grid &g, int n, int max_frames, bool depth_u16, int2 *grid, void *scratch,
-                       unsigned long long *counters, bool count, int max_blocks, int xcd_group) {
+int launch_tsdf_update(hipStream_t s, const Cam &cam, const Grid &g, int n, int max_frames, bool depth_u16, float mind, float maxd, int2 *grid,
+                       void *scratch, unsigned long long *counters, bool count, int max_blocks, int xcd_group) {
     const BatchLayout L = batch_layout(cam, g, max_frames);
-    const BatchBufs B = batch_bufs(L, scratch, n);
+    BatchBufs B = batch_bufs(L, scratch, n);
+    if (n == 1) B.order = B.list;
     const int nbricks = g.nbx * g.nby * g.nbz;
     int nblk = (nbricks + 3) / 4;
     if (nblk > max_blocks) nblk = max_blocks;
+#ifdef TL3D_EXPERIMENTS
+    static const int no_order = getenv("TL3D_NO_ORDER") ? atoi(getenv("TL3D_NO_ORDER")) : 0;     // walk the list as the classification left it
+    if (no_order) B.order = B.list;
+    static const int exp_mode = getenv("TL3D_TSDF_EXP") ? atoi(getenv("TL3D_TSDF_EXP")) : 0;     // timing ablations: results incomplete
+    static const int upd_lds = getenv("TL3D_UPD_LDS") ? atoi(getenv("TL3D_UPD_LDS")) : 0;        // unused LDS per workgroup: caps the waves per SIMD
+    static const int upd_old = getenv("TL3D_UPD_OLD") ? atoi(getenv("TL3D_UPD_OLD")) : 0;        // the frame-major kernel of round 3 (A/B on one box)
+    if (upd_old || exp_mode) {
+        int ob = max_blocks;
+        if (getenv("TL3D_UPD_OLD_BLOCKS")) ob = atoi(getenv("TL3D_UPD_OLD_BLOCKS"));
+        if (nblk > ob) nblk = ob;
 #define TL3D_LAUNCH_UPD(C_, T_, E_) \
     hipLaunchKernelGGL((tsdf_update_kernel<C_, T_, E_>), dim3(nblk), dim3(256), upd_lds, s, cam, g, B, xcd_group, grid, counters)
 #define TL3D_LAUNCH_UPD_E(E_)                                                                          \
     do {                                                                                               \
         if (depth_u16) TL3D_LAUNCH_UPD(false, uint16_t, E_); else TL3D_LAUNCH_UPD(false, float, E_);   \
     } while (0)
-#ifdef TL3D_EXPERIMENTS
-    static const int exp_mode = getenv("TL3D_TSDF_EXP") ? atoi(getenv("TL3D_TSDF_EXP")) : 0;     // timing ablations: results incomplete
-    static const int upd_lds = getenv("TL3D_UPD_LDS") ? atoi(getenv("TL3D_UPD_LDS")) : 0;        // unused LDS per workgroup: caps the waves per SIMD
-#else
-    constexpr int exp_mode = 0, upd_lds = 0;
-#endif
-    if (count) {
-        if (depth_u16) TL3D_LAUNCH_UPD(true, uint16_t, 0); else TL3D_LAUNCH_UPD(true, float, 0);
-    }
-#ifdef TL3D_EXPERIMENTS
-    else if (exp_mode == 1) TL3D_LAUNCH_UPD_E(1);
-    else if (exp_mode == 2) TL3D_LAUNCH_UPD_E(2);
-    else if (exp_mode == 3) TL3D_LAUNCH_UPD_E(3);
-    else if (exp_mode == 4) TL3D_LAUNCH_UPD_E(4);
-    else if (exp_mode == 5) TL3D_LAUNCH_UPD_E(5);
-#endif
-    else TL3D_LAUNCH_UPD_E(0);
-    (void)exp_mode;
+        if (count) {
+            if (depth_u16) TL3D_LAUNCH_UPD(true, uint16_t, 0); else TL3D_LAUNCH_UPD(true, float, 0);
+        }
+        else if (exp_mode == 1) TL3D_LAUNCH_UPD_E(1);
+        else if (exp_mode == 2) TL3D_LAUNCH_UPD_E(2);
+        else if (exp_mode == 3) TL3D_LAUNCH_UPD_E(3);
+        else if (exp_mode == 4) TL3D_LAUNCH_UPD_E(4);
+        else if (exp_mode == 5) TL3D_LAUNCH_UPD_E(5);
+        else TL3D_LAUNCH_UPD_E(0);
 #undef TL3D_LAUNCH_UPD_E
 #undef TL3D_LAUNCH_UPD
+        TL3D_HIP(hipGetLastError());
+        return TL3D_OK;
+    }
+#endif
+    (void)xcd_group;
+#ifdef TL3D_EXPERIMENTS
+    static const int pexp = getenv("TL3D_PAIRS_EXP") ? atoi(getenv("TL3D_PAIRS_EXP")) : 0;
+#define TL3D_LAUNCH_PEXP(E_) \
+    hipLaunchKernelGGL((tsdf_update_pairs_kernel<false, float, E_>), dim3(nblk), dim3(256), 0, s, cam, g, B, mind, maxd, grid, counters)
+    if (pexp && !count && !depth_u16) {
+        switch (pexp) {
+            case 1: TL3D_LAUNCH_PEXP(1); break;
+            case 2: TL3D_LAUNCH_PEXP(2); break;
+            case 3: TL3D_LAUNCH_PEXP(3); break;
+            case 4: TL3D_LAUNCH_PEXP(4); break;
+            case 7: TL3D_LAUNCH_PEXP(7); break;
+            case 8: TL3D_LAUNCH_PEXP(8); break;
+            case 16: TL3D_LAUNCH_PEXP(16); break;
+            default: TL3D_LAUNCH_PEXP(15); break;
+        }
+        TL3D_HIP(hipGetLastError());
+        return TL3D_OK;
+    }
+#endif
+#define TL3D_LAUNCH_PAIRS(C_, T_) \
+    hipLaunchKernelGGL((tsdf_update_pairs_kernel<C_, T_>), dim3(nblk), dim3(256), 0, s, cam, g, B, mind, maxd, grid, counters)
+    if (count) {
+        if (depth_u16) TL3D_LAUNCH_PAIRS(true, uint16_t); else TL3D_LAUNCH_PAIRS(true, float);
+    } else {
+        if (depth_u16) TL3D_LAUNCH_PAIRS(false, uint16_t); else TL3D_LAUNCH_PAIRS(false, float);
+    }
+#undef TL3D_LAUNCH_PAIRS
     TL3D_HIP(hipGetLastError());
     return TL3D_OK;
 }

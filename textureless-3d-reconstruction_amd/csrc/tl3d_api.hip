@@ -1002,7 +1002,7 @@ static int flush_updates(tl3d_ctx *ctx) {
     }
     // profiling mode: one event pair around the update kernel
     const int kt = ktimer_begin(ctx);
-    rc = launch_tsdf_update(ctx->stream, ctx->cam, ctx->grid, n, ctx->tsdf_batch, u16, ctx->tsdf, ctx->tsdf_scratch[half], ctx->d_counters,
+    rc = launch_tsdf_update(ctx->stream, ctx->cam, ctx->grid, n, ctx->tsdf_batch, u16, mind, maxd, ctx->tsdf, ctx->tsdf_scratch[half], ctx->d_counters,
                             ctx->count_records, ctx->tsdf_max_blocks, ctx->tsdf_xcd_group);
     if (rc == TL3D_OK) ctx->stats.tsdf_launches++;
     if (kt >= 0) {
@@ -2063,6 +2063,10 @@ int tl3d_get_stats(tl3d_ctx *ctx, tl3d_stats *out) {
     ctx->stats.tsdf_bricks_free = h[5];
     ctx->stats.tsdf_bricks_free_counted = h[6];
     ctx->stats.tsdf_batch_bricks = h[7];
+#ifdef TL3D_EXPERIMENTS
+    if (h[14]) fprintf(stderr, "[tl3d exp] update kernel, per wave (s_memtime ticks): setup %.0f  pair loop %.0f  record update %.0f  lifetime %.0f;  bricks per wave %.2f, pairs per brick %.1f, waves %llu; longest wave %.0f x launches\n",
+                       (double)h[8] / h[14], (double)h[9] / h[14], (double)h[10] / h[14], (double)h[11] / h[14], (double)h[12] / h[14], h[12] ? (double)h[13] / h[12] : 0.0, h[14], (double)h[15]);
+#endif
     if (ctx->brick_tabs) {
         unsigned cur[4] = {0, 0, 0, 0};
         TL3D_HIP(hipMemcpy(cur, ctx->grid.cursors, sizeof(cur), hipMemcpyDeviceToHost));

@@ -362,8 +362,8 @@ size_t tsdf_batch_scratch_bytes(const Cam &cam, const Grid &g, int max_frames);
 void tsdf_batch_scratch_zero_range(const Cam &cam, const Grid &g, int max_frames, size_t *off, size_t *bytes);
 int launch_tsdf_prepare(hipStream_t s, const Cam &cam, const Grid &g, int n, int max_frames, const PoseF *p, const Frustum &fr,
                         const void *const *depth, bool depth_u16, const float *scale, float mind, float maxd, void *scratch, unsigned *free_cnt);
-int launch_tsdf_update(hipStream_t s, const Cam &cam, const Grid &g, int n, int max_frames, bool depth_u16, int2 *grid, void *scratch,
-                       unsigned long long *counters, bool count, int max_blocks, int xcd_group);
+int launch_tsdf_update(hipStream_t s, const Cam &cam, const Grid &g, int n, int max_frames, bool depth_u16, float mind, float maxd, int2 *grid,
+                       void *scratch, unsigned long long *counters, bool count, int max_blocks, int xcd_group);
 int launch_fold_free(hipStream_t s, const Grid &g, int2 *grid, unsigned *free_cnt);
 // normals + icp
 int launch_normals(hipStream_t s, const Cam &cam, const float *depth, float scale, float mind, float maxd, float jump, int radius, float *sdepth,
