@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TL3D_ABI_VERSION 4
+#define TL3D_ABI_VERSION 5
 
 /* error codes */
 #define TL3D_OK 0
@@ -204,6 +204,16 @@ int tl3d_frame_bounds(tl3d_ctx *ctx, int slot, const double R[9], const double t
  * merged cloud; the extent of the union is the union of the extents). */
 int tl3d_frames_bounds(tl3d_ctx *ctx, int n_frames, const int32_t *slots, const double *R, const double *t, const double *scales,
                        uint32_t flags, int subsample, double min_depth, double max_depth, double out_min[3], double out_max[3]);
+
+/* How many 8^3 bricks a fusion of these frames into the grid `grid` describes (its geometry fields only: channels, nx ny nz, origin,
+ * voxel_size, sdf_trunc; no grid need be attached) WOULD give records to, per channel: the TSDF classification of every frame
+ * and the bricks the frames' samples (stride centroid_subsample; < 1: not counted) fall into, without touching a record.  What
+ * the pools of a sparse grid must hold (tl3d_config.pool_bricks_*): Open3D's hash map sizes itself as the merged cloud is inserted
+ * (D2R:404-410); a pool is allocated before the first frame, and this is how to know its size -- a few microseconds per frame.
+ * Exact: the fusion of the same frames takes exactly these many slots (one per brick, however many waves touch it first). */
+int tl3d_count_bricks(tl3d_ctx *ctx, const tl3d_config *grid, int n_frames, const int32_t *slots, const double *R, const double *t,
+                      const double *scales, int centroid_subsample, double min_depth, double max_depth, int64_t *bricks_tsdf,
+                      int64_t *bricks_centroid);
 
 /* a7 (fusion half): accumulate the same points straight into the centroid channel, no point list
  * (replaces np.vstack + Open3D voxel_down_sample's hash-map insert, D2R:401-410). */

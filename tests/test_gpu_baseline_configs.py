@@ -246,7 +246,7 @@ def test_a_30_m_corridor_at_5_mm_fuses_in_a_sparse_volume():
     pts, col, _ = pipe.reconstruct(poses=rel)
     g = pipe.grid
     assert g.sparse and g.nvox > 1.0e9 and g.dims[2] >= 5600, g          # (the floor comes into view 1.6 m ahead of the first camera)
-    assert g.device_bytes() < 8 * 2 ** 30, g.device_bytes() / 2 ** 30
+    assert g.pool_centroid > 0 and g.device_bytes() < 14 * 2 ** 30, g.device_bytes() / 2 ** 30       # (centroid records: 37.5 GB dense, < 3 GB here; the TSDF channel keeps every free-space observation: most of its bricks hold records)
     st = pipe.stats
     assert st["points_dropped"] == 0 and st["pool_refused"] == 0
     assert st["bricks_centroid"] > 50000 and st["bricks_tsdf"] > st["bricks_centroid"]

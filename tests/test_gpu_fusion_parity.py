@@ -891,12 +891,19 @@ def test_sparse_grid_equals_the_dense_grid_bit_for_bit():
     nbr = 96 ** 3 // 512
     ctx, orc = make_pair(dims=dims, voxel=voxel, centre=centre, n_slots=5)
     origin = tuple(centre[i] - 0.5 * dims[i] * voxel for i in range(3))
-    spec = tl3d.GridSpec(dims, origin, voxel, 4 * voxel, tl3d.CH_TSDF | tl3d.CH_CENTROID, pool_tsdf=3 * nbr // 4, pool_centroid=nbr // 4)
-    sp = tl3d.FusionContext(SMALL["width"], SMALL["height"], SMALL["fx"], SMALL["fy"], SMALL["cx"], SMALL["cy"], n_slots=5, grid=spec)
+    # the sparse context starts WITHOUT a grid: the frames are uploaded, the bricks they will touch are counted (tl3d_count_bricks:
+    # the fusion's own classification, no records), and the grid is attached with pools of exactly that size
+    sp = tl3d.FusionContext(SMALL["width"], SMALL["height"], SMALL["fx"], SMALL["fy"], SMALL["cx"], SMALL["cy"], n_slots=5, grid=None)
     with ctx, sp:
         for c in (ctx, sp):
             for i, (d, col) in enumerate(frames):
                 c.upload(i, d, col)
+        geom = tl3d.GridSpec(dims, origin, voxel, 4 * voxel, tl3d.CH_TSDF | tl3d.CH_CENTROID)
+        nt, nc = sp.count_bricks(geom, list(range(5)), poses, centroid_subsample=1)
+        assert 0 < nc < nbr and 0 < nt < nbr
+        spec = tl3d.GridSpec(dims, origin, voxel, 4 * voxel, tl3d.CH_TSDF | tl3d.CH_CENTROID, pool_tsdf=nt + 8, pool_centroid=nc + 8)
+        sp.attach_grid(spec)
+        for c in (ctx, sp):
             for i in range(5):
                 c.integrate(i, poses[i])
                 c.accumulate_centroid(i, poses[i], subsample=1)
@@ -904,7 +911,8 @@ def test_sparse_grid_equals_the_dense_grid_bit_for_bit():
             orc.tsdf_integrate(d, poses[i][0], poses[i][1])
             orc.centroid_accumulate(d, col, poses[i][0], poses[i][1], subsample=1)
         st = sp.stats()
-        assert st["pool_refused"] == 0 and 0 < st["pool_slots_tsdf"] < 3 * nbr // 4 and 0 < st["pool_slots_centroid"] < nbr // 4
+        # the count is exactly what the fusion takes (one slot per brick, whoever touches it first and however many at once)
+        assert st["pool_refused"] == 0 and st["pool_slots_tsdf"] == nt and st["pool_slots_centroid"] == nc
         assert ctx.stats()["pool_slots_tsdf"] == nbr                            # dense: every brick has records
         gt, gc = sp.download_grid(tl3d.CH_TSDF), sp.download_grid(tl3d.CH_CENTROID)
         assert np.array_equal(gc, orc.centroid)

@@ -344,3 +344,19 @@ def test_launcher_reports_failed_and_signalled_ranks_and_bounds_the_wait(tmp_pat
     t0 = time.monotonic()
     assert launch.spawn_ranks(str(script), ["hang"], 3, timeout_s=1.0, grace_s=2) == 124        # nobody fails, nobody returns
     assert time.monotonic() - t0 < 10
+
+
+def test_layout_from_counts_goes_sparse_per_channel_when_that_halves_the_channel():
+    """choose_layout's decision rule (pipeline.layout_from_counts): per channel a pool of the counted bricks (+ 3 % + 2048) when it
+    is less than half of the dense channel, else the dense channel."""
+    from tl3d.pipeline import layout_from_counts
+    import tl3d
+    g = tl3d.GridSpec((408, 488, 2088), (0.0, 0.0, 0.0), 0.005, 0.02)          # config 3's volume: 811 971 bricks, 16.6 GB dense
+    nbr = g.nvox // 512
+    s = layout_from_counts(g, 300_000, 100_000)
+    assert s.sparse and s.pool_tsdf == int(300_000 * 1.03) + 2048 and s.pool_centroid == int(100_000 * 1.03) + 2048
+    assert s.device_bytes() < 0.2 * g.device_bytes()
+    s = layout_from_counts(g, 700_000, 100_000)                               # most TSDF bricks hold records: that channel stays dense
+    assert s.pool_tsdf == 0 and s.pool_centroid > 0 and s.sparse
+    s = layout_from_counts(g, nbr, nbr)
+    assert not s.sparse and s.device_bytes() == g.device_bytes()

@@ -10,7 +10,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TL3D_LIB") or os.path.join(_HERE, "libtl3d.so")     # TL3D_LIB: a diagnostic build
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 OK, E_INVALID, E_HIP, E_NOMEM, E_CAPACITY, E_STATE, E_NODEVICE = 0, -1, -2, -3, -4, -5, -6
 CH_TSDF, CH_CENTROID, CH_FREE = 1, 2, 4
 DEPTH_F32_M, DEPTH_U16_MM = 0, 1
@@ -23,7 +23,7 @@ TSDF_MAX_WEIGHT = 65536
 SYMBOLS = [
     "tl3d_last_error", "tl3d_version", "tl3d_device_count", "tl3d_runtime_info", "tl3d_probe_hw_queues", "tl3d_grid_max_weight", "tl3d_create", "tl3d_destroy", "tl3d_sync",
     "tl3d_upload_frame", "tl3d_download_depth", "tl3d_pinned_alloc", "tl3d_pinned_free", "tl3d_upload_frame_async",
-    "tl3d_slot_wait", "tl3d_attach_grid", "tl3d_backproject", "tl3d_backproject_device", "tl3d_frame_bounds", "tl3d_frames_bounds", "tl3d_accumulate_centroid",
+    "tl3d_slot_wait", "tl3d_attach_grid", "tl3d_backproject", "tl3d_backproject_device", "tl3d_frame_bounds", "tl3d_frames_bounds", "tl3d_count_bricks", "tl3d_accumulate_centroid",
     "tl3d_accumulate_points", "tl3d_points_bounds", "tl3d_integrate", "tl3d_build_normals",
     "tl3d_download_normals", "tl3d_icp_p2plane", "tl3d_icp_enqueue", "tl3d_icp_collect", "tl3d_icp_batch_enqueue", "tl3d_icp_batch_collect", "tl3d_host_pack_bgr_rows", "tl3d_host_copy_rows", "tl3d_build_normals_many", "tl3d_fuse_frames", "tl3d_grid_reset", "tl3d_grid_device_ptr",
     "tl3d_grid_download", "tl3d_grid_upload", "tl3d_grid_add", "tl3d_grid_touched_bricks", "tl3d_grid_pack_bricks", "tl3d_grid_unpack_bricks", "tl3d_rccl_unique_id", "tl3d_rccl_init", "tl3d_allreduce_grid", "tl3d_extract", "tl3d_statistical_outlier",
@@ -172,6 +172,7 @@ def load():
         "tl3d_backproject_device": [vp, i32, vp, vp, dbl, u32, i32, dbl, dbl, vp, vp, i64, vp],
         "tl3d_frame_bounds": [vp, i32, vp, vp, dbl, u32, i32, dbl, dbl, vp, vp, vp],
         "tl3d_frames_bounds": [vp, i32, vp, vp, vp, vp, u32, i32, dbl, dbl, vp, vp],
+        "tl3d_count_bricks": [vp, C.POINTER(Config), i32, vp, vp, vp, vp, i32, dbl, dbl, C.POINTER(i64), C.POINTER(i64)],
         "tl3d_accumulate_centroid": [vp, i32, vp, vp, dbl, u32, i32, dbl, dbl],
         "tl3d_accumulate_points": [vp, vp, vp, i64],
         "tl3d_points_bounds": [vp, vp, i64, vp, vp],

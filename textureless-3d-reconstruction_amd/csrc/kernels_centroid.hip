@@ -123,6 +123,31 @@ __device__ __forceinline__ void centroid_commit_runs(const Grid &g, CenAdd k, un
 // rarely share a voxel and the points go straight to the grid (centroid_direct_kernel).
 constexpr int CEN_TW = 32, CEN_TH = 32;      // (tiles of 32 x 8 / 32 x 16 samples: the same time within 2 us)
 
+// One frame of a BATCH of accumulations (tl3d_accumulate_centroid collects up to TL3D_CEN_MAXBATCH frames of one stride per launch;
+// blockIdx.y picks the frame).  One frame per launch -- 500 workgroups of a 1080p frame at the reference's stride 2 on 256 CUs, 45 KB
+// of LDS each -- left the chip two thirds empty and every launch paid its ramp: 26.7 us per frame beside the TSDF batches (round
+// 3).  The descriptors travel as the arguments of a tiny kernel (captured at launch, 16 per launch) and are read through the
+// constant address space: a wave-uniform index, scalar loads.
+typedef const CenFrame __attribute__((address_space(4))) *CenPtr;
+struct CenChunk { CenFrame f[16]; };
+static_assert(sizeof(CenChunk) <= 4096, "kernel arguments are limited to 4 KB");
+__global__ __launch_bounds__(256) void cen_desc_upload_kernel(CenChunk c, CenFrame *__restrict__ dst, int n) {
+    const unsigned *src = reinterpret_cast<const unsigned *>(&c);
+    unsigned *out = reinterpret_cast<unsigned *>(dst);
+    const int words = n * (int)(sizeof(CenFrame) / 4);
+    for (int i = threadIdx.x; i < words; i += 256) out[i] = src[i];
+}
+__device__ __forceinline__ void cen_frame_load(CenPtr F, BpArgs &a, PoseD &p, const float *&depth, const uint8_t *&bgr) {
+    a.sub = F->a.sub; a.Ws = F->a.Ws; a.Hs = F->a.Hs; a.flags = F->a.flags;
+    a.scale = F->a.scale; a.min_d = F->a.min_d; a.max_d = F->a.max_d; a.zero = F->a.zero;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) p.r[i] = F->p.r[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) p.ct[i] = F->p.ct[i];
+    depth = F->depth;
+    bgr = F->bgr;
+}
+
 // xf / yf: the context's tables of (u - cx) / fx and (v - cy) / fy (the same IEEE quotients bp_pixel computes, without the
 // two fp64 divisions); colour: the pixel's three bytes in one unaligned 4-byte load (frame buffers have 16 B of slack)
 __device__ __forceinline__ CenAdd centroid_sample(const Cam &cam, const Grid &g, const BpArgs &a, const PoseD &p, const float *__restrict__ depth,
@@ -166,10 +191,14 @@ __device__ __forceinline__ void centroid_stats(int nvalid_thread, int nkept_thre
 }
 
 template <int VAR>
-__global__ __launch_bounds__(256) void centroid_frame_kernel(Cam cam, Grid g, BpArgs a, PoseD p, const float *__restrict__ depth,
-                                                             const uint8_t *__restrict__ bgr, const double *__restrict__ xf,
+__global__ __launch_bounds__(256) void centroid_frame_kernel(Cam cam, Grid g, const CenFrame *__restrict__ frames, const double *__restrict__ xf,
                                                              const double *__restrict__ yf, unsigned long long *__restrict__ grid,
                                                              unsigned long long *__restrict__ counters, int tiles_x) {
+    BpArgs a;
+    PoseD p;
+    const float *depth;
+    const uint8_t *bgr;
+    cen_frame_load((CenPtr)frames + blockIdx.y, a, p, depth, bgr);
     constexpr int CEN_SLOTS = CEN_TW * CEN_TH;
     __shared__ unsigned long long s_key[CEN_SLOTS];
     __shared__ unsigned long long s_val[CEN_SLOTS][4];
@@ -236,10 +265,14 @@ __global__ __launch_bounds__(256) void centroid_frame_kernel(Cam cam, Grid g, Bp
 }
 
 // sparse sampling (stride >= 3): one thread per sample in row-major order, runs combined in the wave, straight to the grid
-__global__ __launch_bounds__(256) void centroid_direct_kernel(Cam cam, Grid g, BpArgs a, PoseD p, const float *__restrict__ depth,
-                                                              const uint8_t *__restrict__ bgr, const double *__restrict__ xf,
+__global__ __launch_bounds__(256) void centroid_direct_kernel(Cam cam, Grid g, const CenFrame *__restrict__ frames, const double *__restrict__ xf,
                                                               const double *__restrict__ yf, unsigned long long *__restrict__ grid,
                                                               unsigned long long *__restrict__ counters) {
+    BpArgs a;
+    PoseD p;
+    const float *depth;
+    const uint8_t *bgr;
+    cen_frame_load((CenPtr)frames + blockIdx.y, a, p, depth, bgr);
     const long long s = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long ns = (long long)a.Ws * a.Hs;
     const int vs = (int)(s / a.Ws), us = (int)(s - (long long)vs * a.Ws);
@@ -315,19 +348,30 @@ __global__ __launch_bounds__(256) void add_u64_kernel(ulonglong2 *__restrict__ d
     }
 }
 
-int launch_centroid_frame(hipStream_t s, const Cam &cam, const Grid &g, const BpArgs &a, const PoseD &p, const float *depth,
-                          const uint8_t *bgr, const double *xf, const double *yf, unsigned long long *grid, unsigned long long *counters) {
+// n frames of ONE stride (a.sub, a.Ws, a.Hs equal) in one launch; `dev` holds the descriptors on the device (>= n entries)
+int launch_centroid_batch(hipStream_t s, const Cam &cam, const Grid &g, int n, const CenFrame *host, CenFrame *dev, const double *xf, const double *yf,
+                          unsigned long long *grid, unsigned long long *counters) {
+    if (n < 1 || n > TL3D_CEN_MAXBATCH) return set_err(TL3D_E_INVALID, "bad centroid batch size %d", n);
+    for (int i0 = 0; i0 < n; i0 += 16) {
+        CenChunk ch;
+        const int m = n - i0 < 16 ? n - i0 : 16;
+        memcpy(ch.f, host + i0, (size_t)m * sizeof(CenFrame));
+        if (m < 16) memset(ch.f + m, 0, (size_t)(16 - m) * sizeof(CenFrame));
+        hipLaunchKernelGGL(cen_desc_upload_kernel, dim3(1), dim3(256), 0, s, ch, dev + i0, m);
+        TL3D_HIP(hipGetLastError());
+    }
+    const BpArgs &a = host[0].a;
     if (a.sub >= 3) {
         const long long ns = (long long)a.Ws * a.Hs;
-        hipLaunchKernelGGL(centroid_direct_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, s, cam, g, a, p, depth, bgr, xf, yf, grid, counters);
+        hipLaunchKernelGGL(centroid_direct_kernel, dim3((unsigned)((ns + 255) / 256), n), dim3(256), 0, s, cam, g, dev, xf, yf, grid, counters);
     } else {
         // experiments flavour only -- TL3D_CEN_VARIANT: timing ablations (2: no grid atomics, 3: samples only, 4: no colour loads); DESIGN.md 7.5
 #ifdef TL3D_EXPERIMENTS
         static const int var = getenv("TL3D_CEN_VARIANT") ? atoi(getenv("TL3D_CEN_VARIANT")) : 0;
 #endif
         const int tiles_x = (a.Ws + CEN_TW - 1) / CEN_TW, tiles_y = (a.Hs + CEN_TH - 1) / CEN_TH;
-        const dim3 gr((unsigned)tiles_x * (unsigned)tiles_y);
-#define CEN_LAUNCH(V_) hipLaunchKernelGGL((centroid_frame_kernel<V_>), gr, dim3(256), 0, s, cam, g, a, p, depth, bgr, xf, yf, grid, counters, tiles_x)
+        const dim3 gr((unsigned)tiles_x * (unsigned)tiles_y, n);
+#define CEN_LAUNCH(V_) hipLaunchKernelGGL((centroid_frame_kernel<V_>), gr, dim3(256), 0, s, cam, g, dev, xf, yf, grid, counters, tiles_x)
 #ifdef TL3D_EXPERIMENTS
         if (var == 2) CEN_LAUNCH(2);
         else if (var == 3) CEN_LAUNCH(3);
@@ -337,6 +381,29 @@ int launch_centroid_frame(hipStream_t s, const Cam &cam, const Grid &g, const Bp
             CEN_LAUNCH(0);
 #undef CEN_LAUNCH
     }
+    TL3D_HIP(hipGetLastError());
+    return TL3D_OK;
+}
+
+// tl3d_count_bricks: the bricks a frame's samples fall into take a slot in the brick table handed in (a scratch table: no records
+// exist); the table's cursor ends up as the number of distinct bricks
+__global__ __launch_bounds__(256) void centroid_mark_kernel(Cam cam, Grid g, BpArgs a, PoseD p, const float *__restrict__ depth,
+                                                            const double *__restrict__ xf, const double *__restrict__ yf) {
+    const long long s = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long ns = (long long)a.Ws * a.Hs;
+    const int vs = (int)(s / a.Ws), us = (int)(s - (long long)vs * a.Ws);
+    bool valid;
+    const CenAdd k = centroid_sample(cam, g, a, p, depth, nullptr, xf, yf, s < ns ? us : a.Ws, vs, valid);
+    const bool want = k.rec != ~0ull;
+    // neighbouring samples share bricks: one lane per run of equal bricks asks
+    const unsigned brick = want ? (unsigned)(k.rec >> 9) : 0xffffffffu;
+    const unsigned prev = __shfl_up(brick, 1);
+    const bool ask = want && ((threadIdx.x & 63) == 0 || prev != brick);
+    (void)wave_slots(g.cen_tab, g.cursors + 2, g.cen_cap, brick, ask);
+}
+int launch_centroid_mark(hipStream_t s, const Cam &cam, const Grid &g, const BpArgs &a, const PoseD &p, const float *depth, const double *xf, const double *yf) {
+    const long long ns = (long long)a.Ws * a.Hs;
+    hipLaunchKernelGGL(centroid_mark_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, s, cam, g, a, p, depth, xf, yf);
     TL3D_HIP(hipGetLastError());
     return TL3D_OK;
 }

@@ -131,10 +131,14 @@ __device__ __forceinline__ void ld_depth4(const uint16_t *__restrict__ p, size_t
 }
 
 // ---- 1. depth tiles --------------------------------------------------------------------------------------
-// One 32x32-pixel region per WAVE: 8 lanes x 16 B cover a region row, a wave 8 rows, four passes the region -- a lane's four
-// 16-B loads are issued before the first is looked at.  A pass is one row of four level-0
-// tiles (lanes with equal q4 >> 1); level-1 and level-2 tiles are combined in registers (min / max / or over lane bits: the same
-// values whatever the order).  No LDS, no workgroup barrier.
+// One 32x32-pixel region per WAVE.  Lane (q4 = lane & 7, rq = lane >> 3) holds the 4x4-pixel block at columns 4 q4 .. 4 q4 + 3, rows
+// 4 rq .. 4 rq + 3: load i of a lane is row 4 rq + i, so every load instruction of the wave covers eight whole 128-byte row
+// segments, and the lane's four 16-B loads are issued before the first is looked at.  The block is reduced inside the lane; an 8x8
+// tile is 2 x 2 lanes (lane bits 0 and 3), a 16x16 tile 4 x 4 (+ bits 1 and 4), the region all of them (+ bits 2 and 5): SIX
+// butterfly steps for the three levels.  (Round 3 gave a lane four rows 8 apart: every row of 8x8 tiles was a 16-lane
+// reduction of its own, 19 steps; the kernel's 33 M vector instructions per 32 frames were a sixth of the batch's -- and the batch is
+// bound by exactly those)  min / max over the VALID pixels: an invalid one enters as NaN, which v_min_f32 / v_max_f32
+// pass over.  No LDS, no workgroup barrier.
 template <typename DT>
 __global__ __launch_bounds__(256) void depth_tiles_kernel(Cam cam, BatchBufs B, Pyramid py, int nrx, int nry) {
     const DescPtr F = const_descs(B) + blockIdx.y;
@@ -143,86 +147,73 @@ __global__ __launch_bounds__(256) void depth_tiles_kernel(Cam cam, BatchBufs B, 
     float4 *__restrict__ tiles = F->tiles;
     float2 *__restrict__ vtile = F->vtile;
     if (blockIdx.x == 0 && threadIdx.x < 2) F->counts[threadIdx.x] = 0u;        // reset the frame's list cursors
-    if (blockIdx.x == 0 && blockIdx.y == 0) {                                    // and the batch list's, and the update's ticket counters
+    if (blockIdx.x == 0 && blockIdx.y == 0) {                                    // and the batch list's, the update's ticket counters, the ordering pass's bins
         if (threadIdx.x == 2) B.hdr[0] = 0u;
         if (threadIdx.x >= 64 && threadIdx.x < 64 + TICKET_GROUPS) B.hdr[HDR_TICKETS + 16u * (threadIdx.x - 64)] = 0u;
-        if (threadIdx.x >= 128) B.hdr[HDR_HIST + (threadIdx.x - 128)] = 0u;                      // histogram and cursors of the ordering pass
+        if (threadIdx.x >= 128) B.hdr[HDR_HIST + (threadIdx.x - 128)] = 0u;
     }
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int q4 = lane & 7, row8 = lane >> 3;
+    const int q4 = lane & 7, rq = lane >> 3;
     const bool vec = (cam.W & 3) == 0;                              // rows are 16-B aligned
+    const float qnan = __uint_as_float(0x7fc00000u);
     for (int region = blockIdx.x * 4 + wid; region < nrx * nry; region += gridDim.x * 4) {
         const int rx = region % nrx, ry = region / nrx;
-        const int u0 = rx * REGION + q4 * 4;
+        const int u0 = rx * REGION + q4 * 4, v0 = ry * REGION + rq * 4;
         const int nv = min(4, cam.W - u0);
         float dd[4][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {                               // pass i: rows 8 i + row8
-            const int v = ry * REGION + 8 * i + row8;
+        for (int i = 0; i < 4; ++i) {
             dd[i][0] = dd[i][1] = dd[i][2] = dd[i][3] = 0.0f;
-            if (v < cam.H && u0 < cam.W) {
+            if (v0 + i < cam.H && u0 < cam.W) {
                 if (vec) {
-                    ld_depth4(depth, (size_t)v * cam.W + u0, dd[i]);
+                    ld_depth4(depth, (size_t)(v0 + i) * cam.W + u0, dd[i]);
                 } else {
-                    for (int k = 0; k < 4; ++k) dd[i][k] = (k < nv) ? ld_depth(depth, (size_t)v * cam.W + u0 + k) : 0.0f;
+                    for (int k = 0; k < 4; ++k) dd[i][k] = (k < nv) ? ld_depth(depth, (size_t)(v0 + i) * cam.W + u0 + k) : 0.0f;
                 }
             }
         }
-        float mn[4], mx[4];
-        int bad[4];
+        // the lane's block: lowest / highest VALID scaled depth, and whether a pixel of it (inside the image) is not valid
+        float mn = qnan, mx = qnan;
+        bool bad = false;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int v = ry * REGION + 8 * i + row8;
-            mn[i] = INFINITY; mx[i] = -INFINITY; bad[i] = 0;
-            if (v < cam.H && u0 < cam.W) {
+            float t[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (k < nv) {
-                        const float d = dd[i][k] * c.sc;
-                        if (d > c.mind && d < c.maxd) {
-                            mn[i] = fminf(mn[i], d);
-                            mx[i] = fmaxf(mx[i], d);
-                        } else {
-                            bad[i] = 1;
-                        }
-                    }
+            for (int k = 0; k < 4; ++k) {
+                const float d = dd[i][k] * c.sc;
+                const bool in_img = (v0 + i < cam.H) && (k < nv) && (u0 < cam.W);
+                const bool ok = d > c.mind && d < c.maxd;
+                t[k] = (ok && in_img) ? d : qnan;
+                bad = bad || (in_img && !ok);
             }
-            // level 0: lanes with equal q4 >> 1: butterfly over lane bits 0, 3, 4, 5
-#pragma unroll
-            for (int d = 1; d <= 32; d = (d == 1 ? 8 : d << 1)) {
-                mn[i] = fminf(mn[i], __shfl_xor(mn[i], d));
-                mx[i] = fmaxf(mx[i], __shfl_xor(mx[i], d));
-                bad[i] |= __shfl_xor(bad[i], d);
-            }
-            if ((lane & 0x39) == 0) {                               // lanes 0, 2, 4, 6: one per level-0 tile of this pass
-                const int tx = rx * 4 + (lane >> 1), ty = ry * 4 + i;
-                if (tx < py.ntx[0] && ty < py.nty[0]) {
-                    tiles[py.off[0] + ty * py.ntx[0] + tx] = make_float4(mn[i], mx[i], bad[i] ? 0.0f : 1.0f, 0.0f);
-                    // (lowest depth if EVERY pixel is valid, else -inf: "never surely free"; highest valid depth, -inf if none: "skip")
-                    vtile[ty * py.ntx[0] + tx] = make_float2(bad[i] ? -INFINITY : mn[i], mx[i]);
-                }
+            mn = fminf(fminf(mn, t[0]), fminf(t[1], fminf(t[2], t[3])));        // (NaN operands are passed over)
+            mx = fmaxf(fmaxf(mx, t[0]), fmaxf(t[1], fmaxf(t[2], t[3])));
+        }
+        // from here on: +inf / -inf for "no valid pixel" (the format of the pyramid), the flag as a number
+        mn = (mn == mn) ? mn : INFINITY;
+        mx = (mx == mx) ? mx : -INFINITY;
+        int bd = bad ? 1 : 0;
+        auto combine = [&](int d) {
+            mn = fminf(mn, __shfl_xor(mn, d));
+            mx = fmaxf(mx, __shfl_xor(mx, d));
+            bd |= __shfl_xor(bd, d);
+        };
+        combine(1); combine(8);                                     // level 0: 8x8 pixels
+        if ((lane & 9) == 0) {
+            const int tx = rx * 4 + (q4 >> 1), ty = ry * 4 + (rq >> 1);
+            if (tx < py.ntx[0] && ty < py.nty[0]) {
+                tiles[py.off[0] + ty * py.ntx[0] + tx] = make_float4(mn, mx, bd ? 0.0f : 1.0f, 0.0f);
+                // (lowest depth if EVERY pixel is valid, else -inf: "never surely free"; highest valid depth, -inf if none: "skip")
+                vtile[ty * py.ntx[0] + tx] = make_float2(bd ? -INFINITY : mn, mx);
             }
         }
-        // level 1: 2 x 2 level-0 tiles = passes (2 j, 2 j + 1) and lane bit 1; level 2: all of it
-        float a2 = INFINITY, b2 = -INFINITY;
-        int bd2 = 0;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            float a = fminf(mn[2 * j], mn[2 * j + 1]), b = fmaxf(mx[2 * j], mx[2 * j + 1]);
-            int bd = bad[2 * j] | bad[2 * j + 1];
-            a = fminf(a, __shfl_xor(a, 2));
-            b = fmaxf(b, __shfl_xor(b, 2));
-            bd |= __shfl_xor(bd, 2);
-            if ((lane & 0x3b) == 0 && py.nlev > 1) {                // lanes 0, 4
-                const int tx = rx * 2 + (lane >> 2), ty = ry * 2 + j;
-                if (tx < py.ntx[1] && ty < py.nty[1]) tiles[py.off[1] + ty * py.ntx[1] + tx] = make_float4(a, b, bd ? 0.0f : 1.0f, 0.0f);
-            }
-            a2 = fminf(a2, a); b2 = fmaxf(b2, b); bd2 |= bd;
+        combine(2); combine(16);                                    // level 1: 16x16
+        if ((lane & 27) == 0 && py.nlev > 1) {
+            const int tx = rx * 2 + (q4 >> 2), ty = ry * 2 + (rq >> 2);
+            if (tx < py.ntx[1] && ty < py.nty[1]) tiles[py.off[1] + ty * py.ntx[1] + tx] = make_float4(mn, mx, bd ? 0.0f : 1.0f, 0.0f);
         }
-        a2 = fminf(a2, __shfl_xor(a2, 4));
-        b2 = fmaxf(b2, __shfl_xor(b2, 4));
-        bd2 |= __shfl_xor(bd2, 4);
-        if (lane == 0 && py.nlev > 2) tiles[py.off[2] + ry * py.ntx[2] + rx] = make_float4(a2, b2, bd2 ? 0.0f : 1.0f, 0.0f);
+        combine(4); combine(32);                                    // level 2: the region
+        if (lane == 0 && py.nlev > 2) tiles[py.off[2] + ry * py.ntx[2] + rx] = make_float4(mn, mx, bd ? 0.0f : 1.0f, 0.0f);
     }
 }
 
@@ -929,7 +920,9 @@ __global__ __launch_bounds__(256, TL3D_UPD_WAVES) void tsdf_update_kernel(Cam ca
 //   * three stages as before -- A project + tile record, B tile test + depth gather, C quantise + add -- software-pipelined
 //     over the pairs: step k runs A(k), C(k-2), B(k-1); a tile record has a full step, a depth value two thirds of one, before
 //     anything waits for it (and seven other waves of the SIMD have work meanwhile).  P pairs take P + 2 steps; the empty slots at either end run with zc = +inf ("behind
-//     everything": no update) and legal addresses, so the steady loop has no branch but its back edge and the frame switch;
+//     everything": no update) and legal addresses, so the steady loop has no branch but its back edge and the frame switch
+//     (stages skipped by wave-uniform branches at either end instead: the compiler's wait counts at the joins turn conservative and
+//     the launch takes a quarter longer: 61 k against 76 k frames/s);
 //   * every load of a stage is a scalar base + a 32-bit per-lane offset.
 // About 45 vector registers: eight waves per SIMD hide what the three of the form above could not.
 // The arithmetic of a voxel is tsdf_project / tsdf_finish, as above: the grid is the oracle's bit for bit.
@@ -961,6 +954,9 @@ __device__ __forceinline__ unsigned keep_scalar(unsigned x) {             // x, 
     return x;
 }
 
+#ifdef TL3D_EXPERIMENTS
+__device__ unsigned long long g_upd_span[16384][2];        // experiments: start / end (100 MHz real-time clock) of every wave of the last stamped launch
+#endif
 constexpr int UPD_WAVES = 8;             // waves per SIMD the pair kernel is built for (64 vector registers)
 
 // EXP (experiments flavour only, results incomplete): bit 0 tile records read at lane * 8 (coalesced), bit 1 every lane reads the frame's
@@ -1002,7 +998,9 @@ __global__ __launch_bounds__(256, UPD_WAVES) void tsdf_update_pairs_kernel(Cam c
     if (t < ntask) fetch(t, brick_n, fm_n, subv_n, slot_n);
     unsigned k_next = t < ntask ? take_ticket() : 0u;
     unsigned long long pf_t0 = 0, pf_setup = 0, pf_loop = 0, pf_rmw = 0, pf_bricks = 0, pf_steps = 0, pf_a = 0, pf_b = 0;
+    unsigned long long pf_rt0 = 0;
     if (EXP & 16) pf_t0 = pf_a = __builtin_readcyclecounter();
+    if (EXP & 32) pf_rt0 = __builtin_amdgcn_s_memrealtime();      // light mode: only the start and the end of every wave (the heavy stamps of bit 4 slow the kernel threefold)
     while (t < ntask) {
         const unsigned brick = brick_n, slot = slot_n;
         unsigned subv = subv_n;
@@ -1158,6 +1156,13 @@ __global__ __launch_bounds__(256, UPD_WAVES) void tsdf_update_pairs_kernel(Cam c
             }
         if (EXP & 16) { const unsigned long long now = __builtin_readcyclecounter(); pf_rmw += now - pf_a; pf_a = now; }
     }
+#ifdef TL3D_EXPERIMENTS
+    if ((EXP & 32) && lane == 0) {
+        const unsigned wv = blockIdx.x * 4u + (unsigned)wid;
+        if (wv < 16384u) { g_upd_span[wv][0] = pf_rt0; g_upd_span[wv][1] = __builtin_amdgcn_s_memrealtime(); }
+        if (wv == 0) atomicAdd(counters + 14, 1ull);
+    }
+#endif
     if ((EXP & 16) && lane == 0) {                             // experiments: where a wave's time goes (s_memtime ticks)
         atomicAdd(counters + 8, pf_setup); atomicAdd(counters + 9, pf_loop); atomicAdd(counters + 10, pf_rmw);
         atomicAdd(counters + 11, __builtin_readcyclecounter() - pf_t0); atomicAdd(counters + 12, pf_bricks); atomicAdd(counters + 13, pf_steps);
@@ -1269,7 +1274,8 @@ static BatchBufs batch_bufs(const BatchLayout &L, void *scratch, int n) {
 // The whole prep of a batch of n frames (one depth kind) on stream s: descriptor upload, depth tiles, pyramid, brick
 // classification, sub-brick masks.  `scratch` is a batch scratch of at least n frames (tsdf_batch_scratch_bytes).
 int launch_tsdf_prepare(hipStream_t s, const Cam &cam, const Grid &g, int n, int max_frames, const PoseF *p, const Frustum &fr,
-                        const void *const *depth, bool depth_u16, const float *scale, float mind, float maxd, void *scratch, unsigned *free_cnt) {
+                        const void *const *depth, bool depth_u16, const float *scale, float mind, float maxd, void *scratch, unsigned *free_cnt,
+                        bool classify_only) {
     if (n < 1 || n > max_frames || n > TL3D_TSDF_MAXBATCH) return set_err(TL3D_E_INVALID, "bad batch size %d", n);
     const BatchLayout L = batch_layout(cam, g, max_frames);
     const Pyramid py = make_pyramid(cam);
@@ -1310,6 +1316,7 @@ int launch_tsdf_prepare(hipStream_t s, const Cam &cam, const Grid &g, int n, int
     const int nquad = (ncells + 3) / 4;                 // the cells in view are known only on the device: a fixed grid strides over each frame's list
     hipLaunchKernelGGL(brick_cull_kernel, dim3(nquad < 256 ? nquad : 256, n), dim3(256), 0, s, cam, g, B, fr, py, free_cnt);
     TL3D_HIP(hipGetLastError());
+    if (classify_only) return TL3D_OK;                    // (tl3d_count_bricks: which bricks WOULD get records is all that is asked)
     // sub-brick masks of the listed bricks (their number is known only on the device: a fixed grid strides over each list)
     const int nbricks = g.nbx * g.nby * g.nbz;
     int ncb = (nbricks + 31) / 32;                       // 8 bricks per wave, 4 waves per workgroup
@@ -1387,6 +1394,7 @@ int launch_tsdf_update(hipStream_t s, const Cam &cam, const Grid &g, int n, int 
             case 7: TL3D_LAUNCH_PEXP(7); break;
             case 8: TL3D_LAUNCH_PEXP(8); break;
             case 16: TL3D_LAUNCH_PEXP(16); break;
+            case 32: TL3D_LAUNCH_PEXP(32); break;
             default: TL3D_LAUNCH_PEXP(15); break;
         }
         TL3D_HIP(hipGetLastError());
@@ -1404,5 +1412,23 @@ int launch_tsdf_update(hipStream_t s, const Cam &cam, const Grid &g, int n, int 
     TL3D_HIP(hipGetLastError());
     return TL3D_OK;
 }
+
+#ifdef TL3D_EXPERIMENTS
+// when the waves of the last stamped launch ended (TL3D_PAIRS_EXP=32)
+void tsdf_debug_print_spans(int nwaves) {
+    static unsigned long long h[16384][2];
+    if (nwaves > 16384) nwaves = 16384;
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_upd_span), sizeof(h)) != hipSuccess) return;
+    unsigned long long t0 = ~0ull, t1 = 0;
+    for (int i = 0; i < nwaves; ++i) if (h[i][0]) { if (h[i][0] < t0) t0 = h[i][0]; if (h[i][1] > t1) t1 = h[i][1]; }
+    if (t1 <= t0) return;
+    const double span = (double)(t1 - t0);
+    int he[10] = {0};
+    for (int i = 0; i < nwaves; ++i) if (h[i][0]) { int b = (int)(10.0 * (double)(h[i][1] - t0) / span); he[b > 9 ? 9 : b]++; }
+    fprintf(stderr, "[tl3d exp] launch %.1f us; waves ENDING in each tenth of it:", span * 0.01);
+    for (int i = 0; i < 10; ++i) fprintf(stderr, " %d", he[i]);
+    fprintf(stderr, "\n");
+}
+#endif
 
 }  // namespace tl3d

@@ -145,6 +145,7 @@ static void icp_lane_free(tl3d_ctx::IcpLane &ln);
 static void icp_batch_free(tl3d_ctx::IcpBatch &b);
 static int bp_check_error(tl3d_ctx *ctx, unsigned long long err);
 static int flush_updates(tl3d_ctx *ctx);
+static int flush_centroid(tl3d_ctx *ctx);
 // every call that reads or writes the TSDF grid, re-uses a frame slot, synchronises or time-stamps first issues the deferred updates
 #define FLUSH_UPDATES(ctx_)                      \
     do {                                         \
@@ -245,15 +246,19 @@ static int reset_brick_tables(tl3d_ctx *ctx) {
     return TL3D_OK;
 }
 
-// allocates (or borrows) the grid channels of cfg and the TSDF side stream / scratch; ctx->stream must exist
-static int alloc_grid(tl3d_ctx *ctx, const tl3d_config *cfg) {
-    Grid &g = ctx->grid;
+static void grid_geometry(Grid &g, const tl3d_config *cfg) {
     g.nx = cfg->nx; g.ny = cfg->ny; g.nz = cfg->nz;
     g.nbx = cfg->nx / 8; g.nby = cfg->ny / 8; g.nbz = cfg->nz / 8;
     g.oxd = cfg->origin[0]; g.oyd = cfg->origin[1]; g.ozd = cfg->origin[2]; g.vsd = cfg->voxel_size;
     g.ox = (float)g.oxd; g.oy = (float)g.oyd; g.oz = (float)g.ozd; g.vs = (float)g.vsd;
     g.trunc = (float)cfg->sdf_trunc;
     g.inv_trunc = (cfg->channels & TL3D_CH_TSDF) ? 1.0f / g.trunc : 0.0f;
+}
+
+// allocates (or borrows) the grid channels of cfg and the TSDF side stream / scratch; ctx->stream must exist
+static int alloc_grid(tl3d_ctx *ctx, const tl3d_config *cfg) {
+    Grid &g = ctx->grid;
+    grid_geometry(g, cfg);
     ctx->nvox = (size_t)g.nx * g.ny * g.nz;
     ctx->tsdf_w_upper = 0;
     ctx->tsdf_w_unknown = false;
@@ -309,7 +314,7 @@ static int alloc_grid(tl3d_ctx *ctx, const tl3d_config *cfg) {
             // wave slots: 61.4k frames/s with 768 workgroups, 59.5k with 1024, 58.2k with 2048 (256 CUs).
             int cus = 0;
             if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || cus < 1) cus = 256;
-            ctx->tsdf_max_blocks = env_int("TL3D_UPDATE_BLOCKS", 3 * cus);
+            ctx->tsdf_max_blocks = env_int("TL3D_UPDATE_BLOCKS", 12 * cus);
         }
         if (ctx->tsdf_max_blocks < 8) ctx->tsdf_max_blocks = 8;
         ctx->tsdf_xcd_group = env_int("TL3D_XCD_GROUP", 1);       // consecutive list entries per ticket chunk (1: best balance; 16: 41.8k against 43.8k frames/s)
@@ -530,6 +535,7 @@ int tl3d_destroy(tl3d_ctx *ctx) {
     if (ctx->bp_stage_xyz) (void)hipFree(ctx->bp_stage_xyz);
     if (ctx->bp_stage_rgb) (void)hipFree(ctx->bp_stage_rgb);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+    if (ctx->d_cen_frames) (void)hipFree(ctx->d_cen_frames);
     if (ctx->d_cen_counters) (void)hipFree(ctx->d_cen_counters);
     if (ctx->rccl_comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(ctx->rccl_comm);
     if (ctx->d_maxw) (void)hipFree(ctx->d_maxw);
@@ -851,6 +857,85 @@ int tl3d_frame_bounds(tl3d_ctx *ctx, int slot, const double R[9], const double t
     return tl3d_frames_bounds(ctx, 1, &s, R, t, &scale, flags, subsample, min_depth, max_depth, out_min, out_max);
 }
 
+// ------------------------------------------------------------------------------------------- occupancy of a planned grid
+// Which bricks of a grid (geometry only: no records, no pools) a fusion of these frames WOULD give records to: the TSDF
+// classification of every frame (tiles, pyramid, brick classes: the update's own prep chain, sub-brick masks and update left out)
+// and the bricks the frames' samples fall into, against scratch brick tables whose cursors count the distinct bricks.  What a
+// sparse grid's pools must hold (tl3d_config.pool_bricks_*): the reference's hash-map merge sizes itself (D2R:404-410); a pool is
+// allocated up front, and this is how to know how large -- a few microseconds per frame instead of a guess.
+int tl3d_count_bricks(tl3d_ctx *ctx, const tl3d_config *cfg, int n_frames, const int32_t *slots, const double *R, const double *t,
+                      const double *scales, int centroid_subsample, double min_depth, double max_depth, int64_t *bricks_tsdf,
+                      int64_t *bricks_centroid) {
+    REQUIRE(ctx && cfg && slots && R && t && bricks_tsdf && bricks_centroid, TL3D_E_INVALID, "null argument");
+    REQUIRE(n_frames >= 1, TL3D_E_INVALID, "n_frames must be positive");
+    int rc = validate_grid(cfg);
+    if (rc) return rc;
+    for (int i = 0; i < n_frames; ++i) {
+        rc = check_slot(ctx, slots[i], true);
+        if (rc) return rc;
+    }
+    FLUSH_UPDATES(ctx);
+    TL3D_HIP(hipSetDevice(ctx->device));
+    Grid g;
+    memset(&g, 0, sizeof(g));
+    grid_geometry(g, cfg);
+    const size_t nbr = ((size_t)g.nx * g.ny * g.nz) >> 9;
+    unsigned *tabs = nullptr, *free_cnt = nullptr;
+    void *scratch = nullptr;
+    auto done = [&](int code) {
+        (void)hipStreamSynchronize(ctx->stream);
+        if (tabs) (void)hipFree(tabs);
+        if (free_cnt) (void)hipFree(free_cnt);
+        if (scratch) (void)hipFree(scratch);
+        return code;
+    };
+    if (hipMalloc(&tabs, (2 * nbr + 64) * sizeof(unsigned)) != hipSuccess) return done(set_err(TL3D_E_NOMEM, "brick table alloc failed"));
+    if (hipMemsetAsync(tabs, 0xff, 2 * nbr * sizeof(unsigned), ctx->stream) != hipSuccess || hipMemsetAsync(tabs + 2 * nbr, 0, 64 * sizeof(unsigned), ctx->stream) != hipSuccess)
+        return done(set_err(TL3D_E_HIP, "memset failed"));
+    g.tsdf_tab = tabs; g.cen_tab = tabs + nbr; g.cursors = tabs + 2 * nbr;
+    g.tsdf_cap = g.cen_cap = (unsigned)nbr;
+    const float mind = (float)min_depth, maxd = (float)max_depth;
+    if (cfg->channels & TL3D_CH_TSDF) {
+        const int batch = TL3D_TSDF_MAXBATCH;
+        const size_t sb = tsdf_batch_scratch_bytes(ctx->cam, g, batch);
+        if (hipMalloc(&free_cnt, nbr * sizeof(unsigned)) != hipSuccess || hipMalloc(&scratch, sb) != hipSuccess) return done(set_err(TL3D_E_NOMEM, "scratch alloc (%zu B) failed", sb));
+        size_t zoff = 0, zbytes = 0;
+        tsdf_batch_scratch_zero_range(ctx->cam, g, batch, &zoff, &zbytes);
+        if (hipMemsetAsync(free_cnt, 0, nbr * sizeof(unsigned), ctx->stream) != hipSuccess) return done(set_err(TL3D_E_HIP, "memset failed"));
+        const Frustum fr = make_frustum(ctx->cam);
+        for (int i0 = 0; i0 < n_frames; i0 += batch) {
+            const int m = n_frames - i0 < batch ? n_frames - i0 : batch;
+            PoseF poses[TL3D_TSDF_MAXBATCH];
+            const void *depths[TL3D_TSDF_MAXBATCH];
+            float sc[TL3D_TSDF_MAXBATCH];
+            for (int j = 0; j < m; ++j) {
+                poses[j] = make_pose_f(R + (size_t)9 * (i0 + j), t + (size_t)3 * (i0 + j));
+                depths[j] = ctx->slots[slots[i0 + j]].depth;
+                sc[j] = (float)(scales ? scales[i0 + j] : 1.0);
+            }
+            if (hipMemsetAsync((char *)scratch + zoff, 0, zbytes, ctx->stream) != hipSuccess) return done(set_err(TL3D_E_HIP, "memset failed"));    // (no update re-arms the frame masks)
+            rc = launch_tsdf_prepare(ctx->stream, ctx->cam, g, m, batch, poses, fr, depths, false, sc, mind, maxd, scratch, free_cnt, true);
+            if (rc) return done(rc);
+        }
+    }
+    if ((cfg->channels & TL3D_CH_CENTROID) && centroid_subsample >= 1) {
+        for (int i = 0; i < n_frames; ++i) {
+            BpArgs a;
+            rc = make_bp_args(ctx, scales ? scales[i] : 1.0, 0, centroid_subsample, min_depth, max_depth, &a);
+            if (rc) return done(rc);
+            const PoseD p = make_pose_d(R + (size_t)9 * i, t + (size_t)3 * i, false);
+            rc = launch_centroid_mark(ctx->stream, ctx->cam, g, a, p, ctx->slots[slots[i]].depth, ctx->bp_factors, ctx->bp_factors + ctx->cam.W);
+            if (rc) return done(rc);
+        }
+    }
+    unsigned cur[4] = {0, 0, 0, 0};
+    if (hipMemcpyAsync(cur, g.cursors, sizeof(cur), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return done(set_err(TL3D_E_HIP, "copy failed"));
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return done(set_err(TL3D_E_HIP, "sync failed"));
+    *bricks_tsdf = (int64_t)(cur[0] < nbr ? cur[0] : nbr);
+    *bricks_centroid = (int64_t)(cur[2] < nbr ? cur[2] : nbr);
+    return done(TL3D_OK);
+}
+
 // ------------------------------------------------------------------------------------------- centroid accumulation
 int tl3d_accumulate_centroid(tl3d_ctx *ctx, int slot, const double R[9], const double t[3], double scale, uint32_t flags,
                              int subsample, double min_depth, double max_depth) {
@@ -861,14 +946,19 @@ int tl3d_accumulate_centroid(tl3d_ctx *ctx, int slot, const double R[9], const d
     BpArgs a;
     rc = make_bp_args(ctx, scale, flags, subsample, min_depth, max_depth, &a);
     if (rc) return rc;
-    TL3D_HIP(hipSetDevice(ctx->device));
     const Slot &s = ctx->slots[slot];
-    const PoseD p = make_pose_d(R, t, (flags & TL3D_F_NO_POSE) != 0);
-    ctx->grid_epoch++;
-    rc = launch_centroid_frame(ctx->stream, ctx->cam, ctx->grid, a, p, s.depth, s.has_color ? s.bgr : nullptr, ctx->bp_factors, ctx->bp_factors + ctx->cam.W,
-                               ctx->centroid, ctx->d_cen_counters);
-    if (rc) return rc;
-    ctx->stats.centroid_launches++;
+    // The frame joins the pending batch (one stride per batch); the batch goes out when it is full, or when any call needs the grid,
+    // a slot, a sync or a time stamp (flush_updates).  Integer sums: the grid does not depend on where the batches are cut.
+    if (ctx->n_cen_pend > 0 && ctx->cen_pend[0].a.sub != a.sub) {
+        rc = flush_centroid(ctx);
+        if (rc) return rc;
+    }
+    CenFrame &f = ctx->cen_pend[ctx->n_cen_pend++];
+    f.p = make_pose_d(R, t, (flags & TL3D_F_NO_POSE) != 0);
+    f.a = a;
+    f.depth = s.depth;
+    f.bgr = s.has_color ? s.bgr : nullptr;
+    if (ctx->n_cen_pend >= TL3D_CEN_MAXBATCH) return flush_centroid(ctx);
     return TL3D_OK;
 }
 
@@ -968,7 +1058,27 @@ static int ktimer_begin(tl3d_ctx *ctx) {
 // Issues the pending batch: its prep chain on a side stream (it needs the frames' uploads, the batch scratch whose previous
 // user -- three batches ago -- has been updated, and the last clear / fold of the free-space counters), then ONE update launch on
 // the main stream behind it.  Results never depend on where the batch boundaries fall (integer sums).
+// the pending voxel-centroid accumulations: one launch for all of them (they share a stride)
+static int flush_centroid(tl3d_ctx *ctx) {
+    if (ctx->n_cen_pend == 0) return TL3D_OK;
+    const int n = ctx->n_cen_pend;
+    ctx->n_cen_pend = 0;                                // whatever happens below, the batch is consumed
+    TL3D_HIP(hipSetDevice(ctx->device));
+    if (!ctx->d_cen_frames && hipMalloc(&ctx->d_cen_frames, sizeof(CenFrame) * TL3D_CEN_MAXBATCH) != hipSuccess)
+        return set_err(TL3D_E_NOMEM, "centroid descriptor alloc failed");
+    ctx->grid_epoch++;
+    const int rc = launch_centroid_batch(ctx->stream, ctx->cam, ctx->grid, n, ctx->cen_pend, ctx->d_cen_frames, ctx->bp_factors, ctx->bp_factors + ctx->cam.W,
+                                         ctx->centroid, ctx->d_cen_counters);
+    if (rc) return rc;
+    ctx->stats.centroid_launches++;
+    return TL3D_OK;
+}
+
 static int flush_updates(tl3d_ctx *ctx) {
+    {
+        const int crc = flush_centroid(ctx);
+        if (crc) return crc;
+    }
     if (ctx->n_pend == 0) return TL3D_OK;
     ctx->grid_epoch++;
     TL3D_HIP(hipSetDevice(ctx->device));
@@ -2066,6 +2176,7 @@ int tl3d_get_stats(tl3d_ctx *ctx, tl3d_stats *out) {
 #ifdef TL3D_EXPERIMENTS
     if (h[14]) fprintf(stderr, "[tl3d exp] update kernel, per wave (s_memtime ticks): setup %.0f  pair loop %.0f  record update %.0f  lifetime %.0f;  bricks per wave %.2f, pairs per brick %.1f, waves %llu; longest wave %.0f x launches\n",
                        (double)h[8] / h[14], (double)h[9] / h[14], (double)h[10] / h[14], (double)h[11] / h[14], (double)h[12] / h[14], h[12] ? (double)h[13] / h[12] : 0.0, h[14], (double)h[15]);
+    if (h[14]) tsdf_debug_print_spans(ctx->tsdf_max_blocks * 4 > 16384 ? 16384 : ctx->tsdf_max_blocks * 4);
 #endif
     if (ctx->brick_tabs) {
         unsigned cur[4] = {0, 0, 0, 0};

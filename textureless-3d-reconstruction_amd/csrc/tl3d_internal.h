@@ -31,7 +31,9 @@ struct Grid {
     const unsigned *free_cnt;    // per-brick free-space counts not yet folded into records (readers add them: see tsdf_record)
 };
 constexpr unsigned SLOT_EMPTY = 0xffffffffu;    // no records yet
-constexpr unsigned SLOT_FULL = 0xfffffffeu;     // the pool had no slot left when the brick was first touched: its updates are dropped (counted)
+constexpr unsigned SLOT_PENDING = 0xfffffffeu;  // a wave is drawing the brick's slot right now (inside the allocating kernel only)
+constexpr unsigned SLOT_FULL = 0xfffffffdu;     // the pool had no slot left when the brick was first touched: its updates are dropped (counted)
+                                                // (every value >= SLOT_FULL reads as "no records")
 
 struct PoseF {                   // world->camera, f32 (or src->tgt for ICP)
     float r[9];
@@ -48,6 +50,15 @@ struct BpArgs {                  // back-projection arguments common to count / 
     unsigned flags;
     double scale, min_d, max_d;
     unsigned long long zero;     // 0 the compiler cannot see: fetch_add(p, zero) stays a read-modify-write (a fresh read, see bp look-back)
+};
+
+// one frame of a batch of voxel-centroid accumulations (kernels_centroid.hip)
+constexpr int TL3D_CEN_MAXBATCH = 32;
+struct CenFrame {
+    PoseD p;
+    BpArgs a;
+    const float *depth;
+    const uint8_t *bgr;
 };
 
 // frustum side planes for brick culling: inside iff nx*x + nz*z >= -rad (left/right), ny*y + nz*z >= -rad
@@ -168,6 +179,9 @@ struct tl3d_ctx {
     int tsdf_batch;                       // frames per batch (env TL3D_TSDF_BATCH, default 32; 1 = no deferral)
     unsigned tsdf_seq, tsdf_batch_no;
     struct PendingUpdate { int slot; tl3d::PoseF pose; float scale; } pend[TL3D_TSDF_MAXBATCH];
+    tl3d::CenFrame cen_pend[tl3d::TL3D_CEN_MAXBATCH];   // voxel-centroid accumulations not yet launched (one stride per batch)
+    int n_cen_pend = 0;
+    tl3d::CenFrame *d_cen_frames = nullptr;              // their descriptors on the device
     int n_pend;                           // frames of the batch being collected
     // extraction is called twice (size query, then with buffers): the block counts of the query are kept while nothing
     // has touched the grids in between (every grid-modifying or pointer-exposing call bumps grid_epoch)
@@ -287,33 +301,46 @@ __device__ __forceinline__ size_t vox_index(int i, int j, int k, int nbx, int nb
 __device__ __forceinline__ unsigned brick_slot(const unsigned *table, unsigned brick) {
     return __hip_atomic_load(table + brick, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// Slot of `brick`, handing one out on first touch.  Wait-free: the slot is drawn before the compare-and-swap, the loser of a
-// race keeps the winner's slot and its own draw is lost to the pool (callers make sure that the lanes of ONE wave do not race
-// for the same brick -- see wave_slots -- so that only cross-wave races leak, and those are rare).  SLOT_FULL when the pool is
-// exhausted (sticky: later touches see it in the table).
+// Slot of `brick`, handing one out on first touch -- exactly one per brick: the wave that turns the entry from EMPTY to PENDING
+// draws the slot and publishes it; a wave that finds PENDING waits for that store (the drawing wave waits for nobody: an atomic add
+// and a store, so the wait ends; it is bounded all the same -- ~30 ms -- and then gives up as if the pool were full, counted).
+// Until round 3 every contender drew a slot and the losers of the compare-and-swap lost theirs to the pool: with 32 frames per
+// accumulation launch, first touches of one brick by a dozen workgroups at once, a tenth of the centroid pool leaked, and a pool
+// sized by a count (tl3d_count_bricks) must not leak.  SLOT_FULL when the pool is exhausted (sticky: later touches see it).
 __device__ __forceinline__ unsigned brick_slot_ensure(unsigned *table, unsigned *cursor, unsigned cap, unsigned brick) {
-    unsigned s = brick_slot(table, brick);
-    if (s != SLOT_EMPTY) return s;
-    unsigned n = atomicAdd(cursor, 1u);
-    if (n >= cap) {
-        n = SLOT_FULL;
-        atomicAdd(cursor + 1, 1u);
+    for (unsigned spin = 0; spin < (1u << 20); ++spin) {
+        const unsigned s = brick_slot(table, brick);
+        if (s < SLOT_PENDING) return s;                            // a slot, or SLOT_FULL
+        if (s == SLOT_EMPTY) {
+            const unsigned old = atomicCAS(table + brick, SLOT_EMPTY, SLOT_PENDING);
+            if (old == SLOT_EMPTY) {
+                unsigned n = atomicAdd(cursor, 1u);
+                if (n >= cap) {
+                    n = SLOT_FULL;
+                    atomicAdd(cursor + 1, 1u);
+                }
+                __hip_atomic_store(table + brick, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return n;
+            }
+            if (old < SLOT_PENDING) return old;
+        }
+        __builtin_amdgcn_s_sleep(2);
     }
-    const unsigned old = atomicCAS(table + brick, SLOT_EMPTY, n);
-    return old == SLOT_EMPTY ? n : old;
+    atomicAdd(cursor + 1, 1u);
+    return SLOT_FULL;
 }
 // the same for every lane of a wave at once (want: the lane needs its brick's slot): one leader per distinct brick draws, the
 // lanes that share the brick take its answer.  Every lane of the wave must call it.
 __device__ __forceinline__ unsigned wave_slots(unsigned *table, unsigned *cursor, unsigned cap, unsigned brick, bool want) {
     unsigned slot = want ? brick_slot(table, brick) : 0u;          // the common case: every brick has its slot already
-    unsigned long long todo = __ballot(want && slot == SLOT_EMPTY);
+    unsigned long long todo = __ballot(want && slot >= SLOT_PENDING);
     while (todo) {
         const int leader = __builtin_ctzll(todo);
         const unsigned b = (unsigned)__builtin_amdgcn_readlane((int)brick, leader);
         unsigned s = 0;
         if ((threadIdx.x & 63) == leader) s = brick_slot_ensure(table, cursor, cap, b);
         s = (unsigned)__builtin_amdgcn_readlane((int)s, leader);
-        const bool mine = want && slot == SLOT_EMPTY && brick == b;
+        const bool mine = want && slot >= SLOT_PENDING && brick == b;
         todo &= ~__ballot(mine);
         if (mine) slot = s;
     }
@@ -352,8 +379,8 @@ int launch_bp_fused(hipStream_t s, const Cam &cam, const BpArgs &a, const PoseD 
                     const double *xf, const double *yf, unsigned long long *state, float *xyz, uint8_t *rgb, unsigned long long cap,
                     unsigned long long *total_out, bool force_dynamic = false);
 // centroid
-int launch_centroid_frame(hipStream_t s, const Cam &cam, const Grid &g, const BpArgs &a, const PoseD &p, const float *depth,
-                          const uint8_t *bgr, const double *xf, const double *yf, unsigned long long *grid, unsigned long long *counters);
+int launch_centroid_batch(hipStream_t s, const Cam &cam, const Grid &g, int n, const CenFrame *host, CenFrame *dev, const double *xf, const double *yf,
+                          unsigned long long *grid, unsigned long long *counters);
 int launch_centroid_points(hipStream_t s, const Grid &g, const float *xyz, const uint8_t *rgb, long long n,
                            unsigned long long *grid, unsigned long long *counters);
 int launch_bounds(hipStream_t s, const float *xyz, long long n, float *slab, int nblocks);
@@ -361,7 +388,12 @@ int launch_bounds(hipStream_t s, const float *xyz, long long n, float *slab, int
 size_t tsdf_batch_scratch_bytes(const Cam &cam, const Grid &g, int max_frames);
 void tsdf_batch_scratch_zero_range(const Cam &cam, const Grid &g, int max_frames, size_t *off, size_t *bytes);
 int launch_tsdf_prepare(hipStream_t s, const Cam &cam, const Grid &g, int n, int max_frames, const PoseF *p, const Frustum &fr,
-                        const void *const *depth, bool depth_u16, const float *scale, float mind, float maxd, void *scratch, unsigned *free_cnt);
+                        const void *const *depth, bool depth_u16, const float *scale, float mind, float maxd, void *scratch, unsigned *free_cnt,
+                        bool classify_only = false);
+int launch_centroid_mark(hipStream_t s, const Cam &cam, const Grid &g, const BpArgs &a, const PoseD &p, const float *depth, const double *xf, const double *yf);
+#ifdef TL3D_EXPERIMENTS
+void tsdf_debug_print_spans(int nwaves);
+#endif
 int launch_tsdf_update(hipStream_t s, const Cam &cam, const Grid &g, int n, int max_frames, bool depth_u16, float mind, float maxd, int2 *grid,
                        void *scratch, unsigned long long *counters, bool count, int max_blocks, int xcd_group);
 int launch_fold_free(hipStream_t s, const Grid &g, int2 *grid, unsigned *free_cnt);

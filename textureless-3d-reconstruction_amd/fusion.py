@@ -245,6 +245,27 @@ class FusionContext:
                                                abi.ptr(lo), abi.ptr(hi)))
         return lo, hi
 
+    def count_bricks(self, grid: "GridSpec", slots, poses, scales=None, centroid_subsample: int = 1, min_depth=None, max_depth=None):
+        """(TSDF bricks, centroid bricks) a fusion of these frames into `grid` would give records to -- geometry only, nothing is
+        allocated or written: what a sparse grid's pools must hold (tl3d.h: tl3d_count_bricks)."""
+        n = len(slots)
+        cfg = abi.Config()
+        cfg.abi_version = abi.ABI_VERSION
+        cfg.channels = int(grid.channels)
+        cfg.nx, cfg.ny, cfg.nz = (int(d) for d in grid.dims)
+        cfg.origin = (C.c_double * 3)(*[float(o) for o in grid.origin])
+        cfg.voxel_size, cfg.sdf_trunc = float(grid.voxel_size), float(grid.sdf_trunc)
+        sl = np.ascontiguousarray(slots, np.int32)
+        R = np.ascontiguousarray(np.stack([np.asarray(p[0], np.float64).reshape(3, 3) for p in poses]))
+        t = np.ascontiguousarray(np.stack([np.asarray(p[1], np.float64).reshape(3) for p in poses]))
+        sc = np.ascontiguousarray(np.ones(n) if scales is None else np.asarray(scales, np.float64))
+        mn_d = self.min_depth if min_depth is None else float(min_depth)
+        mx_d = self.max_depth if max_depth is None else float(max_depth)
+        nt, nc = C.c_int64(0), C.c_int64(0)
+        abi.check(self._lib.tl3d_count_bricks(self._h, C.byref(cfg), n, abi.ptr(sl), abi.ptr(R), abi.ptr(t), abi.ptr(sc), int(centroid_subsample),
+                                              mn_d, mx_d, C.byref(nt), C.byref(nc)))
+        return int(nt.value), int(nc.value)
+
     # ---- fusion ----------------------------------------------------------------------------
     def accumulate_centroid(self, slot: int, pose=None, scale=1.0, subsample: int = 1, min_depth=None, max_depth=None,
                             scale_f64: bool = False):

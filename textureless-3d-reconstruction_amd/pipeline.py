@@ -38,8 +38,9 @@ def plan_grid(bounds_min, bounds_max, voxel_size, grid_dim, channels=abi.CH_TSDF
     Up to a voxel BUDGET (default grid_dim^3 voxels in total; not a cube: a 2 m x 2.4 m x 12 m corridor at 5 mm becomes
     400 x 480 x 2400 voxels) the grid is dense.  Beyond it the grid is SPARSE, as the reference's hash-map merge is
     (D2R:404-410): the same dims, records only for the bricks the data touches, pools sized by sparse_bytes (default: the dense
-    budget's bytes).  Only a scene of more than 2^32 voxels is shrunk about its centre -- longest axis first -- and `clipped`
-    returned True (points outside are dropped and counted by the accumulation kernels; the caller prints the warning)."""
+    budget's bytes) -- a GUESS when nothing is known about the frames; choose_layout() replaces it by a count.  Only a scene of
+    more than 2^32 voxels is shrunk about its centre -- longest axis first -- and `clipped` returned True (points outside are
+    dropped and counted by the accumulation kernels; the caller prints the warning)."""
     v = float(voxel_size)
     mn, mx = np.asarray(bounds_min, np.float64), np.asarray(bounds_max, np.float64)
     origin = mn - 0.5 * v
@@ -70,6 +71,44 @@ def plan_grid(bounds_min, bounds_max, voxel_size, grid_dim, channels=abi.CH_TSDF
         pool_c = int(min(nvox // 512, surf)) if channels & abi.CH_CENTROID else 0
     return GridSpec(tuple(int(d) for d in dims), tuple(float(o) for o in origin), v, trunc_voxels * v, channels,
                     pool_tsdf=pool_t, pool_centroid=pool_c), clipped
+
+
+DENSE_WITHOUT_ASKING = 1 << 30        # bytes: below this a dense grid is allocated (and cleared) faster than its occupancy is counted
+
+
+def layout_from_counts(grid: GridSpec, bricks_tsdf: int, bricks_centroid: int) -> GridSpec:
+    """Per channel: a pool of the counted bricks (+ 3 % + 2048: a slot lost to a race between two waves is not reused) when that
+    is less than half of the dense channel, else the dense channel."""
+    nbr = grid.nvox // 512
+    pool_t = pool_c = 0
+    if grid.channels & abi.CH_TSDF:
+        want = int(bricks_tsdf * 1.03) + 2048
+        pool_t = want if 2 * want < nbr else 0
+    if grid.channels & abi.CH_CENTROID:
+        want = int(bricks_centroid * 1.03) + 2048
+        pool_c = want if 2 * want < nbr else 0
+    return GridSpec(grid.dims, grid.origin, grid.voxel_size, grid.sdf_trunc, grid.channels, pool_tsdf=pool_t, pool_centroid=pool_c)
+
+
+def choose_layout(ctx: FusionContext, grid: GridSpec, slots, poses, scales, centroid_subsample, dist=None, log=print) -> GridSpec:
+    """Dense or sparse, from what the frames will really touch (tl3d_count_bricks: the fusion's own classification, no records).
+
+    The reference's merge is a hash map over occupied voxels (D2R:404-410): memory follows the surfaces, whatever the extent.
+    Here a grid is allocated (and cleared) before the first frame is fused, so its layout is a decision -- taken from a count, not
+    from the extent.  Small grids are dense without asking.  With `dist` (reconstruct_sharded) every rank counts its own frames and
+    all take the SUM (an upper bound of the union the merge will bring to every rank), so that all ranks choose alike."""
+    nbr = grid.nvox // 512
+    dense = GridSpec(grid.dims, grid.origin, grid.voxel_size, grid.sdf_trunc, grid.channels)
+    if dense.device_bytes() <= DENSE_WITHOUT_ASKING:
+        return dense
+    nt, nc = ctx.count_bricks(grid, slots, poses, scales, centroid_subsample=centroid_subsample) if len(slots) else (0, 0)
+    if dist is not None:
+        from . import distributed as dd
+        nt, nc = dd.allreduce_counts([nt, nc], dist)
+    out = layout_from_counts(grid, nt, nc)
+    log(f"  Occupancy: {nt} TSDF bricks, {nc} centroid bricks of {nbr}: "
+        f"{'sparse' if out.sparse else 'dense'} volume, {out.device_bytes() / 2**30:.2f} GiB (dense: {dense.device_bytes() / 2**30:.2f} GiB)")
+    return out
 
 
 class ScaleTracker:
@@ -383,6 +422,9 @@ class DepthToReconstructionPipeline:
                     print(f"  Warning: scene extent {np.round(mx - mn, 3)} m at {cfg.voxel_size} m voxels exceeds the budget of "
                           f"{cfg.grid_dim}^3 voxels; the grid {grid.dims} is centred on the scene and points outside it are dropped "
                           "(raise --grid or --voxel-size)")
+                # dense or sparse: from the bricks these frames will really touch, not from the extent
+                grid = choose_layout(ctx, grid, self.frame_index, self.camera_poses, [self.scales[fi] for fi in self.frame_index],
+                                     cfg.subsample_factor)
             print(f"  Grid {grid.dims} @ {grid.voxel_size * 1e3:g} mm, origin {np.round(grid.origin, 4)}")
             self.grid = grid
             ctx.attach_grid(grid)
@@ -542,6 +584,8 @@ class DepthToReconstructionPipeline:
                     say(f"  Warning: scene extent {np.round(mx - mn, 3)} m at {cfg.voxel_size} m voxels exceeds the budget of "
                         f"{cfg.grid_dim}^3 voxels; the grid {grid.dims} is centred on the scene and points outside it are dropped "
                         "(raise --grid or --voxel-size)")
+                grid = choose_layout(ctx, grid, [slot_of[g] for g in mine], [pose_of[g] for g in mine], [self.scales[g] for g in mine],
+                                     cfg.subsample_factor, dist=dist if world > 1 else None, log=say)
             say(f"  Grid {grid.dims} @ {grid.voxel_size * 1e3:g} mm, origin {np.round(grid.origin, 4)}")
             self.grid = grid
             ctx.attach_grid(grid)
