@@ -7,14 +7,19 @@
 
 A step = one pass of the hot path over one batch of --frames-per-step synthetic frames per GPU (512 = one turn of a
 512-frame orbit, frames 0.7 degrees apart): each frame, already resident in HBM, is integrated into that GPU's 512^3 TSDF
-grid with tl3d_integrate; the library updates two consecutive frames per launch (roofline.frames_per_sweep = 2; the
-same frames at one per launch are measured beside it: roofline.single_frame_per_sweep).  With N > 1 the frames shard
-across ranks (weak scaling: per-GPU batch fixed) and the per-GPU grids are summed once with an RCCL all-reduce inside
-the timed region.  Rank 0 prints ONE JSON line.
+grid with ONE foreign call per 64 frames (tl3d_fuse_frames); the library updates 32 frames per launch
+(roofline.frames_per_sweep = 32; the same frames at one per launch are measured beside it:
+roofline.single_frame_per_sweep).  With N > 1 the frames shard across ranks (weak scaling: per-GPU batch fixed) and the
+per-GPU grids are summed with the product's merge inside the timed region.  Rank 0 prints ONE JSON line.
 
 roofline: algorithmic bytes per launch are COUNTED by the kernel (8 B x (records read + records written),
 SURVEY.md section 8d) plus the depth bytes of the launch's frames; time is hipEvent time on the launching stream over
-the timed region.  cpu_baseline: the C oracle (oracle/tl3d_oracle.c, OpenMP) on the host cores, bounded sample.
+the timed region.  roofline.bound names what really limits the kernel (vector-instruction issue: DESIGN.md 7.5); achieved /
+peak / frac stay priced on the algorithmic HBM bytes, as the measurement contract defines them.  roofline.traffic and the
+two sub-objects scattered_reads / vector_alu come from the builder's own rocprofv3 --pmc passes (profiles/pmc_traffic.json,
+keyed by workload): counters need passes of their own, they are NOT counters of this run, and the line says so.
+cpu_baseline: the C oracle (oracle/tl3d_oracle.c, OpenMP) on the host cores, bounded sample.  rows: the other rows of the
+path, each timed over 5 repetitions (median; [min, max] in rows.spread).
 """
 import argparse
 import json
@@ -307,8 +312,13 @@ def main():
             except Exception:
                 traffic = None
         paired = m["frames_per_sweep"] > 1.01
-        roof = {"bound": "hbm", "kernel": "tsdf_update_kernel", "achieved": m["achieved"], "peak": 8000.0,
+        roof = {"bound": "valu", "bound_note": "the kernel (and the batch: prep chain + update) is limited by vector-instruction issue, "
+                                                 "not by HBM (DESIGN.md 7.5: 4.4 cycles per wave instruction per SIMD measured, tools/ubench_issue.hip); "
+                                                 "achieved / peak / frac are the contract's HBM pricing of the algorithmic bytes",
+                "kernel": "tsdf_update_pairs_kernel", "achieved": m["achieved"], "peak": 8000.0,
                 "unit": "GB/s", "frac": m["frac"], "traffic": traffic,
+                "traffic_source": ("profiles/pmc_traffic.json: the builder's own rocprofv3 --pmc passes over this workload (separate runs; "
+                                   "not counters of this run)") if traffic is not None else None,
                 "bytes_per_launch": m["bytes_per_launch"], "records_per_launch": m["records_per_launch"],
                 "dense_sweep_bytes": int(16.0 * n ** 3 + 4.0 * H * W), "bricks_visited_per_launch": m["bricks_visited_per_launch"],
                 "free_space_bricks_per_launch": m["free_space_bricks_per_launch"],
@@ -320,12 +330,14 @@ def main():
             # 64-B read requests that leave the L2 per second against the chip's measured rate for scattered 4-B reads, and the share
             # of the launch the vector ALU needs at full issue rate (4 cycles per instruction, 4 SIMDs on each of 256 CUs, 2.4 GHz)
             rate = pmc_extra["l2_read_requests_per_launch"] / (m["ms_per_launch"] * 1e-3)
-            roof["scattered_reads"] = {"l2_read_requests_per_launch": pmc_extra["l2_read_requests_per_launch"],
+            roof["scattered_reads"] = {"source": "profiles/pmc_traffic.json (builder PMC passes) + this run's timing",
+                                       "l2_read_requests_per_launch": pmc_extra["l2_read_requests_per_launch"],
                                        "achieved_G_per_s": round(rate * 1e-9, 2), "roof_G_per_s": round(pmc_extra["scattered_read_roof_requests_per_s"] * 1e-9, 2),
                                        "frac": round(rate / pmc_extra["scattered_read_roof_requests_per_s"], 4)}
             if pmc_extra.get("valu_instructions_per_launch"):
                 valu_ms = pmc_extra["valu_instructions_per_launch"] * 4.0 / (1024 * 2.4e9) * 1e3
-                roof["vector_alu"] = {"instructions_per_launch": pmc_extra["valu_instructions_per_launch"], "ms_at_full_issue_rate": round(valu_ms, 4),
+                roof["vector_alu"] = {"source": "profiles/pmc_traffic.json (builder PMC passes) + this run's timing",
+                                      "instructions_per_launch": pmc_extra["valu_instructions_per_launch"], "ms_at_full_issue_rate": round(valu_ms, 4),
                                       "frac_of_launch": round(valu_ms / m["ms_per_launch"], 4)}
         if paired and not args.no_single:
             # the same frames, one per launch (F = 1: what the fraction was quoted on before), same context, same buffers
@@ -391,32 +403,51 @@ def main():
             ctx.sync()
             return (time.perf_counter() - tq) / reps
 
+        REPS = 5                                                   # every row: median of 5 samples, [min, max] in rows.spread
+        spread = {}
+
+        def sampled(key, fn, reps, to_value, digits=1):
+            vals = sorted(to_value(timed(fn, reps)) for _ in range(REPS))
+            rows[key] = round(vals[REPS // 2], digits)
+            spread[key] = [round(vals[0], digits), round(vals[-1], digits)]
+
         rows = {}
         nf = 256
         ctx.reset()
-        t_s = timed(lambda k: step(k, icp=False, centroid=True, frames=nf), 2)
-        rows["tsdf_plus_centroid_s2_fps"] = round(nf / t_s, 1)
+        sampled("tsdf_plus_centroid_s2_fps", lambda k: step(k, icp=False, centroid=True, frames=nf), 2, lambda t_: nf / t_)
         ctx.reset()
-        t_s = timed(lambda k: step(k, icp=True, centroid=False, frames=nf), 2)
-        rows["icp_in_loop_tsdf_fps"] = round(nf / t_s, 1)
+        sampled("icp_in_loop_tsdf_fps", lambda k: step(k, icp=True, centroid=False, frames=nf), 2, lambda t_: nf / t_)
         ctx.reset()
-        t_s = timed(lambda k: step(k, icp=True, centroid=True, frames=nf), 2)
-        rows["icp_in_loop_tsdf_plus_centroid_fps"] = round(nf / t_s, 1)
+        sampled("icp_in_loop_tsdf_plus_centroid_fps", lambda k: step(k, icp=True, centroid=True, frames=nf), 2, lambda t_: nf / t_)
+        # the centroid channel alone (stride 2, the reference's default D2R:65): counted bytes per frame = the samples read
+        # ((4 + 3) B each) + 2 x 32 B per record update (counted by the kernel: one per distinct voxel and 32 x 32 tile of samples)
+        ctx.reset()
+        ctx.reset_stats()
+        sampled("centroid_s2_us_per_frame", lambda k: [ctx.accumulate_centroid((k * nf + j) % n_res, poses[(k * nf + j) % n_res], subsample=2) for j in range(nf)],
+                2, lambda t_: 1e6 * t_ / nf, digits=2)
+        stc = ctx.stats()
+        n_acc = max(1, stc["centroid_launches"])
+        upd_per_frame = stc["centroid_record_updates"] / max(1.0, (REPS * 3.0 * nf))
+        cen_bytes = (4 + 3) * (H // 2) * (W // 2) + 64.0 * upd_per_frame
+        rows["centroid"] = {"subsample": 2, "us_per_frame": rows["centroid_s2_us_per_frame"], "record_updates_per_frame": int(upd_per_frame),
+                            "bytes_per_frame": int(cen_bytes), "achieved_GBps": round(cen_bytes / (rows["centroid_s2_us_per_frame"] * 1e-6) / 1e9, 1),
+                            "frac_of_8TBps": round(cen_bytes / (rows["centroid_s2_us_per_frame"] * 1e-6) / 8e12, 4), "frames_per_launch": 32,
+                            "launches": int(n_acc)}
+        ctx.reset()
         rows["icp"] = {"iters": args.icp_iters, "stride": 4, "pairs_per_launch": 64, "prior": "analytic inter-frame motion"}
-        one = timed(lambda k: ctx.icp((k - 1) % n_res, k % n_res, T_init=T_rel[k % n_res], iters=args.icp_iters, stride=4, max_dist=0.05, eps=0.0), 24)
-        rows["icp_single_chain_us_per_iteration"] = round(1e6 * one / (args.icp_iters + 1), 2)
+        sampled("icp_single_chain_us_per_iteration",
+                lambda k: ctx.icp((k - 1) % n_res, k % n_res, T_init=T_rel[k % n_res], iters=args.icp_iters, stride=4, max_dist=0.05, eps=0.0), 24,
+                lambda t_: 1e6 * t_ / (args.icp_iters + 1), digits=2)
         # batched registration alone: every resident pair in ONE launch (all iterations inside the kernel), and the pipeline's
         # two-level coarse-to-fine schedule (10 x stride 4 @ 20 cm, then 15 x stride 2 @ 5 cm, stop at a 1e-7 update)
         all_pairs = [((k - 1) % n_res, k) for k in range(n_res)]
         fixed = [dict(iters=args.icp_iters, stride=4, max_dist=0.05, eps=0.0)]
-        t_b = timed(lambda k: ctx.icp_batch(all_pairs, fixed, T_init=T_rel), 4)
-        rows["icp_batch_pairs_per_s"] = round(n_res / t_b, 1)
-        rows["icp_batch_us_per_pair_iteration"] = round(1e6 * t_b / n_res / (args.icp_iters + 1), 3)
+        sampled("icp_batch_pairs_per_s", lambda k: ctx.icp_batch(all_pairs, fixed, T_init=T_rel), 2, lambda t_: n_res / t_)
+        rows["icp_batch_us_per_pair_iteration"] = round(1e6 / rows["icp_batch_pairs_per_s"] / (args.icp_iters + 1), 3)
         two = [dict(iters=10, stride=4, max_dist=0.2, eps=1e-7), dict(iters=15, stride=2, max_dist=0.05, eps=1e-7)]
-        t_b = timed(lambda k: ctx.icp_batch(all_pairs, two), 4)
-        rows["icp_batch_two_level_from_identity_pairs_per_s"] = round(n_res / t_b, 1)
-        t_b = timed(lambda k: ctx.icp_batch(all_pairs[1:2], fixed, T_init=T_rel[1:2]), 16)
-        rows["icp_batch_one_pair_us_per_iteration"] = round(1e6 * t_b / (args.icp_iters + 1), 2)
+        sampled("icp_batch_two_level_from_identity_pairs_per_s", lambda k: ctx.icp_batch(all_pairs, two), 2, lambda t_: n_res / t_)
+        sampled("icp_batch_one_pair_us_per_iteration", lambda k: ctx.icp_batch(all_pairs[1:2], fixed, T_init=T_rel[1:2]), 16,
+                lambda t_: 1e6 * t_ / (args.icp_iters + 1), digits=2)
         cap_pts = H * W
         xyz_d = torch.empty((cap_pts, 3), dtype=torch.float32, device=dev)
         rgb_d = torch.empty((cap_pts, 3), dtype=torch.uint8, device=dev)
@@ -441,6 +472,8 @@ def main():
         keep = ctx.statistical_outlier(pts, 20, 2.0, cell_size=2.0 * args.voxel)
         rows["outlier_filter_k20_ms"] = round(1e3 * (time.perf_counter() - tq), 2)
         rows["outlier_filter_kept"] = int(keep.sum())
+        rows["spread"] = spread
+        rows["repetitions"] = REPS
         ctx.reset()
 
     if rank == 0:

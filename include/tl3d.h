@@ -147,6 +147,7 @@ typedef struct tl3d_stats {
     uint64_t pool_slots_tsdf;        /* sparse grids: brick slots handed out so far, per channel (dense: every brick)             */
     uint64_t pool_slots_centroid;
     uint64_t pool_refused;           /* first touches refused because a pool was full: > 0 means the result lacks those bricks   */
+    uint64_t centroid_record_updates; /* 32-B centroid records added to in the grid (counted: one per distinct voxel and tile of samples) */
 } tl3d_stats;
 
 const char *tl3d_last_error(void);

@@ -73,7 +73,8 @@ class Stats(C.Structure):
                 ("centroid_dropped", C.c_uint64), ("tsdf_kernel_ms", C.c_double), ("tsdf_kernel_timed", C.c_uint64),
                 ("tsdf_batch_bricks", C.c_uint64), ("bp_lookback_retries", C.c_uint64), ("icp_batch_timeouts", C.c_uint64),
                 ("icp_batch_fallback_pairs", C.c_uint64), ("merge_bricks_sent", C.c_uint64), ("merge_bricks_total", C.c_uint64),
-                ("pool_slots_tsdf", C.c_uint64), ("pool_slots_centroid", C.c_uint64), ("pool_refused", C.c_uint64)]
+                ("pool_slots_tsdf", C.c_uint64), ("pool_slots_centroid", C.c_uint64), ("pool_refused", C.c_uint64),
+                ("centroid_record_updates", C.c_uint64)]
 
 
 _lib = None

@@ -96,7 +96,8 @@ __device__ __forceinline__ bool centroid_reduce_runs(CenAdd &k) {
 // Tails of a wave straight to the grid.  The L2's atomic units are bound by REQUESTS (an 8-B add costs a 64-B request) and
 // lanes that add to consecutive words in one instruction share one: the tails are listed in LDS and lanes 4j .. 4j+3 add
 // the four words of tail j's record.  stage: this wave's [64][5] words.
-__device__ __forceinline__ void centroid_commit_runs(const Grid &g, CenAdd k, unsigned long long *__restrict__ grid, unsigned long long (*stage)[5]) {
+__device__ __forceinline__ void centroid_commit_runs(const Grid &g, CenAdd k, unsigned long long *__restrict__ grid, unsigned long long (*stage)[5],
+                                                     unsigned long long *__restrict__ counters = nullptr) {
     const bool tail = centroid_reduce_runs(k);
     const int lane = threadIdx.x & 63;
     const unsigned long long m = __ballot(tail);
@@ -108,6 +109,7 @@ __device__ __forceinline__ void centroid_commit_runs(const Grid &g, CenAdd k, un
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int n4 = 4 * (int)__popcll(m);
+    if (lane == 0 && m && counters) atomicAdd(counters + (size_t)(blockIdx.x & 255) * 8 + 2, (unsigned long long)__popcll(m));     // records updated (counted)
     for (int base = 0; base < n4; base += 64) {                     // (wave-uniform trip count: wave_slots needs every lane)
         const int i = base + lane;
         const bool want = i < n4;
@@ -253,6 +255,7 @@ __global__ __launch_bounds__(256) void centroid_frame_kernel(Cam cam, Grid g, co
     }
     __syncthreads();
     if (VAR == 2) return;                                         // timing ablation: no grid atomics
+    if (threadIdx.x == 0 && s_nused) atomicAdd(counters + (size_t)(blockIdx.x & 255) * 8 + 2, (unsigned long long)s_nused);      // records updated (counted)
     const unsigned n4 = 4u * s_nused;
     for (unsigned base = 0; base < n4; base += 256) {              // (wave-uniform trip count: wave_slots needs every lane)
         const unsigned i = base + threadIdx.x;
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(256) void centroid_direct_kernel(Cam cam, Grid g, c
     CenAdd k = centroid_sample(cam, g, a, p, depth, bgr, xf, yf, s < ns ? us : a.Ws, vs, valid);
     centroid_stats(valid ? 1 : 0, (k.rec != ~0ull) ? 1 : 0, counters);
     __shared__ unsigned long long s_stage[4][64][5];
-    centroid_commit_runs(g, k, grid, s_stage[threadIdx.x >> 6]);
+    centroid_commit_runs(g, k, grid, s_stage[threadIdx.x >> 6], counters);
 }
 
 __global__ __launch_bounds__(256) void centroid_points_kernel(Grid g, const float *__restrict__ xyz, const uint8_t *__restrict__ rgb,
@@ -298,7 +301,7 @@ __global__ __launch_bounds__(256) void centroid_points_kernel(Grid g, const floa
     }
     centroid_stats(valid ? 1 : 0, (k.rec != ~0ull) ? 1 : 0, counters);
     __shared__ unsigned long long s_stage[4][64][5];
-    centroid_commit_runs(g, k, grid, s_stage[threadIdx.x >> 6]);
+    centroid_commit_runs(g, k, grid, s_stage[threadIdx.x >> 6], counters);
 }
 
 // per-block min/max of a point list -> slab[block][6]

@@ -2156,7 +2156,8 @@ int tl3d_get_stats(tl3d_ctx *ctx, tl3d_stats *out) {
     TL3D_HIP(hipMemcpyAsync(hc.data(), ctx->d_cen_counters, hc.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     TL3D_HIP(hipStreamSynchronize(ctx->stream));
     h[0] = h[1] = 0;
-    for (int i = 0; i < 256; ++i) { h[0] += hc[(size_t)i * 8]; h[1] += hc[(size_t)i * 8 + 1]; }
+    unsigned long long cen_updates = 0;
+    for (int i = 0; i < 256; ++i) { h[0] += hc[(size_t)i * 8]; h[1] += hc[(size_t)i * 8 + 1]; cen_updates += hc[(size_t)i * 8 + 2]; }
     for (int i = 0; i < ctx->ktimers_used; ++i) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, ctx->ktimers[i].a, ctx->ktimers[i].b) == hipSuccess) {
@@ -2167,6 +2168,7 @@ int tl3d_get_stats(tl3d_ctx *ctx, tl3d_stats *out) {
     ctx->ktimers_used = 0;
     ctx->stats.centroid_points = h[0];
     ctx->stats.centroid_dropped = h[1];
+    ctx->stats.centroid_record_updates = cen_updates;
     ctx->stats.tsdf_records_read = h[2];
     ctx->stats.tsdf_records_written = h[3];
     ctx->stats.tsdf_bricks_visited = h[4];
