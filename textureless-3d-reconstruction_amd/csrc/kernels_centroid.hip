@@ -119,11 +119,12 @@ __device__ __forceinline__ void centroid_commit_runs(const Grid &g, CenAdd k, un
     }
 }
 
-// LDS table of the per-frame kernel: open addressing, 1024 slots for the at most 1024 samples of a 32 x 32 tile (never more
+// LDS table of the per-frame kernel: open addressing, one slot per sample of a tile (never more
 // distinct keys than slots, so every probe sequence ends); key = record index + 1 (0 = empty), four 64-bit sums per slot.
 // Dense sampling only (stride 1 and 2: 74 / 18 pixels per 5 mm voxel at 1 m); from stride 3 on neighbouring samples
 // rarely share a voxel and the points go straight to the grid (centroid_direct_kernel).
-constexpr int CEN_TW = 32, CEN_TH = 32;      // (tiles of 32 x 8 / 32 x 16 samples: the same time within 2 us)
+constexpr int CEN_TW = 32, CEN_TH = 16;     // 32 frames per launch: 32 x 32 tiles (44 KB of LDS, three workgroups per CU) 9.5 us per frame,
+                                            // 32 x 16 (22 KB, seven) 7.3, 32 x 8 8.0 -- smaller tiles send more partial sums to the grid
 
 // One frame of a BATCH of accumulations (tl3d_accumulate_centroid collects up to TL3D_CEN_MAXBATCH frames of one stride per launch;
 // blockIdx.y picks the frame).  One frame per launch -- 500 workgroups of a 1080p frame at the reference's stride 2 on 256 CUs, 45 KB
