@@ -14,8 +14,8 @@ per-GPU grids are summed with the product's merge inside the timed region.  Rank
 
 roofline: algorithmic bytes per launch are COUNTED by the kernel (8 B x (records read + records written),
 SURVEY.md section 8d) plus the depth bytes of the launch's frames; time is hipEvent time on the launching stream over
-the timed region.  roofline.bound names what really limits the kernel (vector-instruction issue: DESIGN.md 7.5); achieved /
-peak / frac stay priced on the algorithmic HBM bytes, as the measurement contract defines them.  roofline.traffic and the
+the timed region.  roofline.bound / achieved / peak / frac price the algorithmic bytes against HBM, as the measurement contract
+defines them; roofline.limited_by names what really limits the kernel (vector-instruction issue: DESIGN.md 7.5).  roofline.traffic and the
 two sub-objects scattered_reads / vector_alu come from the builder's own rocprofv3 --pmc passes (profiles/pmc_traffic.json,
 keyed by workload): counters need passes of their own, they are NOT counters of this run, and the line says so.
 cpu_baseline: the C oracle (oracle/tl3d_oracle.c, OpenMP) on the host cores, bounded sample.  rows: the other rows of the
@@ -312,9 +312,10 @@ def main():
             except Exception:
                 traffic = None
         paired = m["frames_per_sweep"] > 1.01
-        roof = {"bound": "valu", "bound_note": "the kernel (and the batch: prep chain + update) is limited by vector-instruction issue, "
-                                                 "not by HBM (DESIGN.md 7.5: 4.4 cycles per wave instruction per SIMD measured, tools/ubench_issue.hip); "
-                                                 "achieved / peak / frac are the contract's HBM pricing of the algorithmic bytes",
+        roof = {"bound": "hbm",                               # the roof achieved / peak / frac are priced against (the measurement contract's field) ...
+                "limited_by": "vector-instruction issue, not HBM: the update kernel and the batch as a whole (prep chain + update) run at "
+                              "~85 % of the chip's measured issue rate of 4.4 cycles per wave instruction per SIMD (DESIGN.md 7.5, "
+                              "tools/ubench_issue.hip); see vector_alu",     # ... and what really limits the kernel
                 "kernel": "tsdf_update_pairs_kernel", "achieved": m["achieved"], "peak": 8000.0,
                 "unit": "GB/s", "frac": m["frac"], "traffic": traffic,
                 "traffic_source": ("profiles/pmc_traffic.json: the builder's own rocprofv3 --pmc passes over this workload (separate runs; "

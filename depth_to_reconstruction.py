@@ -117,9 +117,7 @@ def main(argv=None):
         z = np.load(args.anchors)
         anchors = {int(k[3:]): (z[k], z["p2_" + k[3:]]) for k in z.files if k.startswith("p3_")}
     if dist is not None:
-        if args.estimate_scale:
-            raise SystemExit("--estimate-scale chains every view's scale through its predecessor: run it on one GPU")
-        points, colors, poses = pipeline.reconstruct_sharded(dist, anchors=anchors)
+        points, colors, poses = pipeline.reconstruct_sharded(dist, anchors=anchors, estimate_scale=args.estimate_scale)
         rank = dist.get_rank()
         dist.barrier()
         dist.destroy_process_group()

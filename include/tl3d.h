@@ -47,6 +47,7 @@ extern "C" {
                                    pending on every rank and fold into the records at the next read).  OR-ed into the channel mask
                                    of tl3d_grid_touched_bricks / _pack_bricks / _unpack_bricks: pending counts stay pending and mark
                                    no brick, i.e. the free-space observations travel as 4 bytes per brick, not as 4 KB of records */
+#define TL3D_CH_SUB 8u          /* with the merge helpers below: the unit is a 4x4x4 SUB-BRICK (64 contiguous records), ids = brick * 8 + sub-brick */
 
 /* fixed-point formats of the accumulators (exact, order-free sums => bit-identical multi-GPU merge) */
 #define TL3D_TSDF_QSCALE 32767          /* tsdf in [-1,1] -> rint(tsdf * 32767)                  */
@@ -165,6 +166,9 @@ int tl3d_probe_hw_queues(int device, int n_streams, double spin_ms, double *elap
 int tl3d_create(const tl3d_config *cfg, int device, tl3d_ctx **out);
 int tl3d_destroy(tl3d_ctx *ctx);
 int tl3d_sync(tl3d_ctx *ctx);
+/* The hipStream_t the context enqueues on (the caller's, tl3d_config.stream, or the library's own): so that a caller can put ITS device
+ * work -- a collective on the grid memory -- in the same order instead of waiting for the device (tl3d.distributed does). */
+int tl3d_get_stream(tl3d_ctx *ctx, void **stream);
 
 /* a2: frames.  Replaces DepthImageLoader.load_depth's dtype handling (D2R:80-97) and the in-RAM frame
  * lists self.images/self.depths (D2R:434-437).  bgr may be NULL (colour (0,0,0)). */

@@ -122,7 +122,23 @@ def _chain_worker(rank, world, port, out_dir):
     chained, index, log = dd.chain_from_table(table, n)
     mn, mx = dd.allreduce_bounds(np.array([rank, -rank, 5.0]), np.array([rank + 1.0, 0.5, 5.0 + rank]), dist)
     cnt = dd.allreduce_counts([10 + rank, 1], dist)
+    # the Sim(3) chain's hand-over (reconstruct_sharded(estimate_scale=True)): the ranks take turns, each advances the state over its
+    # own views and hands it on; every rank ends with the same table of rows
+    state = dict(prev=0, prev_scale=1.0, avg=1.0, T_guess=np.eye(4))
+    rows = {}
+    for turn in range(world):
+        if turn == rank:
+            for cur in range(max(lo, 1), hi):
+                ok = cur != 3
+                if ok:
+                    state.update(prev=cur, prev_scale=1.0 + 0.01 * cur, avg=1.0 + 0.01 * cur, T_guess=register(cur - 1, cur)["T"])
+                rows[cur] = dict(T=register(state["prev"] if not ok else cur - 1, cur)["T"], against=cur - 1, ok=ok, fitness=0.5, rmse=1e-3, n_corr=99, iters_run=3,
+                                 status=0, scale_raw=1.0 + 0.01 * cur, scale=state["avg"])
+        state = dd.handover_sim3_state(state, turn, dist)
+    sim3 = dd.exchange_sim3_rows(rows, n, dist)
     np.savez(os.path.join(out_dir, f"chain{rank}.npz"), index=np.array(index), rounds=rounds, mn=mn, mx=mx, cnt=np.array(cnt),
+             sim3_prev=state["prev"], sim3_avg=state["avg"], sim3_T=state["T_guess"], sim3_scales=np.array([sim3[c]["scale"] for c in range(1, n)]),
+             sim3_ok=np.array([sim3[c]["ok"] for c in range(1, n)]),
              poses=np.array([np.hstack([r, t.reshape(3, 1)]) for r, t in chained]), dropped=np.array([e["dropped"] for e in log]),
              against=np.array([e["against"] for e in log]))
     dist.barrier()
@@ -149,3 +165,7 @@ def test_sharded_registration_exchange_and_skip_rule(tmp_path):
         tg = poses[k][1].reshape(3) - rg @ t0.reshape(3)
         assert np.linalg.norm(row[:, :3] - rg) + np.linalg.norm(row[:, 3] - tg) < 1e-12
     assert a["mn"].tolist() == [0.0, -1.0, 5.0] and a["mx"].tolist() == [2.0, 0.5, 6.0] and a["cnt"].tolist() == [21, 2]
+    # Sim(3) hand-over: the state after the last rank's turn, and the whole table, on both ranks (compared key by key above)
+    assert int(a["sim3_prev"]) == 6 and abs(float(a["sim3_avg"]) - 1.06) < 1e-15
+    assert a["sim3_ok"].tolist() == [True, True, False, True, True, True]
+    assert np.allclose(a["sim3_scales"], [1.01, 1.02, 1.02, 1.04, 1.05, 1.06], atol=1e-15)

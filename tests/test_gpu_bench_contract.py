@@ -33,12 +33,12 @@ def test_bench_json_contract():
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and d["unit"] == "frames/s"
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and "vector-instruction issue" in r["limited_by"]
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["achieved"] > 0
     assert d["config"]["depth_format"] == "f32"
     # (per-launch averages are truncated to integers in the JSON: equal up to that)
     fps = r["frames_per_sweep"]                         # a launch updates a batch of up to 32 frames (here: the 4 frames of a step)
-    assert 1.0 <= fps <= 32.0 and r["kernel"] == "tsdf_update_kernel"
+    assert 1.0 <= fps <= 32.0 and r["kernel"] == "tsdf_update_pairs_kernel"
     assert abs(r["bytes_per_launch"] - (8 * r["records_per_launch"] + 8 * r["free_space_bricks_counted_per_launch"] + fps * 4 * 270 * 480)) <= 64
     assert abs(r["us_per_frame"] - 1e3 * r["ms_per_launch"] / fps) < 0.05
     if fps > 1.01:
@@ -54,6 +54,11 @@ def test_bench_json_contract():
               "backproject_s1_device_us", "backproject_s1_GBps", "extract_centroid_to_host_ms", "outlier_filter_k20_ms"):
         assert rows[k] > 0, k
     assert rows["extract_points"] > 100 and rows["outlier_filter_kept"] <= rows["extract_points"]
+    # every row is a median of 5 samples, its [min, max] beside it; the centroid channel has a row of its own with COUNTED bytes
+    assert rows["repetitions"] == 5 and all(lo <= rows[k] <= hi for k, (lo, hi) in rows["spread"].items())
+    cen = rows["centroid"]
+    assert cen["record_updates_per_frame"] > 0 and abs(cen["bytes_per_frame"] - (7 * (270 // 2) * (480 // 2) + 64 * cen["record_updates_per_frame"])) <= 64
+    assert abs(cen["frac_of_8TBps"] - cen["achieved_GBps"] / 8000.0) < 1e-3
     # the reference's own CPU path (restated), bounded sample, beside the port
     rr = c["restated_reference_path"]
     assert rr["kind"] == "restated reference" and rr["value"] > 0 and rr["cores"] == 1 and "voxel centroid" in rr["sample"]

@@ -613,7 +613,11 @@ def test_brick_merge_sends_free_space_as_counts_and_records_only_where_there_are
     assert np.array_equal(g, orc.tsdf) and np.array_equal(c, orc.centroid)
     assert info["bricks_total"] == 16 ** 3 and 0 < info["bricks_sent"] < info["bricks_total"] // 2
     assert n_folded > info["bricks_sent"], (n_folded, info)           # a fold-first merge would also have packed the bricks that hold nothing but a count
-    assert info["bytes"] == info["bricks_sent"] * (4096 + 16384) + 5 * info["bricks_total"]
+    # what travelled: the counts (4 B per brick), two sub-brick maps (8 B per brick each), and the occupied SUB-BRICKS of each channel
+    # (512 B / 2 KB each) -- a surface crosses a brick in a few of its eight sub-bricks: far fewer bytes than whole bricks
+    nt, nc = info["sub_bricks_tsdf"], info["sub_bricks_centroid"]
+    assert info["bytes"] == 4 * info["bricks_total"] + 16 * info["bricks_total"] + 512 * nt + 2048 * nc
+    assert 0 < nc < nt <= 8 * info["bricks_sent"] and 2048 * nc < 0.5 * 16384 * info["bricks_sent"]
 
 
 def test_tsdf_on_ragged_image_sizes_is_bit_exact():

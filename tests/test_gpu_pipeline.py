@@ -423,3 +423,59 @@ def test_der_driver_with_local_depth_model_and_per_frame_clouds(tmp_path, capsys
     # a missing checkpoint is an explicit error, never a download
     assert cli.main(["--input", str(inp), "--output", str(out_dir), "--depth-model", str(tmp_path / "nope")]) == 1
     assert "never touches the network" in capsys.readouterr().out
+
+
+@pytest.mark.parametrize("layout", ["dense", "sparse"])
+def test_two_ranks_merge_their_device_grids_to_the_oracle_sum(tmp_path, layout):
+    """The device form of the merge under MORE than one rank (world size 1 makes every sum the identity): two processes on this one
+    GPU (gloo), each fuses half of the frames, distributed.merge_context_grids sums the device grids -- free-space counts as counts,
+    occupied 4x4x4 sub-bricks of each channel packed, all-reduced and unpacked (into pool slots a rank did not have, for a sparse
+    grid) -- and BOTH ranks then hold the C oracle's grids of all the frames, bit for bit."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("tl3d_launch_t", os.path.join(root, "textureless-3d-reconstruction_amd", "launch.py"))
+    launch = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(launch)
+    env = {"TL3D_SHARE_DEVICE": "1", "TL3D_DIST_BACKEND": "gloo"}
+    rc = launch.spawn_ranks(os.path.join(root, "tests", "two_rank_merge_worker.py"), [str(tmp_path), layout], 2, timeout_s=300, extra_env=env)
+    assert rc == 0
+    for r in range(2):
+        ok, grew, refused, nt, nc, nbr, nbytes = (int(x) for x in (tmp_path / f"rank{r}.txt").read_text().split())
+        assert ok == 1 and grew == 1 and refused == 0
+        assert 0 < nc < nt < 8 * nbr and nbytes < 0.5 * nbr * (4096 + 16384)          # occupied sub-bricks, not the volume
+
+
+def test_cli_two_ranks_estimate_scale_equal_one_process(tmp_path):
+    """Relative depth (what Depth-Anything emits, DER:1135/1227) on more than one GPU: `--estimate-scale --gpus 2`.  A view's Sim(3)
+    registration needs its target's scale, so the ranks take turns along the chain (the state -- last kept view, its scale, running
+    scale, motion prior -- is handed from rank to rank); fusion and merge stay parallel.  Same .ply bytes as one process, and the
+    scales are the true ones."""
+    import subprocess
+    import sys
+    from PIL import Image
+    scene, poses, rel, frames = _sequence(n=9, kind="object")
+    rng = np.random.default_rng(5)
+    true_s = np.concatenate([[1.0], rng.uniform(0.8, 1.25, len(frames) - 1)])
+    rgb_dir, depth_dir = tmp_path / "rgb", tmp_path / "depth"
+    rgb_dir.mkdir(); depth_dir.mkdir()
+    for i, (d, c) in enumerate(frames):
+        Image.fromarray(c[..., ::-1]).save(rgb_dir / f"frame_{i:04d}.png")
+        np.save(depth_dir / f"frame_{i:04d}_depth.npy", (d / np.float32(true_s[i])).astype(np.float32))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--rgb-folder", str(rgb_dir), "--depth-folder", str(depth_dir), "--fx", "525", "--fy", "525", "--cx", "320", "--cy", "240",
+              "--no-vis", "--estimate-scale", "--scale-update-weight", "1.0", "--icp-iters", "20", "--no-stream"]
+    env = dict(os.environ, TL3D_DIST_BACKEND="gloo", TL3D_SHARE_DEVICE="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    one, two = tmp_path / "one.ply", tmp_path / "two.ply"
+    r1 = subprocess.run([sys.executable, os.path.join(root, "depth_to_reconstruction.py"), *common, "--output", str(one)], env=env,
+                        capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0 and one.exists(), r1.stdout[-2000:] + r1.stderr[-2000:]
+    r2 = subprocess.run([sys.executable, os.path.join(root, "depth_to_reconstruction.py"), *common, "--output", str(two), "--gpus", "2"], env=env,
+                        capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0 and two.exists(), r2.stdout[-2000:] + r2.stderr[-2000:]
+    assert "the ranks take turns along the chain" in r2.stdout
+    assert one.read_bytes() == two.read_bytes()
+    pts, _ = rn.read_ply(two)
+    ref_p, _ = _reference_cpu_path(frames, rel, ReconstructionConfig(**CAM, voxel_size=0.005, subsample_factor=2))
+    assert len(pts) > 20000 and rn.chamfer_mean(pts, ref_p) < 1e-3

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("TL3D_LIB") or os.path.join(_HERE, "libtl3d.so")     #
 
 ABI_VERSION = 5
 OK, E_INVALID, E_HIP, E_NOMEM, E_CAPACITY, E_STATE, E_NODEVICE = 0, -1, -2, -3, -4, -5, -6
-CH_TSDF, CH_CENTROID, CH_FREE = 1, 2, 4
+CH_TSDF, CH_CENTROID, CH_FREE, CH_SUB = 1, 2, 4, 8
 DEPTH_F32_M, DEPTH_U16_MM = 0, 1
 F_SCALE_F64, F_NO_POSE = 1, 2
 EXTRACT_CENTROID, EXTRACT_TSDF = 0, 1
@@ -21,7 +21,7 @@ TSDF_MAX_WEIGHT = 65536
 
 # every symbol include/tl3d.h declares (checked by tests/test_cabi_symbols.py against the header text)
 SYMBOLS = [
-    "tl3d_last_error", "tl3d_version", "tl3d_device_count", "tl3d_runtime_info", "tl3d_probe_hw_queues", "tl3d_grid_max_weight", "tl3d_create", "tl3d_destroy", "tl3d_sync",
+    "tl3d_last_error", "tl3d_version", "tl3d_device_count", "tl3d_runtime_info", "tl3d_probe_hw_queues", "tl3d_grid_max_weight", "tl3d_create", "tl3d_destroy", "tl3d_sync", "tl3d_get_stream",
     "tl3d_upload_frame", "tl3d_download_depth", "tl3d_pinned_alloc", "tl3d_pinned_free", "tl3d_upload_frame_async",
     "tl3d_slot_wait", "tl3d_attach_grid", "tl3d_backproject", "tl3d_backproject_device", "tl3d_frame_bounds", "tl3d_frames_bounds", "tl3d_count_bricks", "tl3d_accumulate_centroid",
     "tl3d_accumulate_points", "tl3d_points_bounds", "tl3d_integrate", "tl3d_build_normals",
@@ -162,6 +162,7 @@ def load():
         "tl3d_create": [C.POINTER(Config), i32, C.POINTER(vp)],
         "tl3d_destroy": [vp],
         "tl3d_sync": [vp],
+        "tl3d_get_stream": [vp, C.POINTER(vp)],
         "tl3d_upload_frame": [vp, i32, vp, i32, vp],
         "tl3d_download_depth": [vp, i32, vp],
         "tl3d_pinned_alloc": [C.c_size_t, C.POINTER(vp)],

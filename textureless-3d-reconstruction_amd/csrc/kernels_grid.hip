@@ -74,19 +74,22 @@ int launch_max_weight_dense(hipStream_t s, const int2 *grid, size_t nvox, int *d
 // map[b] |= 1 when brick b has a voxel with a TSDF weight or a centroid count.  One wave per brick; TSDF: 16 B per lane x 4,
 // centroid: the record's second word (sz | n << 32) of 8 records per lane.  (Pending free-space counts are not records: they
 // travel as the small per-brick counter array, tl3d_grid_device_ptr(TL3D_CH_FREE).)
+// SUB: the map has EIGHT bytes per brick, one per 4x4x4 sub-brick (64 contiguous records: tl3d_internal.h in_brick_index).
+template <bool SUB>
 __global__ __launch_bounds__(256) void touched_bricks_kernel(Grid g, const int4 *__restrict__ tsdf2, const unsigned long long *__restrict__ cen,
                                                              unsigned nbricks, unsigned char *__restrict__ map) {
     const int lane = threadIdx.x & 63;
     for (unsigned b = blockIdx.x * 4u + (threadIdx.x >> 6); b < nbricks; b += gridDim.x * 4u) {
-        bool any = false;
+        unsigned subs = 0u;                                           // (wave-uniform) sub-bricks of b that hold anything
         if (tsdf2) {
             const unsigned slot = (unsigned)__builtin_amdgcn_readfirstlane((int)brick_slot(g.tsdf_tab, b));
             if (slot < SLOT_FULL) {
                 const int4 *r = tsdf2 + ((size_t)slot << 8);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < 4; ++k) {                          // 16 B = records 2 (64 k + lane), + 1: sub-brick 2 k (lanes 0-31), 2 k + 1 (32-63)
                     const int4 v = r[k * 64 + lane];
-                    any = any || v.y != 0 || v.w != 0;
+                    const unsigned long long m = __ballot(v.y != 0 || v.w != 0);
+                    subs |= ((m & 0xffffffffull) ? 1u : 0u) << (2 * k) | ((m >> 32) ? 1u : 0u) << (2 * k + 1);
                 }
             }
         }
@@ -95,10 +98,14 @@ __global__ __launch_bounds__(256) void touched_bricks_kernel(Grid g, const int4 
             if (slot < SLOT_FULL) {
                 const unsigned long long *r = cen + ((size_t)slot << 11);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) any = any || (r[(size_t)(k * 64 + lane) * 4 + 1] >> 32) != 0ull;
+                for (int k = 0; k < 8; ++k) subs |= (__ballot((r[(size_t)(k * 64 + lane) * 4 + 1] >> 32) != 0ull) ? 1u : 0u) << k;
             }
         }
-        if (__ballot(any) != 0ull && lane == 0) map[b] = 1;
+        if (SUB) {
+            if (lane < 8 && ((subs >> lane) & 1u)) map[(size_t)b * 8 + lane] = 1;
+        } else if (subs && lane == 0) {
+            map[b] = 1;
+        }
     }
 }
 
@@ -107,15 +114,20 @@ __global__ __launch_bounds__(256) void touched_bricks_kernel(Grid g, const int4 
 // add_free is set: the image a reader of a dense grid would see).  MODE 1: the brick's records = row.  MODE 2: records += row
 // (32-bit lanes for the TSDF channel, 64-bit for the centroid channel).  MODE 1 / 2 give a brick without records a slot when its
 // row holds anything.
-template <int MODE, bool IS_TSDF>
+// SUB: a row is ONE 4x4x4 SUB-BRICK (64 records), idx[i] = brick * 8 + sub-brick: what the multi-GPU merge sends, so that a brick
+// whose surface crosses two of its sub-bricks does not travel whole (the centroid channel: 2 KB instead of 16 KB).
+template <int MODE, bool IS_TSDF, bool SUB = false>
 __global__ __launch_bounds__(256) void brick_rows_kernel(Grid g, int4 *__restrict__ pool, const unsigned *__restrict__ idx, long long n,
                                                          int4 *__restrict__ rows, int add_free) {
-    constexpr unsigned words16 = IS_TSDF ? 256u : 1024u;
+    constexpr unsigned words16_brick = IS_TSDF ? 256u : 1024u;
+    constexpr unsigned words16 = SUB ? words16_brick / 8u : words16_brick;
     __shared__ unsigned s_slot;
     __shared__ int s_any;
     unsigned *table = IS_TSDF ? g.tsdf_tab : g.cen_tab;
     for (long long i = blockIdx.x; i < n; i += gridDim.x) {
-        const unsigned brick = idx ? idx[i] : (unsigned)i;
+        const unsigned id = idx ? idx[i] : (unsigned)i;
+        const unsigned brick = SUB ? id >> 3 : id;
+        const size_t in_brick = SUB ? (size_t)(id & 7u) * words16 : 0;
         int4 *q = rows + (size_t)i * words16;
         if (MODE == 0) {
             const unsigned slot = brick_slot(table, brick);
@@ -123,7 +135,7 @@ __global__ __launch_bounds__(256) void brick_rows_kernel(Grid g, int4 *__restric
             const int dq = (int)(c * 32767u), dw = (int)c;
             for (unsigned w = threadIdx.x; w < words16; w += 256) {
                 int4 v = make_int4(0, 0, 0, 0);
-                if (slot < SLOT_FULL) v = pool[((size_t)slot * words16) + w];
+                if (slot < SLOT_FULL) v = pool[((size_t)slot * words16_brick) + in_brick + w];
                 if (IS_TSDF) { v.x += dq; v.y += dw; v.z += dq; v.w += dw; }
                 q[w] = v;
             }
@@ -141,7 +153,7 @@ __global__ __launch_bounds__(256) void brick_rows_kernel(Grid g, int4 *__restric
             __syncthreads();
             const unsigned slot = s_slot;
             if (slot < SLOT_FULL) {
-                int4 *r = pool + (size_t)slot * words16;
+                int4 *r = pool + (size_t)slot * words16_brick + in_brick;
                 for (unsigned w = threadIdx.x; w < words16; w += 256) {
                     if (MODE == 1) {
                         r[w] = q[w];
@@ -163,20 +175,26 @@ __global__ __launch_bounds__(256) void brick_rows_kernel(Grid g, int4 *__restric
     }
 }
 
-int launch_touched_bricks(hipStream_t s, const Grid &g, const int2 *tsdf, const unsigned long long *cen, unsigned nbricks, unsigned char *map) {
+int launch_touched_bricks(hipStream_t s, const Grid &g, const int2 *tsdf, const unsigned long long *cen, unsigned nbricks, unsigned char *map, bool sub) {
     const unsigned nb = (nbricks + 3u) / 4u < 4096u ? (nbricks + 3u) / 4u : 4096u;
-    hipLaunchKernelGGL(touched_bricks_kernel, dim3(nb ? nb : 1), dim3(256), 0, s, g, reinterpret_cast<const int4 *>(tsdf), cen, nbricks, map);
+    if (sub) hipLaunchKernelGGL(touched_bricks_kernel<true>, dim3(nb ? nb : 1), dim3(256), 0, s, g, reinterpret_cast<const int4 *>(tsdf), cen, nbricks, map);
+    else hipLaunchKernelGGL(touched_bricks_kernel<false>, dim3(nb ? nb : 1), dim3(256), 0, s, g, reinterpret_cast<const int4 *>(tsdf), cen, nbricks, map);
     TL3D_HIP(hipGetLastError());
     return TL3D_OK;
 }
 
 // mode 0 rows <- bricks, 1 bricks <- rows, 2 bricks += rows; idx may be null (row i = brick i)
-int launch_brick_rows(hipStream_t s, const Grid &g, int mode, bool is_tsdf, void *pool, const unsigned *idx, long long n, void *rows, bool add_free) {
+int launch_brick_rows(hipStream_t s, const Grid &g, int mode, bool is_tsdf, void *pool, const unsigned *idx, long long n, void *rows, bool add_free, bool sub) {
     if (n <= 0) return TL3D_OK;
-    const unsigned nb = (unsigned)(n < 8192 ? n : 8192);
-#define TL3D_ROWS(M_, T_) hipLaunchKernelGGL((brick_rows_kernel<M_, T_>), dim3(nb), dim3(256), 0, s, g, static_cast<int4 *>(pool), idx, n, static_cast<int4 *>(rows), add_free ? 1 : 0)
-    if (is_tsdf) { if (mode == 0) TL3D_ROWS(0, true); else if (mode == 1) TL3D_ROWS(1, true); else TL3D_ROWS(2, true); }
-    else { if (mode == 0) TL3D_ROWS(0, false); else if (mode == 1) TL3D_ROWS(1, false); else TL3D_ROWS(2, false); }
+    const unsigned nb = (unsigned)(n < 16384 ? n : 16384);
+#define TL3D_ROWS(M_, T_, S_) hipLaunchKernelGGL((brick_rows_kernel<M_, T_, S_>), dim3(nb), dim3(256), 0, s, g, static_cast<int4 *>(pool), idx, n, static_cast<int4 *>(rows), add_free ? 1 : 0)
+    if (sub) {
+        if (is_tsdf) { if (mode == 0) TL3D_ROWS(0, true, true); else if (mode == 1) TL3D_ROWS(1, true, true); else TL3D_ROWS(2, true, true); }
+        else { if (mode == 0) TL3D_ROWS(0, false, true); else if (mode == 1) TL3D_ROWS(1, false, true); else TL3D_ROWS(2, false, true); }
+    } else {
+        if (is_tsdf) { if (mode == 0) TL3D_ROWS(0, true, false); else if (mode == 1) TL3D_ROWS(1, true, false); else TL3D_ROWS(2, true, false); }
+        else { if (mode == 0) TL3D_ROWS(0, false, false); else if (mode == 1) TL3D_ROWS(1, false, false); else TL3D_ROWS(2, false, false); }
+    }
 #undef TL3D_ROWS
     TL3D_HIP(hipGetLastError());
     return TL3D_OK;

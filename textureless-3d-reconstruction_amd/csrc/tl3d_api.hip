@@ -584,6 +584,12 @@ int tl3d_sync(tl3d_ctx *ctx) {
 }
 
 // ------------------------------------------------------------------------------------------- frames
+int tl3d_get_stream(tl3d_ctx *ctx, void **stream) {
+    REQUIRE(ctx && stream, TL3D_E_INVALID, "null argument");
+    *stream = (void *)ctx->stream;
+    return TL3D_OK;
+}
+
 int tl3d_upload_frame(tl3d_ctx *ctx, int slot, const void *depth_hd, int depth_kind, const uint8_t *bgr_hd) {
     return upload_impl(ctx, slot, depth_hd, depth_kind, bgr_hd, true);
 }
@@ -1846,28 +1852,31 @@ int tl3d_grid_add(tl3d_ctx *ctx, uint32_t channel, const void *other, size_t byt
 int tl3d_grid_touched_bricks(tl3d_ctx *ctx, uint32_t channels, uint8_t *map_dev, int64_t n_bricks) {
     REQUIRE(ctx && map_dev, TL3D_E_INVALID, "null argument");
     const bool counts_apart = (channels & TL3D_CH_FREE) != 0;      // the free-space counts travel on their own (tl3d.h)
-    channels &= ~TL3D_CH_FREE;
+    const bool sub = (channels & TL3D_CH_SUB) != 0;                 // one byte per 4x4x4 sub-brick
+    channels &= ~(TL3D_CH_FREE | TL3D_CH_SUB);
     if (channels == 0) channels = (ctx->tsdf ? TL3D_CH_TSDF : 0u) | (ctx->centroid ? TL3D_CH_CENTROID : 0u);
     REQUIRE((channels & ~(TL3D_CH_TSDF | TL3D_CH_CENTROID)) == 0, TL3D_E_INVALID, "bad channel mask 0x%x", channels);
     if (channels & TL3D_CH_TSDF) REQUIRE(ctx->tsdf != nullptr, TL3D_E_STATE, "TSDF channel not enabled");
     if (channels & TL3D_CH_CENTROID) REQUIRE(ctx->centroid != nullptr, TL3D_E_STATE, "centroid channel not enabled");
-    REQUIRE(n_bricks == (int64_t)(ctx->nvox >> 9), TL3D_E_INVALID, "the grid has %zu bricks, the map %lld", ctx->nvox >> 9, (long long)n_bricks);
+    REQUIRE(n_bricks == (int64_t)(ctx->nvox >> 9) * (sub ? 8 : 1), TL3D_E_INVALID, "the grid has %zu %sbricks, the map %lld", (ctx->nvox >> 9) * (sub ? 8 : 1), sub ? "sub-" : "",
+            (long long)n_bricks);
     REQUIRE(is_device_ptr(map_dev), TL3D_E_INVALID, "the brick map must be device memory");
     if (counts_apart) FLUSH_UPDATES(ctx);
     else FLUSH_AND_FOLD(ctx);
     TL3D_HIP(hipSetDevice(ctx->device));
     return launch_touched_bricks(ctx->stream, ctx->grid, (channels & TL3D_CH_TSDF) ? ctx->tsdf : nullptr, (channels & TL3D_CH_CENTROID) ? ctx->centroid : nullptr,
-                                 (unsigned)n_bricks, map_dev);
+                                 (unsigned)(ctx->nvox >> 9), map_dev, sub);
 }
 
 static int brick_rows(tl3d_ctx *ctx, uint32_t channel, const uint32_t *bricks_dev, int64_t n, void *packed_dev, bool pack) {
     void *p;
     size_t nb;
     const bool counts_apart = (channel & TL3D_CH_FREE) != 0;       // records only: pending free-space counts stay pending
-    channel &= ~TL3D_CH_FREE;
+    const bool sub = (channel & TL3D_CH_SUB) != 0;                  // rows are 4x4x4 sub-bricks, ids = brick * 8 + sub-brick
+    channel &= ~(TL3D_CH_FREE | TL3D_CH_SUB);
     int rc = grid_sel(ctx, channel, &p, &nb);
     if (rc) return rc;
-    REQUIRE(n >= 0 && n <= (int64_t)(ctx->nvox >> 9), TL3D_E_INVALID, "brick count %lld out of range", (long long)n);
+    REQUIRE(n >= 0 && n <= (int64_t)(ctx->nvox >> 9) * (sub ? 8 : 1), TL3D_E_INVALID, "brick count %lld out of range", (long long)n);
     if (n == 0) return TL3D_OK;
     REQUIRE(bricks_dev && packed_dev && is_device_ptr(bricks_dev) && is_device_ptr(packed_dev), TL3D_E_INVALID, "brick list and block must be device memory");
     if (counts_apart) FLUSH_UPDATES(ctx);
@@ -1875,7 +1884,7 @@ static int brick_rows(tl3d_ctx *ctx, uint32_t channel, const uint32_t *bricks_de
     ctx->grid_epoch++;
     TL3D_HIP(hipSetDevice(ctx->device));
     if (!pack && channel == TL3D_CH_TSDF) ctx->tsdf_w_unknown = true;      // the records now hold what the caller summed
-    return launch_brick_rows(ctx->stream, ctx->grid, pack ? 0 : 1, channel == TL3D_CH_TSDF, p, bricks_dev, n, packed_dev, false);
+    return launch_brick_rows(ctx->stream, ctx->grid, pack ? 0 : 1, channel == TL3D_CH_TSDF, p, bricks_dev, n, packed_dev, false, sub);
 }
 
 int tl3d_grid_pack_bricks(tl3d_ctx *ctx, uint32_t channel, const uint32_t *bricks_dev, int64_t n, void *packed_dev) {

@@ -412,8 +412,8 @@ int launch_extract_write(hipStream_t s, const Grid &g, int mode, int min_count, 
 // grids
 int launch_max_weight(hipStream_t s, const Grid &g, const int2 *pool, int *d_out);
 int launch_max_weight_dense(hipStream_t s, const int2 *grid, size_t nvox, int *d_out);
-int launch_touched_bricks(hipStream_t s, const Grid &g, const int2 *tsdf, const unsigned long long *cen, unsigned nbricks, unsigned char *map);
-int launch_brick_rows(hipStream_t s, const Grid &g, int mode, bool is_tsdf, void *pool, const unsigned *idx, long long n, void *rows, bool add_free);
+int launch_touched_bricks(hipStream_t s, const Grid &g, const int2 *tsdf, const unsigned long long *cen, unsigned nbricks, unsigned char *map, bool sub = false);
+int launch_brick_rows(hipStream_t s, const Grid &g, int mode, bool is_tsdf, void *pool, const unsigned *idx, long long n, void *rows, bool add_free, bool sub = false);
 int launch_iota(hipStream_t s, unsigned *t, unsigned n);
 int probe_hw_queues(int n_streams, double spin_ms, double *elapsed_ms);
 int launch_add_i32(hipStream_t s, int *dst, const int *src, size_t n);

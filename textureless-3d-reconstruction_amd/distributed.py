@@ -112,80 +112,90 @@ def _headroom_check(ctx, dist):
 def allreduce_context_grids(ctx, dist, sparse: bool = True) -> dict:
     """Device form of the merge: all-reduce on the library's own grid memory.
 
-    sparse (default): only the bricks ANY rank holds something in travel -- one byte per brick MAX-all-reduced gives every rank
-    the same brick set, their records are packed into one block (tl3d_grid_pack_bricks), SUM-all-reduced and unpacked.  A
-    frame-sharded run of a few dozen frames per rank touches a few per cent of a 1024^3 grid (BASELINE config 5: 32 frames per
-    rank at 8 GPUs), so the full-grid all-reduce (8.6 GB int32 + 34 GB of centroid words) would dwarf the fusion itself.  Falls
-    back to the full-grid all-reduce (zero-copy torch views) when more than half of the bricks are touched.
-    Works with any backend: RCCL reduces the device tensors in place; gloo takes them through the host.
-    Returns what went over the wire: bricks_sent, bricks_total, bytes."""
+    sparse (default): what travels is what any rank OBSERVED, at the granularity of a 4x4x4 sub-brick (64 contiguous records) and
+    per channel: one byte per sub-brick MAX-all-reduced gives every rank the same list, the listed sub-bricks are packed into one
+    block (tl3d_grid_pack_bricks with TL3D_CH_SUB), SUM-all-reduced and unpacked.  A frame-sharded run of a few dozen frames per
+    rank touches a few per cent of a 1024^3 grid (BASELINE config 5: 32 frames per rank at 8 GPUs), and of a touched brick the
+    centroid channel fills one or two sub-bricks (a surface crosses it): whole 16-KB bricks were 6.3 of the 7.9 GB a rank sent
+    in round 3.  A channel of which more than half is touched is all-reduced whole (zero-copy view; a sparse grid: every
+    sub-brick it holds).  Works with any backend: RCCL reduces the device tensors in place; gloo takes them through the host.
+
+    Ordering: every torch operation here runs on the CONTEXT's stream (torch.cuda.ExternalStream over tl3d_get_stream), so the
+    library's kernels and torch's stay in program order without a device-wide wait between them (round 3 bracketed each step with
+    torch.cuda.synchronize()); a collective is ordered against that stream by torch.distributed as against any current stream.
+    Returns what went over the wire: sub_bricks_tsdf / sub_bricks_centroid (eighths of a brick), bricks_sent (the larger of the two,
+    in bricks), bricks_total, bytes (records + maps + counts)."""
     import torch
     dev = torch.device("cuda", ctx.device)
     on_device = dist.get_backend() == "nccl"
-    # (device-wide waits below are torch's: tl3d_sync would fold the pending free-space counts into the records, and from the brick
-    # map to the unpack nothing may do that)
-    wait = torch.cuda.synchronize
     ch = ctx.grid.channels
-    if ch & abi.CH_TSDF:
-        _headroom_check(ctx, dist)
     nbr = ctx.n_bricks
-    row_bytes = (4096 if ch & abi.CH_TSDF else 0) + (16384 if ch & abi.CH_CENTROID else 0)
+    stream = torch.cuda.ExternalStream(ctx.stream_ptr(), device=dev)
 
     def reduce_(t, op=None):
         kw = {} if op is None else {"op": op}
         if on_device:
             dist.all_reduce(t, **kw)
             return t
-        h = t.cpu()
+        h = t.cpu()                                           # (a blocking copy on the current = the context's stream)
         dist.all_reduce(h, **kw)
         t.copy_(h)
         return t
 
-    # The free-space observations of a frame-sharded run cover most of the volume between the cameras and the surfaces, but they
-    # are ONE count per brick (tl3d.h: TL3D_CH_FREE), pending until something reads the channel.  They travel as what they are --
-    # 4 bytes per brick, summed -- and only bricks with RECORDS (a surface came within the truncation band, or a point fell in)
-    # travel as records.  Folded first (as until round 3), every brick a camera ever looked through would go as 4 KB of records.
-    idx = None
-    free_apart = bool(ch & abi.CH_TSDF)
-    fl = abi.CH_FREE if free_apart else 0
-    if sparse:
-        m = torch.zeros(nbr, dtype=torch.uint8, device=dev)
-        wait()                                               # torch fills m on ITS stream; the library marks bricks on the context's
-        ctx.touched_bricks(m, ch | fl)
-        wait()
-        reduce_(m, dist.ReduceOp.MAX)
-        idx = torch.nonzero(m, as_tuple=False).flatten().to(torch.int32)
-        wait()                                               # (the conversion, too, runs on torch's stream)
-        if 2 * idx.numel() >= nbr:
-            idx = None
-    if idx is None:
-        for channel in (abi.CH_TSDF, abi.CH_CENTROID):
-            if ch & channel:
-                t = ctx.grid_tensor(channel)                 # (TSDF: folds the pending counts into the records first, on the context's stream)
-                wait()
-                reduce_(t)
-        torch.cuda.synchronize()
-        return dict(bricks_sent=nbr, bricks_total=nbr, bytes=nbr * row_bytes)
-    n = int(idx.numel())
-    if free_apart:
-        cnt = ctx.grid_tensor(abi.CH_FREE)
-        wait()
-        reduce_(cnt)                                         # every rank now holds the scan's counts, still pending
-        wait()
-    if n:
-        for channel, words, dt in ((abi.CH_TSDF, 1024, torch.int32), (abi.CH_CENTROID, 2048, torch.int64)):
+    with torch.cuda.stream(stream):
+        if ch & abi.CH_TSDF:
+            _headroom_check(ctx, dist)
+        # The free-space observations of a frame-sharded run cover most of the volume between the cameras and the surfaces, but they
+        # are ONE count per brick (tl3d.h: TL3D_CH_FREE), pending until something reads the channel.  They travel as what they are --
+        # 4 bytes per brick, summed -- and only sub-bricks with RECORDS (a surface came within the truncation band, or a point fell in)
+        # travel as records.
+        free_apart = bool(ch & abi.CH_TSDF)
+        fl = abi.CH_FREE if free_apart else 0
+        sent = {}
+        nbytes = 0
+        if free_apart:
+            cnt = ctx.grid_tensor(abi.CH_FREE)
+            reduce_(cnt)                                      # every rank now holds the scan's counts, still pending
+            nbytes += 4 * nbr
+        for channel, row_words, dt in ((abi.CH_TSDF, 128, torch.int32), (abi.CH_CENTROID, 256, torch.int64)):
             if not ch & channel:
                 continue
-            block = torch.empty((n, words), dtype=dt, device=dev)
-            ctx.pack_bricks(channel | (fl if channel == abi.CH_TSDF else 0), idx, block)
-            wait()
-            reduce_(block)
-            wait()
-            ctx.unpack_bricks(channel | (fl if channel == abi.CH_TSDF else 0), idx, block)
-            wait()
-            del block
-    torch.cuda.synchronize()
-    return dict(bricks_sent=n, bricks_total=nbr, bytes=n * row_bytes + nbr + (4 * nbr if free_apart else 0))
+            chf = channel | (fl if channel == abi.CH_TSDF else 0)
+            row_bytes = row_words * (4 if dt == torch.int32 else 8)
+            idx = None
+            if sparse:
+                m = torch.zeros(8 * nbr, dtype=torch.uint8, device=dev)
+                ctx.touched_bricks(m, chf | abi.CH_SUB)
+                reduce_(m, dist.ReduceOp.MAX)
+                nbytes += 8 * nbr
+                idx = torch.nonzero(m, as_tuple=False).flatten().to(torch.int32)
+                del m
+                if 2 * idx.numel() >= 8 * nbr and not ctx.grid.sparse:
+                    idx = None
+            if idx is None:
+                if ctx.grid.sparse:                           # no dense layout to view: every sub-brick of the channel
+                    idx = torch.arange(8 * nbr, dtype=torch.int32, device=dev)
+                else:
+                    t = ctx.grid_tensor(channel)              # (TSDF: folds the pending counts into the records first, on the context's stream)
+                    reduce_(t)
+                    sent[channel] = 8 * nbr
+                    nbytes += 8 * nbr * row_bytes
+                    continue
+            n = int(idx.numel())
+            # blocks of at most 2 GiB: a 1024^3 scan's union can be several GB per channel, and the block is a copy
+            step = max(1, (2 << 30) // row_bytes)
+            for i0 in range(0, n, step):
+                part = idx[i0:i0 + step]
+                block = torch.empty((int(part.numel()), row_words), dtype=dt, device=dev)
+                ctx.pack_bricks(chf | abi.CH_SUB, part, block)
+                reduce_(block)
+                ctx.unpack_bricks(chf | abi.CH_SUB, part, block)
+                del block
+            sent[channel] = n
+            nbytes += n * row_bytes
+        stream.synchronize()                                  # the caller's own torch work may sit on another stream
+    return dict(bricks_sent=(max(sent.values(), default=0) + 7) // 8, bricks_total=nbr, bytes=int(nbytes),
+                sub_bricks_tsdf=int(sent.get(abi.CH_TSDF, 0)), sub_bricks_centroid=int(sent.get(abi.CH_CENTROID, 0)))
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -232,6 +242,40 @@ def exchange_registrations(local: dict, n_frames: int, dist=None, into: dict = N
             table[cur] = dict(T=buf[cur, :16].reshape(4, 4).copy(), against=int(buf[cur, 16]), ok=bool(buf[cur, 17] > 0.5), fitness=float(buf[cur, 18]),
                               rmse=float(buf[cur, 19]), n_corr=int(buf[cur, 20]), iters_run=int(buf[cur, 21]), status=int(buf[cur, 22]))
     return got if into is not None else table
+
+
+def handover_sim3_state(state: dict, src: int, dist=None) -> dict:
+    """The state of the Sim(3) registration chain (pipeline._sim3_chain: last kept view and its scale, running scale, motion prior)
+    as rank `src` leaves it, on every rank: the next rank continues the chain from it.  19 doubles."""
+    import torch
+    if _world(dist) == 1:
+        return state
+    buf = torch.zeros(19, dtype=torch.float64)
+    if dist.get_rank() == src:
+        buf[0], buf[1], buf[2] = float(state["prev"]), float(state["prev_scale"]), float(state["avg"])
+        buf[3:19] = torch.from_numpy(np.ascontiguousarray(np.asarray(state["T_guess"], np.float64).reshape(16)))
+    buf = _reduce(buf, dist).numpy()                       # (zeros from everybody else: a sum is a broadcast)
+    return dict(prev=int(round(buf[0])), prev_scale=float(buf[1]), avg=float(buf[2]), T_guess=buf[3:19].reshape(4, 4).copy())
+
+
+def exchange_sim3_rows(local: dict, n_frames: int, dist=None) -> dict:
+    """The rows of pipeline._sim3_chain every rank produced for the views it owns -> the whole table on every rank."""
+    import torch
+    cols = 27          # 16 T | against | ok | fitness | rmse | n_corr | iters_run | status | scale_raw | scale | present
+    buf = torch.zeros((n_frames, cols), dtype=torch.float64)
+    for cur, r in local.items():
+        buf[cur, :16] = torch.from_numpy(np.ascontiguousarray(np.asarray(r["T"], np.float64).reshape(16)))
+        buf[cur, 16:27] = torch.tensor([float(r["against"]), float(r["ok"]), float(r["fitness"]), float(r["rmse"]), float(r["n_corr"]),
+                                        float(r["iters_run"]), float(r["status"]), float(r["scale_raw"]), float(r["scale"]), 0.0, 1.0],
+                                       dtype=torch.float64)
+    buf = _reduce(buf, dist).numpy()
+    table = {}
+    for cur in range(n_frames):
+        if buf[cur, 26] > 0.5:
+            table[cur] = dict(T=buf[cur, :16].reshape(4, 4).copy(), against=int(buf[cur, 16]), ok=bool(buf[cur, 17] > 0.5), fitness=float(buf[cur, 18]),
+                              rmse=float(buf[cur, 19]), n_corr=int(buf[cur, 20]), iters_run=int(buf[cur, 21]), status=int(buf[cur, 22]),
+                              scale_raw=float(buf[cur, 23]), scale=float(buf[cur, 24]))
+    return table
 
 
 def resolve_chain(table: dict, n_frames: int):

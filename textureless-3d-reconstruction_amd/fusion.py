@@ -138,6 +138,12 @@ class FusionContext:
     def sync(self):
         abi.check(self._lib.tl3d_sync(self._h))
 
+    def stream_ptr(self) -> int:
+        """The hipStream_t the context enqueues on, as an integer (torch.cuda.ExternalStream takes it)."""
+        p = C.c_void_p()
+        abi.check(self._lib.tl3d_get_stream(self._h, C.byref(p)))
+        return int(p.value or 0)
+
     # ---- frames ----------------------------------------------------------------------------
     def upload(self, slot: int, depth, bgr=None):
         """depth: float32 [H,W] metres / relative units, or uint16 [H,W] millimetres (16-bit PNG, D2R:85-90)."""
@@ -447,8 +453,9 @@ class FusionContext:
     def touched_bricks(self, map_dev, channels: int = 0):
         """map_dev[b] |= 1 (uint8, one per brick, device memory, zeroed by the caller) for every brick that holds anything.
         With abi.CH_FREE in `channels` (and in the channel of pack_bricks / unpack_bricks) pending free-space counts stay pending
-        and mark nothing: they travel on their own, as grid_tensor(abi.CH_FREE)."""
-        abi.check(self._lib.tl3d_grid_touched_bricks(self._h, int(channels), abi.ptr(map_dev), int(self.n_bricks)))
+        and mark nothing: they travel on their own, as grid_tensor(abi.CH_FREE).  With abi.CH_SUB the unit is a 4x4x4 sub-brick:
+        the map has 8 bytes per brick, the lists of pack_bricks / unpack_bricks hold brick * 8 + sub-brick, rows are 64 records."""
+        abi.check(self._lib.tl3d_grid_touched_bricks(self._h, int(channels), abi.ptr(map_dev), int(map_dev.shape[0])))
 
     def pack_bricks(self, channel: int, bricks_dev, packed_dev):
         abi.check(self._lib.tl3d_grid_pack_bricks(self._h, int(channel), abi.ptr(bricks_dev), int(bricks_dev.shape[0]), abi.ptr(packed_dev)))

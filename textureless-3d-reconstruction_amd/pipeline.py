@@ -298,28 +298,23 @@ class DepthToReconstructionPipeline:
             i = batch[-1] + 1
         return poses, index
 
-    def _register_with_scale(self, ctx: FusionContext, scale0: float, init_poses=None, weight: float = 0.3):
-        """Registration of RELATIVE depth maps (row f3): every view's metric scale is the 7th unknown of its registration
-        against the previous kept view (Sim(3) point-to-plane ICP, tl3d_icp_params.estimate_scale), which replaces the
-        reference's median of Z_triangulated / depth over SIFT points (D2R:297-326, DER:659-697).  View 0 fixes the gauge
-        (scale0 = config.depth_scale, or the anchors' estimate); the running scale follows the reference's rule
-        avg = (1 - w) avg + w scale_i (D2R:650, w = 0.3; config.scale_update_weight = 1 trusts every view's own estimate).
-        The source of a run is the NEW view (unknown scale), the target the previous one (scale known, normals built with
-        it), so the run returns cur -> prev; its inverse is the (R_rel, t_rel) the reference chains (D2R:618-620).
-        Sequential by nature: a view's target needs that view's scale."""
+    def _sim3_levels(self):
         cfg = self.config
-        n = len(self.depths)
         wide = [(15, max(2, int(cfg.icp_stride) * 2), 1.0)] + [tuple(l) for l in cfg.icp_coarse] + [(cfg.icp_iters, cfg.icp_stride, cfg.icp_max_dist)]
         common = dict(damping=cfg.icp_damping, eig_rel=cfg.icp_eig_rel, eps=cfg.icp_eps, estimate_scale=True)
-        level_list = [dict(iters=int(lv[0]), stride=int(lv[1]), max_dist=float(lv[2]), **common) for lv in wide][-abi.ICP_MAX_LEVELS:]
-        poses = [(np.eye(3), np.zeros((3, 1)))]
-        index, scales = [0], [float(scale0)] * n
-        tr = ScaleTracker(scale0)
-        tr.history = [tr.avg]
-        prev = 0
-        ctx.build_normals(0, scale=scale0)
-        T_guess = np.eye(4)                                  # cur -> prev of the last pair (constant velocity)
-        for cur in range(1, n):
+        return [dict(iters=int(lv[0]), stride=int(lv[1]), max_dist=float(lv[2]), **common) for lv in wide][-abi.ICP_MAX_LEVELS:]
+
+    def _sim3_chain(self, ctx: FusionContext, frames, slot_of, state, init_poses=None, weight: float = 0.3):
+        """One stretch of the Sim(3) registration chain: the views `frames` (ascending global indices), one after the other,
+        each against the last kept view.  `state` = dict(prev, prev_scale, avg, T_guess) is where the chain stands -- the last kept
+        view (resident in slot_of, its normals built with prev_scale), the running scale and the constant-velocity prior -- and
+        comes back advanced, so that the next stretch (the next rank, reconstruct_sharded) continues exactly where this one ends.
+        Returns {cur: row}; row: T (prev -> cur, the (R_rel, t_rel) the reference chains), against, ok, scale_raw (the
+        registration's own estimate), scale (the running value the view is fused with), statistics."""
+        level_list = self._sim3_levels()
+        rows = {}
+        prev, avg, T_guess = int(state["prev"]), float(state["avg"]), np.asarray(state["T_guess"], np.float64).reshape(4, 4)
+        for cur in frames:
             print(f"\nProcessing image {cur}...")
             T0 = T_guess
             if init_poses is not None:
@@ -328,24 +323,60 @@ class DepthToReconstructionPipeline:
                 rr = np.asarray(r0) @ np.asarray(r1).T       # cur -> prev
                 T0 = np.eye(4)
                 T0[:3, :3], T0[:3, 3] = rr, (np.asarray(t0).reshape(3) - rr @ np.asarray(t1).reshape(3))
-            res = ctx.icp_batch([(cur, prev)], level_list, T_init=[T0], scales=[tr.avg])[0]
-            self.icp_log.append(dict(frame=cur, against=prev, scale=res["scale"], **{k: res[k] for k in ("fitness", "rmse", "n_corr", "iters_run", "status")}))
-            if res["status"] == 2 or res["n_corr"] < 8 or not np.isfinite(res["scale"]) or not (1e-3 < res["scale"] < 1e3):
+            res = ctx.icp_batch([(slot_of[cur], slot_of[prev])], level_list, T_init=[T0], scales=[avg])[0]
+            ok = not (res["status"] == 2 or res["n_corr"] < 8 or not np.isfinite(res["scale"]) or not (1e-3 < res["scale"] < 1e3))
+            row = dict(T=np.eye(4), against=prev, ok=ok, scale_raw=float(res["scale"]) if np.isfinite(res["scale"]) else 0.0, scale=avg,
+                       **{k: res[k] for k in ("fitness", "rmse", "n_corr", "iters_run", "status")})
+            rows[cur] = row
+            if not ok:
                 print(f"  Skipping - registration failed (correspondences: {res['n_corr']})")
                 continue
-            s_cur = tr.update(res["scale"], weight)
-            scales[cur] = s_cur
+            avg = (1.0 - weight) * avg + weight * res["scale"]               # D2R:650 with weight = 0.3
             T = res["T"]
             Ti = np.eye(4)
             Ti[:3, :3] = T[:3, :3].T
             Ti[:3, 3] = -T[:3, :3].T @ T[:3, 3]              # prev -> cur = (R_rel, t_rel)
-            r_c, t_c = compose(Ti[:3, :3], Ti[:3, 3], *poses[-1])
-            poses.append((r_c, t_c))
-            index.append(cur)
-            print(f"  ICP: fitness {res['fitness']:.3f}, rmse {res['rmse'] * 1e3:.2f} mm, {res['iters_run']} iterations, scale {res['scale']:.6f} -> {s_cur:.6f}")
-            ctx.build_normals(cur, scale=s_cur)
+            row["T"], row["scale"] = Ti, avg
+            print(f"  ICP: fitness {res['fitness']:.3f}, rmse {res['rmse'] * 1e3:.2f} mm, {res['iters_run']} iterations, scale {res['scale']:.6f} -> {avg:.6f}")
+            ctx.build_normals(slot_of[cur], scale=avg)
             T_guess = T
             prev = cur
+            state.update(prev=prev, prev_scale=avg)
+        state.update(avg=avg, T_guess=T_guess)
+        return rows
+
+    def _register_with_scale(self, ctx: FusionContext, scale0: float, init_poses=None, weight: float = 0.3):
+        """Registration of RELATIVE depth maps (row f3): every view's metric scale is the 7th unknown of its registration
+        against the previous kept view (Sim(3) point-to-plane ICP, tl3d_icp_params.estimate_scale), which replaces the
+        reference's median of Z_triangulated / depth over SIFT points (D2R:297-326, DER:659-697).  View 0 fixes the gauge
+        (scale0 = config.depth_scale, or the anchors' estimate); the running scale follows the reference's rule
+        avg = (1 - w) avg + w scale_i (D2R:650, w = 0.3; config.scale_update_weight = 1 trusts every view's own estimate).
+        The source of a run is the NEW view (unknown scale), the target the previous one (scale known, normals built with
+        it), so the run returns cur -> prev; its inverse is the (R_rel, t_rel) the reference chains (D2R:618-620).
+        Sequential by nature: a view's target needs that view's scale.  (Both views of a run read window-averaged depth when
+        config.icp_smooth_radius > 0: the target through its normal map, the source through the averaged map its own normals were
+        built from -- a view is a source BEFORE its scale is known, so its map is built with the running value first and rebuilt
+        with its own scale once that is known; the averaged depth itself does not depend on the scale.)"""
+        n = len(self.depths)
+        ctx.build_normals_many(list(range(n)), [float(scale0)] * n)       # every view's averaged depth (what a SOURCE reads); normals are rebuilt per view below
+        state = dict(prev=0, prev_scale=float(scale0), avg=float(scale0), T_guess=np.eye(4))
+        rows = self._sim3_chain(ctx, list(range(1, n)), {g: g for g in range(n)}, state, init_poses, weight)
+        return self._sim3_finish(rows, n, scale0)
+
+    def _sim3_finish(self, rows, n, scale0):
+        """(poses, kept frame indices, per-frame scales) from the rows of every view 1 .. n-1: cam0 = (I, 0), then
+        R = R_rel R_prev, t = R_rel t_prev + t_rel over the kept views (D2R:618-620)."""
+        poses, index, scales = [(np.eye(3), np.zeros((3, 1)))], [0], [float(scale0)] * n
+        for cur in range(1, n):
+            row = rows[cur]
+            self.icp_log.append(dict(frame=cur, against=row["against"], scale=row["scale_raw"],
+                                     **{k: row[k] for k in ("fitness", "rmse", "n_corr", "iters_run", "status")}))
+            if not row["ok"]:
+                continue
+            scales[cur] = row["scale"]
+            r_c, t_c = compose(row["T"][:3, :3], row["T"][:3, 3], *poses[-1])
+            poses.append((r_c, t_c))
+            index.append(cur)
         return poses, index, scales
 
     # ---- reconstruct ---------------------------------------------------------------------------------
@@ -488,7 +519,7 @@ class DepthToReconstructionPipeline:
                 out[b_] = dict(res, against=a)
         return out
 
-    def reconstruct_sharded(self, dist, grid: Optional[GridSpec] = None, init_poses=None, poses=None, anchors=None):
+    def reconstruct_sharded(self, dist, grid: Optional[GridSpec] = None, init_poses=None, poses=None, anchors=None, estimate_scale: bool = False):
         """reconstruct() over the ranks of an initialised torch.distributed group, one process per GPU:
 
           1. rank r uploads its contiguous frame range [lo, hi) plus the one-frame halo lo - 1 and registers every pair whose
@@ -503,6 +534,10 @@ class DepthToReconstructionPipeline:
              identity or init_poses; reconstruct() seeds later batches with a constant-velocity prior, so the two can converge
              to poses that differ in the last bits); rank 0 extracts, filters and returns the cloud (other ranks return
              (None, None, poses)).
+        estimate_scale (relative depth, no anchors: reconstruct()'s Sim(3) registration): a view's target needs that view's scale,
+        so the chain is sequential -- the ranks take turns, each continues it over its own views from the state the previous rank
+        hands over (last kept view and its scale, running scale, motion prior: 19 doubles), and the poses, the scales and the
+        cloud are those of the single-process run bit for bit; fusion and merge stay parallel.
         Every frame must be loaded on every rank's host (load_data); only the rank's own range goes to its GPU."""
         from . import distributed as dd
         world, rank = dist.get_world_size(), dist.get_rank()
@@ -534,6 +569,27 @@ class DepthToReconstructionPipeline:
                 ctx.upload(slot_of[g], self.depths[g], self.images[g])
             if poses is not None:
                 self.camera_poses, self.frame_index = list(poses), list(range(len(poses)))
+            elif estimate_scale:
+                say("\n--- Step 1: Register frames (Sim(3) point-to-plane ICP: pose and depth scale; the ranks take turns along the chain) ---")
+                scale0 = float(self.scales[0])
+                weight = float(getattr(cfg, "scale_update_weight", 0.3))
+                for g in resident:
+                    ctx.build_normals(slot_of[g], scale=scale0)           # every view's averaged depth (what a SOURCE reads)
+                state = dict(prev=0, prev_scale=scale0, avg=scale0, T_guess=np.eye(4))
+                rows = {}
+                for turn in range(world):
+                    mine_now = list(range(max(lo, 1), hi)) if turn == rank else []
+                    if mine_now:
+                        slots = dict(slot_of)
+                        if state["prev"] not in slots:                    # the last kept view lives on another rank's GPU: bring it here
+                            ctx.upload(spare, self.depths[state["prev"]], self.images[state["prev"]])
+                            slots[state["prev"]] = spare
+                        ctx.build_normals(slots[state["prev"]], scale=state["prev_scale"])     # the target's normals, with ITS scale
+                        with contextlib.redirect_stdout(io.StringIO()) if rank else contextlib.nullcontext():
+                            rows = self._sim3_chain(ctx, mine_now, slots, state, init_poses, weight)
+                    state = dd.handover_sim3_state(state, turn, dist)
+                table = dd.exchange_sim3_rows(rows, n, dist)
+                self.camera_poses, self.frame_index, self.scales = self._sim3_finish(table, n, scale0)
             else:
                 say("\n--- Step 1: Register frames (point-to-plane ICP, frame to frame, pairs sharded by rank) ---")
                 for g in resident:

@@ -112,9 +112,21 @@ def main():
     t0 = time.perf_counter()
     with contextlib.redirect_stdout(log):
         pts, col, est = pipe.reconstruct()
+    t_first = time.perf_counter() - t0
+    first_timings = pipe.timings
+    # the same call again in the same process: the first one also pays for what a process pays once (code objects loaded on first
+    # launch, the allocator's first large blocks, registration buffers) -- both are reported
+    pipe = DepthToReconstructionPipeline(cfg)
+    pipe.set_frames(images, depths)
+    t0 = time.perf_counter()
+    with contextlib.redirect_stdout(log):
+        pts, col, est = pipe.reconstruct()
     t_rec = time.perf_counter() - t0
+    occupancy = [l.strip() for l in log.getvalue().splitlines() if "Occupancy" in l][-1:]
     out = dict(config=name, frames=n, width=W, height=H, valid_pixel_fraction=round(valid_frac, 3), render_s=round(t_render, 1),
-               reconstruct_s=round(t_rec, 2), frames_per_s_whole_pipeline=round(n / t_rec, 1), stage_s=pipe.timings)
+               reconstruct_s=round(t_rec, 3), frames_per_s_whole_pipeline=round(n / t_rec, 1), stage_s=pipe.timings,
+               first_call_in_process=dict(reconstruct_s=round(t_first, 3), frames_per_s=round(n / t_first, 1), stage_s=first_timings),
+               layout=occupancy[0] if occupancy else "dense without asking (small grid)")
     if pts is None:
         out["error"] = "reconstruction failed"
         print(json.dumps(out))
