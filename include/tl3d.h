@@ -97,6 +97,11 @@ typedef struct tl3d_config {
                                    size, D2R:404-410): nx ny nz may describe a volume far larger than memory.  Bricks that are only
                                    ever free space hold a 4-byte count, no records.  When the pool runs out further new bricks are
                                    refused and counted (tl3d_stats.pool_refused): nothing is written out of bounds.             */
+    int64_t voxel_offset[3];    /* the grid is a BLOCK of a larger voxel lattice: its voxel (0,0,0) is voxel voxel_offset of the lattice that
+                                   starts at `origin` (multiples of TL3D_BRICK).  Voxel indices are computed against `origin` as ever (Open3D:
+                                   floor((p - origin) / voxel), D2R:404-410) and the offset is subtracted: a lattice of more than 2^32
+                                   voxels is fused block by block with identical voxels (DenseReconstructor.merge_pointclouds does).  Centroid
+                                   channel only: a grid with a TSDF channel must have offset 0.                                      */
 } tl3d_config;
 
 /* Result of an ICP run (device solve, read back once at the end). */

@@ -258,21 +258,28 @@ def test_a_30_m_corridor_at_5_mm_fuses_in_a_sparse_volume():
 
 
 def test_merge_pointclouds_of_a_large_extent_uses_a_sparse_grid():
-    """merge_pointclouds (D2R:386-420 / DER:615-645) on clouds 20 m apart at 5 mm: the dense centroid grid would take 99 GB (it
-    used to raise MemoryError); the occupied voxels are what Open3D's hash map holds, and what the sparse grid holds.  (The brick
-    tables index 2^32 voxels: beyond that extent the call still refuses.)"""
+    """merge_pointclouds (D2R:386-420 / DER:615-645) on clouds 61 m x 26 m x 3 m apart at 5 mm -- the reference's defaults reach 50 m
+    (D2R:57, :64) and Open3D's hash map holds the occupied voxels whatever the extent.  The lattice has 3.9e10 voxels: more than one
+    grid's brick table indexes (2^32), so it is fused block by block (tl3d_config.voxel_offset: blocks of ONE lattice, identical
+    voxels), each block a sparse grid; the result equals the restated Open3D merge."""
     from tl3d.config import ReconstructionConfig
     from tl3d.dense import DensePointCloudGenerator
     from tl3d.config import CameraIntrinsics
     from oracle import ref_numpy as rn
     rng = np.random.default_rng(7)
     a = (rng.random((40000, 3)) * np.array([1.0, 1.0, 0.02])).astype(np.float32)
-    b = a + np.array([20.0, 8.0, 1.0], np.float32)
+    b = a + np.array([61.0, 26.0, 3.0], np.float32)
+    c = (rng.random((20000, 3)) * np.array([61.0, 0.01, 0.01]) + np.array([0.0, 13.0, 1.5])).astype(np.float32)     # a line across every block boundary in x
     ca = rng.integers(0, 255, (40000, 3)).astype(np.uint8)
+    cc = rng.integers(0, 255, (20000, 3)).astype(np.uint8)
     gen = DensePointCloudGenerator(CameraIntrinsics(fx=500.0, fy=500.0, cx=320.0, cy=240.0, width=640, height=480))
     try:
-        pts, colr = gen.merge_pointclouds([(a, ca), (b, ca)], voxel_size=0.005)
+        pts, colr = gen.merge_pointclouds([(a, ca), (b, ca), (c, cc)], voxel_size=0.005)
     finally:
         gen.close()
-    ref_p, ref_c = rn.merge_open3d([(a, ca), (b, ca)], 0.005, sor=False)
+    ref_p, ref_c = rn.merge_open3d([(a, ca), (b, ca), (c, cc)], 0.005, sor=False)
     assert len(pts) == len(ref_p) and rn.chamfer_mean(pts, ref_p) < 2e-6
+    # (the same number of voxels and every centroid within the accumulator quantum of one of the reference's: the same voxel set)
+    from scipy.spatial import cKDTree
+    d, _ = cKDTree(ref_p).query(pts)
+    assert d.max() < 0.005 / 1024 + 61.0 * 2 ** -22

@@ -45,7 +45,7 @@ class Config(C.Structure):
                 ("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32),
                 ("origin", C.c_double * 3), ("voxel_size", C.c_double), ("sdf_trunc", C.c_double),
                 ("ext_tsdf", C.c_void_p), ("ext_centroid", C.c_void_p), ("stream", C.c_void_p),
-                ("pool_bricks_tsdf", C.c_int64), ("pool_bricks_centroid", C.c_int64)]
+                ("pool_bricks_tsdf", C.c_int64), ("pool_bricks_centroid", C.c_int64), ("voxel_offset", C.c_int64 * 3)]
 
 
 class IcpResult(C.Structure):

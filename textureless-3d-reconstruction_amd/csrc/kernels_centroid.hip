@@ -23,6 +23,7 @@ __device__ __forceinline__ CenAdd centroid_key(const Grid &g, const float p[3], 
     CenAdd o;
     o.rec = ~0ull;
     const double org[3] = {g.oxd, g.oyd, g.ozd};
+    const double off[3] = {g.offx, g.offy, g.offz};
     const int dims[3] = {g.nx, g.ny, g.nz};
     int idx[3];
     unsigned long long q[3];
@@ -30,8 +31,9 @@ __device__ __forceinline__ CenAdd centroid_key(const Grid &g, const float p[3], 
     for (int a = 0; a < 3; ++a) {
         const double rc = ((double)p[a] - org[a]) / g.vsd;
         const double fl = floor(rc);
-        if (!(fl >= 0.0 && fl < (double)dims[a])) return o;
-        idx[a] = (int)fl;
+        const double loc = fl - off[a];                       // (integers below 2^53: exact) this grid's voxel, a block of the lattice
+        if (!(loc >= 0.0 && loc < (double)dims[a])) return o;
+        idx[a] = (int)loc;
         int qq = (int)((rc - fl) * 4096.0);
         if (qq > 4095) qq = 4095;
         q[a] = (unsigned long long)qq;

@@ -39,6 +39,7 @@ __device__ __forceinline__ int extract_record(const Grid &g, const ExtArgs &a, c
     int ijk[3];
     rec_coords(idx, g.nbx, g.nby, ijk[0], ijk[1], ijk[2]);
     const double org[3] = {g.oxd, g.oyd, g.ozd};
+    const double off[3] = {g.offx, g.offy, g.offz};
     if (a.mode == TL3D_EXTRACT_CENTROID) {
         const unsigned long long *rec = cen_record(g, cen, idx);
         if (!rec) return 0;
@@ -57,7 +58,7 @@ __device__ __forceinline__ int extract_record(const Grid &g, const ExtArgs &a, c
 #pragma unroll
             for (int ax = 0; ax < 3; ++ax) {
                 const double f = ((double)s[ax] + 0.5 * (double)n) / ((double)n * 4096.0);
-                xyz[3 * o + ax] = (float)(org[ax] + ((double)ijk[ax] + f) * g.vsd);
+                xyz[3 * o + ax] = (float)(org[ax] + (off[ax] + (double)ijk[ax] + f) * g.vsd);
             }
             uint8_t c[3];
             mean_colour(rec, n, c);

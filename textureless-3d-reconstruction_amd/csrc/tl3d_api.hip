@@ -49,6 +49,7 @@ struct Rccl {
     int (*CommInitRank)(void **, int, const void *, int) = nullptr;      // ncclUniqueId is passed BY VALUE in C: see rccl_init_rank
     int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
     int (*CommDestroy)(void *) = nullptr;
+    int (*CommAbort)(void *) = nullptr;            // optional
     const char *(*GetErrorString)(int) = nullptr;
 };
 struct RcclId { char bytes[TL3D_RCCL_ID_BYTES]; };
@@ -66,6 +67,7 @@ int rccl_load() {
     g_rccl.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(g_rccl.lib, "ncclAllReduce");
     g_rccl.CommDestroy = (int (*)(void *))dlsym(g_rccl.lib, "ncclCommDestroy");
     g_rccl.GetErrorString = (const char *(*)(int))dlsym(g_rccl.lib, "ncclGetErrorString");
+    g_rccl.CommAbort = (int (*)(void *))dlsym(g_rccl.lib, "ncclCommAbort");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy) {
         g_rccl.lib = nullptr;
         return set_err(TL3D_E_STATE, "librccl.so lacks the expected entry points");
@@ -216,6 +218,12 @@ static int validate_grid(const tl3d_config *cfg) {
     REQUIRE(cfg->voxel_size > 0, TL3D_E_INVALID, "voxel_size must be positive");
     if (cfg->channels & TL3D_CH_TSDF) REQUIRE(cfg->sdf_trunc > 0, TL3D_E_INVALID, "sdf_trunc must be positive");
     REQUIRE(cfg->pool_bricks_tsdf >= 0 && cfg->pool_bricks_centroid >= 0, TL3D_E_INVALID, "negative brick pool size");
+    for (int a = 0; a < 3; ++a)
+        REQUIRE(cfg->voxel_offset[a] >= 0 && cfg->voxel_offset[a] % TL3D_BRICK == 0 && cfg->voxel_offset[a] < (1ll << 40), TL3D_E_INVALID,
+                "voxel_offset must be non-negative multiples of %d", TL3D_BRICK);
+    if (cfg->channels & TL3D_CH_TSDF)
+        REQUIRE(cfg->voxel_offset[0] == 0 && cfg->voxel_offset[1] == 0 && cfg->voxel_offset[2] == 0, TL3D_E_INVALID,
+                "a grid with a TSDF channel cannot be a block of a larger lattice (voxel_offset must be 0)");
     if (cfg->pool_bricks_tsdf > 0 || cfg->pool_bricks_centroid > 0)
         REQUIRE(cfg->ext_tsdf == nullptr && cfg->ext_centroid == nullptr, TL3D_E_INVALID, "a sparse grid (pool_bricks_*) cannot live in caller-owned dense memory");
     return TL3D_OK;
@@ -250,6 +258,7 @@ static void grid_geometry(Grid &g, const tl3d_config *cfg) {
     g.nx = cfg->nx; g.ny = cfg->ny; g.nz = cfg->nz;
     g.nbx = cfg->nx / 8; g.nby = cfg->ny / 8; g.nbz = cfg->nz / 8;
     g.oxd = cfg->origin[0]; g.oyd = cfg->origin[1]; g.ozd = cfg->origin[2]; g.vsd = cfg->voxel_size;
+    g.offx = (double)cfg->voxel_offset[0]; g.offy = (double)cfg->voxel_offset[1]; g.offz = (double)cfg->voxel_offset[2];
     g.ox = (float)g.oxd; g.oy = (float)g.oyd; g.oz = (float)g.ozd; g.vs = (float)g.vsd;
     g.trunc = (float)cfg->sdf_trunc;
     g.inv_trunc = (cfg->channels & TL3D_CH_TSDF) ? 1.0f / g.trunc : 0.0f;
@@ -1941,6 +1950,21 @@ int tl3d_rccl_init(tl3d_ctx *ctx, int world, int rank, const uint8_t id_in[TL3D_
     return TL3D_OK;
 }
 
+// A rank that fails BETWEEN the collectives of a merge must not simply return: its peers would sit in the next all-reduce for ever.
+// The communicator is aborted (the peers' pending and later collectives on it end with an error) and the context forgets it.
+static int rccl_abandon(tl3d_ctx *ctx, int code) {
+    if (ctx->rccl_comm) {
+        if (g_rccl.CommAbort) (void)g_rccl.CommAbort(ctx->rccl_comm);
+        else if (g_rccl.CommDestroy) (void)g_rccl.CommDestroy(ctx->rccl_comm);
+        ctx->rccl_comm = nullptr;
+    }
+    return code;
+}
+#define REQUIRE_OR_ABANDON(cond_, code_, ...) \
+    do {                                       \
+        if (!(cond_)) return rccl_abandon(ctx, set_err(code_, __VA_ARGS__)); \
+    } while (0)
+
 int tl3d_allreduce_grid(tl3d_ctx *ctx, uint32_t channels) {
     REQUIRE(ctx != nullptr, TL3D_E_INVALID, "null ctx");
     REQUIRE(ctx->rccl_comm != nullptr, TL3D_E_STATE, "call tl3d_rccl_init first");
@@ -1955,17 +1979,17 @@ int tl3d_allreduce_grid(tl3d_ctx *ctx, uint32_t channels) {
         // int32 headroom over all ranks: the sum of the ranks' largest voxel weights bounds the merged grid's
         long long w = 0;
         int rc = measure_max_weight(ctx, ctx->tsdf, &w);
-        if (rc) return rc;
+        if (rc) return rccl_abandon(ctx, rc);
         long long *d_w = nullptr;
-        TL3D_HIP(hipMalloc(&d_w, sizeof(long long)));
+        REQUIRE_OR_ABANDON(hipMalloc(&d_w, sizeof(long long)) == hipSuccess, TL3D_E_NOMEM, "alloc failed");
         hipError_t e = hipMemcpyAsync(d_w, &w, sizeof(w), hipMemcpyHostToDevice, ctx->stream);
         int nrc = e == hipSuccess ? g_rccl.AllReduce(d_w, d_w, 1, 4 /* ncclInt64 */, 0 /* ncclSum */, ctx->rccl_comm, ctx->stream) : -1;
         long long total = 0;
         if (nrc == 0) e = hipMemcpyAsync(&total, d_w, sizeof(total), hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         (void)hipFree(d_w);
-        REQUIRE(nrc == 0 && e == hipSuccess, TL3D_E_HIP, "weight all-reduce failed: %s", nrc ? rccl_msg(nrc) : hipGetErrorString(e));
-        REQUIRE(total <= TL3D_TSDF_MAX_WEIGHT, TL3D_E_STATE,
+        REQUIRE_OR_ABANDON(nrc == 0 && e == hipSuccess, TL3D_E_HIP, "weight all-reduce failed: %s", nrc ? rccl_msg(nrc) : hipGetErrorString(e));
+        REQUIRE_OR_ABANDON(total <= TL3D_TSDF_MAX_WEIGHT, TL3D_E_STATE,
                 "the merged TSDF grid could hold %lld observations per voxel (limit %d): merge more often or extract between scans", total,
                 TL3D_TSDF_MAX_WEIGHT);
         ctx->tsdf_w_upper = total;
@@ -1976,7 +2000,7 @@ int tl3d_allreduce_grid(tl3d_ctx *ctx, uint32_t channels) {
     // few dozen frames per rank touches a few per cent of a 1024^3 grid.
     const size_t nbr = ctx->nvox >> 9;
     unsigned char *d_map = nullptr;
-    TL3D_HIP(hipMalloc(&d_map, nbr));
+    REQUIRE_OR_ABANDON(hipMalloc(&d_map, nbr) == hipSuccess, TL3D_E_NOMEM, "brick map alloc failed");
     std::vector<unsigned char> h_map(nbr);
     std::vector<unsigned> h_idx;
     int rc = TL3D_OK;
@@ -1989,7 +2013,7 @@ int tl3d_allreduce_grid(tl3d_ctx *ctx, uint32_t channels) {
         if (nrc == 0) e = hipMemcpyAsync(h_map.data(), d_map, nbr, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         (void)hipFree(d_map);
-        REQUIRE(rc == TL3D_OK && nrc == 0 && e == hipSuccess, TL3D_E_HIP, "brick-map all-reduce failed: %s", nrc > 0 ? rccl_msg(nrc) : hipGetErrorString(e));
+        REQUIRE_OR_ABANDON(rc == TL3D_OK && nrc == 0 && e == hipSuccess, TL3D_E_HIP, "brick-map all-reduce failed: %s", nrc > 0 ? rccl_msg(nrc) : hipGetErrorString(e));
     }
     for (size_t b = 0; b < nbr; ++b)
         if (h_map[b]) h_idx.push_back((unsigned)b);
@@ -1997,23 +2021,26 @@ int tl3d_allreduce_grid(tl3d_ctx *ctx, uint32_t channels) {
     if (ctx->sparse && (channels & TL3D_CH_TSDF) && ctx->free_cnt) {
         // bricks without records carry their free-space observations as a count: summed like the records (4 B per brick)
         const int nrc = g_rccl.AllReduce(ctx->free_cnt, ctx->free_cnt, nbr, 3 /* ncclUint32 */, 0, ctx->rccl_comm, ctx->stream);
-        REQUIRE(nrc == 0, TL3D_E_HIP, "ncclAllReduce (free-space counts) failed: %s", rccl_msg(nrc));
+        REQUIRE_OR_ABANDON(nrc == 0, TL3D_E_HIP, "ncclAllReduce (free-space counts) failed: %s", rccl_msg(nrc));
     }
     ctx->stats.merge_bricks_sent += sparse ? h_idx.size() : nbr;
     ctx->stats.merge_bricks_total += nbr;
     if (!sparse) {
         if (channels & TL3D_CH_TSDF) {
             const int nrc = g_rccl.AllReduce(ctx->tsdf, ctx->tsdf, ctx->nvox * 2, 2 /* ncclInt32 */, 0, ctx->rccl_comm, ctx->stream);
-            REQUIRE(nrc == 0, TL3D_E_HIP, "ncclAllReduce (TSDF) failed: %s", rccl_msg(nrc));
+            REQUIRE_OR_ABANDON(nrc == 0, TL3D_E_HIP, "ncclAllReduce (TSDF) failed: %s", rccl_msg(nrc));
         }
         if (channels & TL3D_CH_CENTROID) {
             const int nrc = g_rccl.AllReduce(ctx->centroid, ctx->centroid, ctx->nvox * 4, 5 /* ncclUint64 */, 0, ctx->rccl_comm, ctx->stream);
-            REQUIRE(nrc == 0, TL3D_E_HIP, "ncclAllReduce (centroid) failed: %s", rccl_msg(nrc));
+            REQUIRE_OR_ABANDON(nrc == 0, TL3D_E_HIP, "ncclAllReduce (centroid) failed: %s", rccl_msg(nrc));
         }
-        TL3D_HIP(hipStreamSynchronize(ctx->stream));
+        REQUIRE_OR_ABANDON(hipStreamSynchronize(ctx->stream) == hipSuccess, TL3D_E_HIP, "sync failed");
         return TL3D_OK;
     }
-    if (h_idx.empty()) return TL3D_OK;
+    if (h_idx.empty()) {                                 // (the free-space counts' all-reduce may still be in flight)
+        REQUIRE_OR_ABANDON(hipStreamSynchronize(ctx->stream) == hipSuccess, TL3D_E_HIP, "sync failed");
+        return TL3D_OK;
+    }
     unsigned *d_idx = nullptr;
     void *d_pack = nullptr;
     const size_t n = h_idx.size();
@@ -2021,7 +2048,7 @@ int tl3d_allreduce_grid(tl3d_ctx *ctx, uint32_t channels) {
     if (hipMalloc(&d_idx, n * sizeof(unsigned)) != hipSuccess || hipMalloc(&d_pack, n * row) != hipSuccess) {
         (void)hipGetLastError();
         if (d_idx) (void)hipFree(d_idx);
-        return set_err(TL3D_E_NOMEM, "merge staging alloc (%zu B) failed", n * row);
+        return rccl_abandon(ctx, set_err(TL3D_E_NOMEM, "merge staging alloc (%zu B) failed", n * row));
     }
     hipError_t e = hipMemcpyAsync(d_idx, h_idx.data(), n * sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream);
     int nrc = 0;
@@ -2038,7 +2065,7 @@ int tl3d_allreduce_grid(tl3d_ctx *ctx, uint32_t channels) {
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(d_idx);
     (void)hipFree(d_pack);
-    REQUIRE(rc == TL3D_OK && nrc == 0 && e == hipSuccess, TL3D_E_HIP, "sparse grid all-reduce failed: %s", nrc ? rccl_msg(nrc) : hipGetErrorString(e));
+    REQUIRE_OR_ABANDON(rc == TL3D_OK && nrc == 0 && e == hipSuccess, TL3D_E_HIP, "sparse grid all-reduce failed: %s", nrc ? rccl_msg(nrc) : hipGetErrorString(e));
     return TL3D_OK;
 }
 

@@ -21,6 +21,7 @@ struct Grid {
     int nbx, nby, nbz;           // bricks (8^3 voxels)
     float ox, oy, oz, vs;        // f32 origin / voxel size (TSDF path)
     double oxd, oyd, ozd, vsd;   // fp64 (centroid path, Open3D index semantics)
+    double offx, offy, offz;     // the grid's voxel (0,0,0) is voxel (offx, offy, offz) of the lattice that starts at the origin (integers; centroid path)
     float trunc, inv_trunc;
     // Brick tables: the records of virtual brick b of a channel sit in pool slot table[b] (512 records each).  A dense grid has
     // the identity table and a pool of every brick; a SPARSE grid starts with an empty table and hands out slots on first

@@ -106,27 +106,38 @@ class _DeviceDense:
         origin = mn - 0.5 * v
         dims = np.floor((mx - origin) / v).astype(np.int64) + 1
         dims = ((dims + 7) // 8) * 8
-        nvox = int(dims[0]) * int(dims[1]) * int(dims[2])
-        if nvox > (1 << 32):
-            raise MemoryError(f"merge_pointclouds: extent {mx - mn} m at voxel {v} m needs a {tuple(int(d) for d in dims)} grid: more than "
-                              "2^32 voxels (the brick tables index 32 bits); raise voxel_size")
-        # Open3D's hash map holds the occupied voxels only (D2R:404-410): so does a sparse grid.  A cloud of n points occupies
-        # at most n voxels, i.e. at most n bricks; the pool is what the points can need, capped by the memory budget.
+        # Open3D's hash map holds the occupied voxels only, whatever the extent (D2R:404-410; the reference's defaults reach
+        # 50 m at 5 mm: D2R:57, :64).  Here a grid's brick table is direct-indexed: up to 2^32 voxels per grid.  A larger lattice is
+        # fused BLOCK BY BLOCK: blocks of at most 2^31 voxels (multiples of 8 per axis) of the one lattice that starts at `origin`
+        # (tl3d_config.voxel_offset: indices are computed against `origin` and the block's offset subtracted, so the voxels are the
+        # single-grid voxels exactly); every point list goes to every block, a block keeps the points that fall into it.
+        blocks = _lattice_blocks(dims, 1 << 31)
         n_points = int(sum(len(p) for p in pts))
-        pool = 0
-        if nvox * 32 > MERGE_GRID_BUDGET_BYTES // 4:
-            pool = int(min(nvox // 512, max(4096, min(n_points, MERGE_GRID_BUDGET_BYTES // 16384))))
-        spec = GridSpec(tuple(int(d) for d in dims), tuple(float(o) for o in origin), v, 4 * v, abi.CH_CENTROID, pool_centroid=pool)
-        with FusionContext(8, 8, 1.0, 1.0, 0.0, 0.0, n_slots=1, grid=spec, device=self._device) as ctx:
-            for p, c in zip(pts, col):
-                ctx.accumulate_points(p, c)
-            if pool and ctx.stats()["pool_refused"]:
-                raise MemoryError(f"merge_pointclouds: the cloud occupies more than {pool} bricks of 8^3 voxels at voxel {v} m "
-                                  f"({pool * 16384 / 2**30:.0f} GiB of records): raise voxel_size")
-            xyz, rgb = ctx.extract(abi.EXTRACT_CENTROID)
-            if sor and len(xyz) > 0:
+        out_xyz, out_rgb = [], []
+        for off, bdims in blocks:
+            nvox = int(bdims[0]) * int(bdims[1]) * int(bdims[2])
+            # A cloud of n points occupies at most n voxels, i.e. at most n bricks; the pool is what the points can need, capped by the
+            # memory budget.
+            pool = 0
+            if nvox * 32 > MERGE_GRID_BUDGET_BYTES // 4:
+                pool = int(min(nvox // 512, max(4096, min(n_points, MERGE_GRID_BUDGET_BYTES // 16384))))
+            spec = GridSpec(tuple(int(d) for d in bdims), tuple(float(o) for o in origin), v, 4 * v, abi.CH_CENTROID, pool_centroid=pool,
+                            voxel_offset=tuple(int(o) for o in off))
+            with FusionContext(8, 8, 1.0, 1.0, 0.0, 0.0, n_slots=1, grid=spec, device=self._device) as ctx:
+                for p, c in zip(pts, col):
+                    ctx.accumulate_points(p, c)
+                if pool and ctx.stats()["pool_refused"]:
+                    raise MemoryError(f"merge_pointclouds: the cloud occupies more than {pool} bricks of 8^3 voxels at voxel {v} m "
+                                      f"({pool * 16384 / 2**30:.0f} GiB of records): raise voxel_size")
+                xyz, rgb = ctx.extract(abi.EXTRACT_CENTROID)
+            out_xyz.append(xyz)
+            out_rgb.append(rgb)
+        xyz = np.concatenate(out_xyz) if len(out_xyz) > 1 else out_xyz[0]
+        rgb = np.concatenate(out_rgb) if len(out_rgb) > 1 else out_rgb[0]
+        if sor and len(xyz) > 0:
+            with FusionContext(8, 8, 1.0, 1.0, 0.0, 0.0, n_slots=1, grid=None, device=self._device) as ctx:
                 keep = ctx.statistical_outlier(xyz, nb_neighbors, std_ratio, cell_size=2.0 * v)
-                xyz, rgb = xyz[keep], rgb[keep]
+            xyz, rgb = xyz[keep], rgb[keep]
         # the reference hands back what Open3D holds: fp64 points, uint8 colours (D2R:417-418)
         return xyz.astype(np.float64), rgb
 
@@ -134,6 +145,25 @@ class _DeviceDense:
         for c in self._bp_ctx.values():
             c.close()
         self._bp_ctx.clear()
+
+
+def _lattice_blocks(dims, max_voxels):
+    """[(offset, dims)] of blocks that tile a lattice of `dims` voxels (multiples of 8), each of at most max_voxels: the longest axis
+    is halved (at a multiple of 8) until every block fits."""
+    out, todo = [], [(np.zeros(3, np.int64), np.asarray(dims, np.int64))]
+    while todo:
+        off, d = todo.pop()
+        if int(d[0]) * int(d[1]) * int(d[2]) <= max_voxels:
+            out.append((off, d))
+            continue
+        a = int(np.argmax(d))
+        h = ((int(d[a]) // 2 + 7) // 8) * 8
+        lo, hi = d.copy(), d.copy()
+        lo[a], hi[a] = h, d[a] - h
+        off_hi = off.copy()
+        off_hi[a] += h
+        todo += [(off_hi, hi), (off, lo)]
+    return sorted(out, key=lambda b: (int(b[0][2]), int(b[0][1]), int(b[0][0])))
 
 
 class DenseReconstructor(_DeviceDense):

@@ -26,6 +26,9 @@ class GridSpec:
     # merge gives for free, D2R:404-410).
     pool_tsdf: int = 0
     pool_centroid: int = 0
+    # the grid is a BLOCK of a larger voxel lattice that starts at `origin`: index of its voxel (0, 0, 0) in that lattice (multiples of 8;
+    # centroid channel only -- tl3d.h: tl3d_config.voxel_offset)
+    voxel_offset: Tuple[int, int, int] = (0, 0, 0)
 
     @property
     def sparse(self) -> bool:
@@ -103,6 +106,7 @@ class FusionContext:
             cfg.voxel_size = float(grid.voxel_size)
             cfg.sdf_trunc = float(grid.sdf_trunc)
             cfg.pool_bricks_tsdf, cfg.pool_bricks_centroid = int(grid.pool_tsdf), int(grid.pool_centroid)
+            cfg.voxel_offset = (C.c_int64 * 3)(*[int(o) for o in grid.voxel_offset])
         cfg.ext_tsdf = abi.ptr(ext_tsdf)
         cfg.ext_centroid = abi.ptr(ext_centroid)
         cfg.stream = abi.ptr(stream)
@@ -185,6 +189,7 @@ class FusionContext:
         cfg.origin = (C.c_double * 3)(*[float(o) for o in grid.origin])
         cfg.voxel_size, cfg.sdf_trunc = float(grid.voxel_size), float(grid.sdf_trunc)
         cfg.pool_bricks_tsdf, cfg.pool_bricks_centroid = int(grid.pool_tsdf), int(grid.pool_centroid)
+        cfg.voxel_offset = (C.c_int64 * 3)(*[int(o) for o in grid.voxel_offset])
         cfg.ext_tsdf, cfg.ext_centroid = abi.ptr(ext_tsdf), abi.ptr(ext_centroid)
         abi.check(self._lib.tl3d_attach_grid(self._h, C.byref(cfg)))
         self._keep = (ext_tsdf, ext_centroid)

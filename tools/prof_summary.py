@@ -1,8 +1,10 @@
 """pmc_traffic.json for bench.py from the --pmc passes of tools/pmc_quick.sh:  python3 tools/prof_summary.py <out dir> <pmc dir>.
 
-traffic = (FETCH_SIZE + WRITE_SIZE) x 1024 per dispatch of tsdf_update_kernel, at face value: the kernel has no 16-B-per-lane
-streaming reads (the case in which gfx950's FETCH_SIZE reports half the bytes); its 8-B-per-lane record runs and 4-B gathers are
-calibrated on known byte counts by tools/ubench_fetch.hip (pmc_calibration.txt beside this file)."""
+traffic = (FETCH_SIZE + WRITE_SIZE) x 1024 per dispatch of the update kernel PLUS the half of its coalesced record reads that
+FETCH_SIZE does not tally on gfx950 (8 B per lane reads report 0.500 of their bytes, like the 16-B case of the guide; scattered
+4-B gathers report 0.98 x 64 B per lane; WRITE_SIZE is exact: tools/ubench_fetch.hip, profiles/r03_pmc_calibration.txt).  The
+record bytes read equal the record bytes written (every touched record is read and written once per launch), so the correction is
+0.5 x WRITE_SIZE.  This corrected figure is what bench.py reports as roofline.traffic."""
 import json
 import os
 import re
@@ -16,7 +18,7 @@ for line in open(os.path.join(pmc, "summary.txt")):
         cur = line.strip()
         continue
     m = re.match(r"\s+(\S+)\s+mean\s+([0-9.]+)", line)
-    if m and cur and "tsdf_update_kernel<false" in cur:
+    if m and cur and ("tsdf_update_kernel<false" in cur or "tsdf_update_pairs_kernel<false" in cur):
         vals[m.group(1)] = float(m.group(2))
 bench = None
 for line in open(os.path.join(pmc, "bench1.log")):
@@ -30,7 +32,7 @@ if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals and bench:
     # that FETCH_SIZE misses is added back.
     rec_read = min(vals["WRITE_SIZE"], 2.0 * vals["FETCH_SIZE"]) * 1024.0
     j = {"grid": bench["config"]["grid"], "width": 1080, "height": 1920, "depth_format": bench["config"]["depth_format"], "free_space_counters": True,
-         "kernel": "tsdf_update_kernel", "frames_per_sweep": int(round(r["frames_per_sweep"])), "fetch_size_kb": round(vals["FETCH_SIZE"], 1),
+         "kernel": "tsdf_update_pairs_kernel", "frames_per_sweep": int(round(r["frames_per_sweep"])), "fetch_size_kb": round(vals["FETCH_SIZE"], 1),
          "write_size_kb": round(vals["WRITE_SIZE"], 1),
          "hbm_bytes_per_launch": int((vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0 + 0.5 * rec_read),
          "record_read_bytes_added_back": int(0.5 * rec_read),
