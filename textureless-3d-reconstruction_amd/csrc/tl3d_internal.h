@@ -145,7 +145,7 @@ constexpr int ICP_SLAB = 40;     // doubles per block partial: 30 sums of the po
 // every touched record once per batch.  Three batch scratch buffers are taken in turn, so the prep chains of batches k+1 and k+2
 // run beside the update of batch k.
 #define TL3D_TSDF_MAXBATCH 32
-constexpr int TSDF_SCRATCHES = 3;
+constexpr int TSDF_SCRATCHES = 4;
 
 struct tl3d_ctx {
     tl3d_config cfg;

@@ -347,7 +347,8 @@ class FramePrefetcher:
         self._f32 = [PinnedArray((h, w), np.float32) for _ in range(self.n_staging)]
         self._u16 = [PinnedArray((h, w), np.uint16) for _ in range(self.n_staging)]
         self._bgr = [PinnedArray((h, w, 3), np.uint8) for _ in range(self.n_staging)]
-        self._pool = ThreadPoolExecutor(max_workers=max(1, int(workers)))
+        self.workers = max(1, int(workers))
+        self._pool = ThreadPoolExecutor(max_workers=self.workers)
         self.decode_s = 0.0
 
     def _decode(self, i, b):

@@ -416,6 +416,9 @@ class DepthToReconstructionPipeline:
                     for _i, _slot in pre:
                         pass
                 finally:
+                    # where a file-fed run's time goes: decode (summed over the worker threads) against the wall time of the stage
+                    self.decode_stats = dict(workers=pre.workers, decode_thread_seconds=round(pre.decode_s, 3),
+                                             decode_ms_per_frame_and_thread=round(1e3 * pre.decode_s / max(1, n), 2))
                     pre.close()
             else:
                 for i in range(n):

@@ -48,7 +48,8 @@ try:
                 t1 = time.perf_counter()
                 pts, col, _ = pipe.reconstruct(grid=grid, poses=rel)
             t2 = time.perf_counter()
+            dec = getattr(pipe, "decode_stats", None)
             print(f"{kind:4s} {mode:10s}: load {t1 - t0_:6.2f} s, reconstruct {t2 - t1:6.2f} s, total {N / (t2 - t0_):7.1f} frames/s, "
-                  f"{len(pts)} points; stages {pipe.timings}", flush=True)
+                  f"{len(pts)} points; stages {pipe.timings}" + (f"; decode {dec}" if dec else ""), flush=True)
 finally:
     shutil.rmtree(root, ignore_errors=True)

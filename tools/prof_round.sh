@@ -9,7 +9,7 @@
 # 4. plain bench lines: default (f32), 16-bit frames, the config-5 shape.
 # Writes gpurun_out/prof_<tag>/; copy what should be judged into profiles/.
 set -uo pipefail
-TAG="${1:-r03}"
+TAG="${1:-r04}"
 export TMPDIR=/tmp
 OUT="$PWD/gpurun_out/prof_${TAG}"
 rm -rf "$OUT"; mkdir -p "$OUT"
@@ -34,14 +34,14 @@ for l in open(os.path.join(out, "bench_rows_traced.json")):
 rows = []
 for f in glob.glob(os.path.join(out, "trace2", "**", "*kernel_trace.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        if "tsdf_update_kernel<false" in r["Kernel_Name"]:
+        if "tsdf_update_pairs_kernel<false" in r["Kernel_Name"]:
             rows.append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
 rows.sort()
 if b and rows:
     per_step = 512 // 32
     n_head = (b["warmup"] + 2 * b["steps"]) * per_step
     head, rest = [d for _, d in rows[:n_head]], [d for _, d in rows[n_head:]]
-    print(f"tsdf_update_kernel<false, ...> dispatches of `python3 bench.py`: {len(rows)}")
+    print(f"tsdf_update_pairs_kernel<false, ...> dispatches of `python3 bench.py`: {len(rows)}")
     print(f"  first {len(head)} (warm-up, timed region, profiled re-run: 32 frames per launch): mean {sum(head) / len(head):.1f} us  min {min(head):.1f}  max {max(head):.1f}")
     print(f"  last {len(head) - b['warmup'] * per_step - b['steps'] * per_step} of those (the profiled re-run): mean {sum(head[-b['steps'] * per_step:]) / (b['steps'] * per_step):.1f} us;  bench.py's hipEvent figure: {1e3 * b['roofline']['ms_per_launch']:.1f} us")
     if rest: print(f"  the other {len(rest)} (one frame per launch, rows): mean {sum(rest) / len(rest):.1f} us  min {min(rest):.1f}  max {max(rest):.1f}")

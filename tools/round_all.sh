@@ -2,7 +2,7 @@
 # usage (GPU box, repo root): bash tools/round_all.sh r03  -- the round's profile set (tools/prof_round.sh) and the four full-length
 # BASELINE configuration runs (tools/run_config.py); everything lands under gpurun_out/.
 set -uo pipefail
-TAG="${1:-r03}"
+TAG="${1:-r04}"
 bash tools/prof_round.sh "$TAG" > "gpurun_out/prof_round_${TAG}.log" 2>&1; echo "prof_round rc=$?"
 : > "gpurun_out/${TAG}_config_runs.jsonl"
 for c in 2 3 4 4b; do
