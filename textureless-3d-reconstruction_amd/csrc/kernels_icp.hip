@@ -20,9 +20,11 @@
 
 namespace tl3d {
 
+// PM: `depth` is kept in phase-major rows (pm_index, tl3d_internal.h: the window-averaged depth), else row-major (the frame itself)
+template <bool PM>
 __device__ __forceinline__ bool load_vertex(const Cam &cam, const float *__restrict__ depth, int u, int v, float sc,
                                             float mind, float maxd, float p[3]) {
-    const float d = depth[(size_t)v * cam.W + u] * sc;
+    const float d = depth[PM ? pm_index(u, v, pm_w4(cam.W)) : (size_t)v * cam.W + u] * sc;
     if (!(d > mind && d < maxd)) return false;
     p[0] = (((float)u - cam.cx) / cam.fx) * d;
     p[1] = (((float)v - cam.cy) / cam.fy) * d;
@@ -62,10 +64,12 @@ __global__ __launch_bounds__(256) void smooth_depth_kernel(Cam cam, const float 
             }
         res = (float)n / sum;
     }
-    out[(size_t)v * cam.W + u] = res;
+    out[pm_index(u, v, pm_w4(cam.W))] = res;              // phase-major rows: what the registration samples at its stride
 }
 
-// step: the tangent vectors come from the pixels `step` to either side (1: plain central differences)
+// step: the tangent vectors come from the pixels `step` to either side (1: plain central differences).  The map is written in
+// phase-major rows.
+template <bool PM>
 __global__ __launch_bounds__(256) void normals_kernel(Cam cam, const float *__restrict__ depth, float sc, float mind,
                                                       float maxd, float jump, int step, float4 *__restrict__ nmap) {
     const int u = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -74,11 +78,11 @@ __global__ __launch_bounds__(256) void normals_kernel(Cam cam, const float *__re
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
     float p[3], l[3], r[3], up[3], dn[3];
     bool ok = (u >= step && v >= step && u <= cam.W - 1 - step && v <= cam.H - 1 - step);
-    ok = ok && load_vertex(cam, depth, u, v, sc, mind, maxd, p);
-    ok = ok && load_vertex(cam, depth, u - step, v, sc, mind, maxd, l);
-    ok = ok && load_vertex(cam, depth, u + step, v, sc, mind, maxd, r);
-    ok = ok && load_vertex(cam, depth, u, v - step, sc, mind, maxd, up);
-    ok = ok && load_vertex(cam, depth, u, v + step, sc, mind, maxd, dn);
+    ok = ok && load_vertex<PM>(cam, depth, u, v, sc, mind, maxd, p);
+    ok = ok && load_vertex<PM>(cam, depth, u - step, v, sc, mind, maxd, l);
+    ok = ok && load_vertex<PM>(cam, depth, u + step, v, sc, mind, maxd, r);
+    ok = ok && load_vertex<PM>(cam, depth, u, v - step, sc, mind, maxd, up);
+    ok = ok && load_vertex<PM>(cam, depth, u, v + step, sc, mind, maxd, dn);
     if (ok) {
         ok = fabsf(l[2] - p[2]) <= jump && fabsf(r[2] - p[2]) <= jump && fabsf(up[2] - p[2]) <= jump &&
              fabsf(dn[2] - p[2]) <= jump;
@@ -98,43 +102,63 @@ __global__ __launch_bounds__(256) void normals_kernel(Cam cam, const float *__re
             o = make_float4(nx, ny, nz, p[2]);
         }
     }
-    nmap[(size_t)v * cam.W + u] = o;
+    nmap[pm_index(u, v, pm_w4(cam.W))] = o;
 }
 
 // accumulate this workgroup's share of the sums and leave the workgroup total in sm_out[0..31] (valid for threads < 32
 // after the function's last barrier)
 // `member` of `members` workgroups share one registration: member m takes samples m*256 + tid, + members*256, ...
-template <bool SCALE>
+// ray_tab (batched kernel; null: computed in place): the pixel-ray factors ((float)u - cx) / fx for u < W, then ((float)v - cy) / fy
+// for v < H, in LDS -- the very quotients the expression gives (filled with that expression), looked up instead of divided
+// out four times per sample and pass (an IEEE f32 division is ~10 vector instructions; they were 40 of the ~115 per sample).
+template <bool SCALE, bool TAB>
 __device__ __forceinline__ void icp_accumulate_core(const Cam &cam, const float *__restrict__ depth_s, const float4 *__restrict__ nmap_t,
                                                     float sc, float mind, float maxd, float md2, int stride, int Ws, int Hs,
-                                                    const float r[9], const float t[3], int member, int members,
-                                                    double (*sm)[ICP_SLAB], double *__restrict__ sm_out, unsigned long long *stamp = nullptr) {
+                                                    const float r[9], const float t[3], int member, int members, int src_pm,
+                                                    double (*sm)[ICP_SLAB], double *__restrict__ sm_out, unsigned long long *stamp = nullptr,
+                                                    const float *ray_tab = nullptr) {
     const float wlim = (float)cam.W - 0.5f, hlim = (float)cam.H - 0.5f;
+    // Both maps are device memory: say so.  The batched kernel reads the pointers from a table in memory, where the compiler only
+    // knows a generic pointer and issues FLAT loads -- which also count on the LDS counter, so that every wait for an LDS read (the
+    // ray tables below) would wait for every gather in flight and undo the software pipeline.
+    typedef const __attribute__((address_space(1))) float *gfloat_p;
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(1))) v4f *gfloat4_p;
+    const gfloat_p depth_g = (gfloat_p)depth_s;
+    const gfloat4_p nmap_g = (gfloat4_p)nmap_t;
+    // the target map is kept in phase-major rows, the source depth too when it is a window-averaged one (src_pm); a raw frame is
+    // row-major: (mask, shift, phase length, row length) make one index expression of both (wave-uniform values)
+    const int w4 = pm_w4(cam.W);
+    const int s_mask = src_pm ? 3 : 0, s_shift = src_pm ? 2 : 0, s_row = src_pm ? 4 * w4 : cam.W;
+    const float *xtab = ray_tab, *ytab = ray_tab + cam.W;
+    auto xray = [&](int u) { return TAB ? xtab[u] : ((float)u - cam.cx) / cam.fx; };
+    auto yray = [&](int v) { return TAB ? ytab[v] : ((float)v - cam.cy) / cam.fy; };
     double acc[30];
 #pragma unroll
     for (int i = 0; i < 30; ++i) acc[i] = 0.0;
     double accs[8];                                      // scale column (Sim(3) runs): sum J_a J_alpha (6), J_alpha^2, J_alpha r
 #pragma unroll
     for (int i = 0; i < 8; ++i) accs[i] = 0.0;
-    const long long ns = (long long)Ws * Hs;
-    // Four samples per trip, every load of the trip issued before its first use (source depths, then the normal-map
-    // gathers): a thread's trip costs one depth latency + one gather latency instead of four of each (with two workgroups per
-    // CU there are two waves per SIMD to hide them behind: two samples per trip left the SIMD idle 60 % of the time).  Addresses of
-    // rejected samples are clamped to element 0 so that the loads need no branch; the per-thread order of the sums is the
-    // sample order, as before.
-    const long long step = (long long)members * 256;
+    // Samples are walked with 32-bit pixel coordinates kept per thread (a sample index divided by the level's width cost a 64-bit
+    // division per sample): sample s = vs * Ws + us; the next one of this thread is `step` = members * 256 samples on.
+    const int step = members * 256;
+    const int dvs = step / Ws, dus = step - dvs * Ws;        // wave-uniform
     struct Samp { float px, py, pz; int ut, vt; bool src_ok, ok; };
-    auto prep = [&](float draw, int u, int v, bool in_range) {
+    auto prep = [&](float draw, int u, int v) {
         Samp q;
         const float d = draw * sc;
-        q.src_ok = in_range && (d > mind && d < maxd);
-        const float p0 = (((float)u - cam.cx) / cam.fx) * d;
-        const float p1 = (((float)v - cam.cy) / cam.fy) * d;
+        q.src_ok = (d > mind && d < maxd);
+        const float p0 = xray(u) * d;
+        const float p1 = yray(v) * d;
         q.px = fmaf(r[0], p0, fmaf(r[1], p1, fmaf(r[2], d, t[0])));
         q.py = fmaf(r[3], p0, fmaf(r[4], p1, fmaf(r[5], d, t[1])));
         q.pz = fmaf(r[6], p0, fmaf(r[7], p1, fmaf(r[8], d, t[2])));
         bool ok = q.src_ok && (q.pz > 0.0f);
-        const float inv = 1.0f / q.pz;
+        // 1 / pz: v_rcp_f32 + one Newton step IS the IEEE quotient for every positive float in [2^-126, 2^126) (exhaustive check:
+        // tools/ubench_rcp.hip, profiles/r03_ubench_rcp.txt); lanes outside take the division; pz <= 0 is rejected whatever it gives
+        float inv = __builtin_amdgcn_rcpf(q.pz);
+        inv = fmaf(fmaf(-q.pz, inv, 1.0f), inv, inv);
+        if (__builtin_expect(ok && !(q.pz >= 1.17549435e-38f && q.pz < 8.5e37f), 0)) inv = 1.0f / q.pz;
         const float uf = fmaf(cam.fx * q.px, inv, cam.cx);
         const float vf = fmaf(cam.fy * q.py, inv, cam.cy);
         ok = ok && (uf >= -0.5f && uf < wlim && vf >= -0.5f && vf < hlim);
@@ -146,13 +170,13 @@ __device__ __forceinline__ void icp_accumulate_core(const Cam &cam, const float 
         q.ok = ok;
         return q;
     };
-    auto accum = [&](const Samp &q, const float4 nd) {
+    auto accum = [&](const Samp &q, const v4f nd) {
         if (q.src_ok) acc[29] += 1.0;
         const float dt = nd.w;
         if (!(q.ok && dt > 0.0f)) return;
         const float px = q.px, py = q.py, pz = q.pz;
-        const float qx = (((float)q.ut - cam.cx) / cam.fx) * dt;
-        const float qy = (((float)q.vt - cam.cy) / cam.fy) * dt;
+        const float qx = xray(q.ut) * dt;
+        const float qy = yray(q.vt) * dt;
         const float dx = px - qx, dy = py - qy, dz = pz - dt;
         const float dist2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
         if (!(dist2 <= md2)) return;
@@ -160,47 +184,78 @@ __device__ __forceinline__ void icp_accumulate_core(const Cam &cam, const float 
         const double J[6] = {(double)fmaf(py, nd.z, -(pz * nd.y)), (double)fmaf(pz, nd.x, -(px * nd.z)),
                              (double)fmaf(px, nd.y, -(py * nd.x)), (double)nd.x, (double)nd.y, (double)nd.z};
         const double rr = (double)res;
+        // every factor is an f32 value, so every product is EXACT in fp64 (48 significant bits) and fma(a, b, s) rounds the very
+        // sum s + a * b the oracle's multiply-then-add rounds: one instruction instead of two, the same bits
         int m = 0;
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
 #pragma unroll
-            for (int b = a; b < 6; ++b) { acc[m] += J[a] * J[b]; ++m; }
-            acc[21 + a] += J[a] * rr;
+            for (int b = a; b < 6; ++b) { acc[m] = fma(J[a], J[b], acc[m]); ++m; }
+            acc[21 + a] = fma(J[a], rr, acc[21 + a]);
         }
-        acc[27] += rr * rr;
+        acc[27] = fma(rr, rr, acc[27]);
         acc[28] += 1.0;
         if (SCALE) {
             // sigma <- sigma exp(alpha) moves q = R sigma p_hat + t by alpha (q - t):  J_alpha = n . (q - t)
             const double ja = (double)fmaf(nd.x, px - t[0], fmaf(nd.y, py - t[1], nd.z * (pz - t[2])));
 #pragma unroll
-            for (int a = 0; a < 6; ++a) accs[a] += J[a] * ja;
-            accs[6] += ja * ja;
-            accs[7] += ja * rr;
+            for (int a = 0; a < 6; ++a) accs[a] = fma(J[a], ja, accs[a]);
+            accs[6] = fma(ja, ja, accs[6]);
+            accs[7] = fma(ja, rr, accs[7]);
         }
     };
-    constexpr int NS = 4;                                // samples per trip: every load of the trip issued before its first use
-    for (long long sb = (long long)member * 256 + threadIdx.x; sb < ns; sb += NS * step) {
-        float d[NS];
-        int uu[NS], vv[NS];
-        bool in[NS];
+    // Four samples per trip, software-pipelined over the trips: while trip i is added up, the normal-map gathers of trip i + 1 and
+    // the source depths of trip i + 2 are in flight (the trace of round 4 showed a trip of the plain loop -- depths, wait, gathers,
+    // wait, sums -- at 2.7-4 us, two exposed memory latencies, against ~0.8 us of arithmetic: with two workgroups per CU there is
+    // one other wave per SIMD to fill them).  Loads past a thread's last sample go to element 0 and count as depth 0 (rejected
+    // as any invalid depth); the per-thread order of the sums is the sample order, as ever.
+    constexpr int NS = 4;
+    struct Src { float d[NS]; int uu[NS], vv[NS]; };
+    int us, vs;                                              // the next sample this thread fetches
+    {
+        const int s0 = member * 256 + (int)threadIdx.x;
+        vs = s0 / Ws;
+        us = s0 - vs * Ws;
+    }
+    auto fetch_src = [&]() {
+        Src x;
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
-            const long long sk = sb + k * step;
-            in[k] = sk < ns;
-            const long long skc = in[k] ? sk : sb;
-            const int vs = (int)(skc / Ws), us = (int)(skc - (long long)vs * Ws);
-            uu[k] = us * stride;
-            vv[k] = vs * stride;
-            d[k] = depth_s[(size_t)vv[k] * cam.W + uu[k]];
+            const bool in = vs < Hs;
+            x.uu[k] = in ? us * stride : 0;
+            x.vv[k] = in ? vs * stride : 0;
+            const float dv = depth_g[(size_t)x.vv[k] * s_row + ((x.uu[k] & s_mask) * w4 + (x.uu[k] >> s_shift))];
+            x.d[k] = in ? dv : 0.0f;
+            us += dus;
+            vs += dvs;
+            if (us >= Ws) { us -= Ws; vs += 1; }
         }
-        Samp q[NS];
+        return x;
+    };
+    const int vs_first = vs;
+    Src src = fetch_src();                                  // trip 0's depths
+    Samp q[NS];
+    v4f nd[NS];
 #pragma unroll
-        for (int k = 0; k < NS; ++k) q[k] = prep(d[k], uu[k], vv[k], in[k]);
-        float4 nd[NS];
+    for (int k = 0; k < NS; ++k) q[k] = prep(src.d[k], src.uu[k], src.vv[k]);
 #pragma unroll
-        for (int k = 0; k < NS; ++k) nd[k] = nmap_t[(size_t)q[k].vt * cam.W + q[k].ut];
+    for (int k = 0; k < NS; ++k) nd[k] = nmap_g[pm_index(q[k].ut, q[k].vt, w4)];      // trip 0's gathers
+    int vs_cur = vs_first, vs_next = vs;                    // row of the first sample of the trip in q / of the trip in src
+    src = fetch_src();                                      // trip 1's depths
+    while (vs_cur < Hs) {                                   // the trip in q holds at least one sample
+        Samp qn[NS];
+        v4f ndn[NS];
 #pragma unroll
-        for (int k = 0; k < NS; ++k) accum(q[k], nd[k]);
+        for (int k = 0; k < NS; ++k) qn[k] = prep(src.d[k], src.uu[k], src.vv[k]);
+#pragma unroll
+        for (int k = 0; k < NS; ++k) ndn[k] = nmap_g[pm_index(qn[k].ut, qn[k].vt, w4)];     // next trip's gathers
+        vs_cur = vs_next;
+        vs_next = vs;
+        src = fetch_src();                                  // the depths of the trip after the next
+#pragma unroll
+        for (int k = 0; k < NS; ++k) accum(q[k], nd[k]);    // this trip's gathers were issued a trip ago
+#pragma unroll
+        for (int k = 0; k < NS; ++k) { q[k] = qn[k]; nd[k] = ndn[k]; }
     }
     if (stamp) stamp[0] = wall_clock64();
     // Wave reduction of the 30 sums.  A shuffle tree per sum is 30 x 6 dependent 64-bit shuffles (6.6 us measured, a third of
@@ -253,11 +308,11 @@ __device__ __forceinline__ void icp_accumulate(const Cam &cam, const IcpRun *__r
     r[6] = (float)state->T[8]; r[7] = (float)state->T[9]; r[8] = (float)state->T[10]; t[2] = (float)state->T[11];
     const float sc = (float)state->scale;                  // the caller's scale, or the running estimate of a Sim(3) run
     if (run->est_scale)
-        icp_accumulate_core<true>(cam, run->depth_src, run->nmap_tgt, sc, run->mind, run->maxd, run->md2, run->stride, run->Ws, run->Hs,
-                                  r, t, (int)blockIdx.x, (int)gridDim.x, sm, sm_out);
+        icp_accumulate_core<true, false>(cam, run->depth_src, run->nmap_tgt, sc, run->mind, run->maxd, run->md2, run->stride, run->Ws, run->Hs,
+                                  r, t, (int)blockIdx.x, (int)gridDim.x, run->src_pm, sm, sm_out);
     else
-        icp_accumulate_core<false>(cam, run->depth_src, run->nmap_tgt, sc, run->mind, run->maxd, run->md2, run->stride, run->Ws, run->Hs,
-                                   r, t, (int)blockIdx.x, (int)gridDim.x, sm, sm_out);
+        icp_accumulate_core<false, false>(cam, run->depth_src, run->nmap_tgt, sc, run->mind, run->maxd, run->md2, run->stride, run->Ws, run->Hs,
+                                   r, t, (int)blockIdx.x, (int)gridDim.x, run->src_pm, sm, sm_out);
 }
 
 // 1/x and 1/sqrt(x) to ~1e-16 relative: hardware seed + two Newton steps (no IEEE division / square-root sequence)
@@ -751,51 +806,178 @@ __device__ __forceinline__ size_t icp_sync_line(int pair, int rows) {        // 
 // SCALE_OK: the launch may hold levels that estimate the source depth's scale (Sim(3)).  The common instantiation (false) carries
 // neither the scale column's sums nor the 7-unknown solver: 256 registers instead of 512, i.e. TWO workgroups per CU instead of one
 // -- twice the pairs in flight (a waiting member holds its slot).
-template <bool SCALE_OK>
+// TWO SLOTS PER WORKGROUP (round 4).  The trace of a 512-pair launch (tools/bench_icp.py, TL3D_ICP_TRACE) showed a pass of a pair at
+// ~21 us of which a member accumulated for 9 and then sat out 10-12: the stragglers' arrivals, the last arriver's sum + solve + pose
+// update (7 us on one wave) and the poll.  A workgroup therefore holds two (pair, member) slots and runs whichever has its pose:
+// while slot A's pair is being solved, slot B accumulates.  Nothing blocks on ONE slot: a workgroup with a ready slot runs it, a
+// workgroup with none polls both generation lines in turn -- so every pair whose tickets are all handed out still completes whatever
+// the other slots of its workgroups hold (the argument above, per slot), and the slots it frees take the next tickets.  The second
+// slot only takes a ticket once every workgroup of the grid has had the chance of a first one (tickets handed out >= gridDim.x): a
+// launch with fewer slots than the chip holds workgroups spreads over all CUs as before.
+// TAB: the pixel-ray factors of the W columns and H rows sit in (dynamic) LDS, filled once per workgroup (icp_accumulate_core);
+// frames too large for that (W + H > ICP_RAY_TAB_MAX) run the instantiation that divides.
+constexpr int ICP_RAY_TAB_MAX = 12288;                     // floats: 48 KB
+enum { ICP_PH_NEED = 0, ICP_PH_INIT = 1, ICP_PH_READY = 2, ICP_PH_WAITING = 3, ICP_PH_EMPTY = 4 };
+struct IcpSlot {                                           // LDS; written by thread 0 only, read by all after a barrier
+    int phase, ticket, pair, member;
+    int lv, it, done, over, failed_run, final_pass;
+    unsigned gen, polls;
+    unsigned long long wait_t0;
+};
+template <bool SCALE_OK, bool TAB>
 __global__ __launch_bounds__(256, SCALE_OK ? 1 : 2) void icp_batch_kernel(Cam cam, IcpBatchArgs a) {
     __shared__ double sm[8][ICP_SLAB];
     __shared__ double tot[ICP_SLAB];
-    __shared__ float sT[13];                               // the pose as 12 floats + the source depth's scale
-    __shared__ int s_flag[4];                              // [0] ticket, [1] last arriver, [2] generation word seen, [3] wait failed
+    __shared__ float sT[2][16];                            // per slot: the pose as 12 floats + the source depth's scale
+    __shared__ IcpSlot sl[2];
+    __shared__ int s_flag[4];                              // [1] last arriver, [3] leave the launch (a wait timed out)
+    extern __shared__ float ray_tab_lds[];                 // TAB: [W] x factors, then [H] y factors
+    const float *ray_tab = ray_tab_lds;
     const int tid = threadIdx.x;
-    for (;;) {                                             // one (pair, member) slot per trip
-    if (tid == 0) s_flag[0] = (int)__hip_atomic_fetch_add(a.ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (TAB) {
+        for (int i = tid; i < cam.W; i += 256) ray_tab_lds[i] = ((float)i - cam.cx) / cam.fx;
+        for (int i = tid; i < cam.H; i += 256) ray_tab_lds[cam.W + i] = ((float)i - cam.cy) / cam.fy;
+    }
+    if (tid == 0) {
+        sl[0].phase = ICP_PH_NEED;
+        sl[1].phase = ICP_PH_NEED;
+        s_flag[3] = 0;
+    }
     __syncthreads();
-    const int ticket = s_flag[0];
-    const int pair = ticket / a.members, member = ticket - pair * a.members;
-    if (pair >= a.n_pairs) return;                         // every slot has been handed out
-    const IcpBatchPair pr = a.pairs[pair];
-    IcpState *st = a.states + pair;
-    unsigned *stage = a.stage ? a.stage + (size_t)ticket * 4 : nullptr;      // experiments: how far this workgroup got
-    if (stage && tid == 0) { stage[0] = 1u; stage[1] = (unsigned)blockIdx.x; stage[3] = __builtin_amdgcn_s_getreg((4 << 11) | (0 << 6) | 20); }
-    unsigned *arrive = a.sync + icp_sync_line(pair, a.sync_rows);
-    unsigned *genl = a.sync + (size_t)64 * a.sync_rows * 16 + icp_sync_line(pair, a.sync_rows);
-    double *slab = a.slab + (size_t)pair * a.members * ICP_SLAB;
-    unsigned gen = 0;
-    int failed_run = 0;                                    // a pass of this pair found the system singular (status 2)
-    unsigned long long *dbg = (a.dbg && pair == 0 && tid == 0) ? a.dbg + (size_t)member * 16 * 8 : nullptr;
-#define ICP_STAMP(k_) do { if (dbg && gen < 16u) dbg[gen * 8 + (k_)] = wall_clock64(); } while (0)
-    if (tid < 12) sT[tid] = (float)st->T[tid];             // the initial pose and scale: uploaded before the launch
-    if (tid == 12) sT[12] = (float)st->scale;
-    __syncthreads();
-    for (int lv = 0; lv < a.n_levels; ++lv) {
+    const size_t gen_base = (size_t)64 * a.sync_rows * 16;
+    // what the pair of a pass just completed goes on with, from the generation word (thread 0)
+    auto advance = [&](int s, unsigned word) {
+        IcpSlot &S = sl[s];
+        S.gen += 1u;
+        S.done = (int)(word & 1u);
+        S.over = (int)((word >> 1) & 1u);
+        S.failed_run = (int)((word >> 2) & 1u);
+        if (S.final_pass) {
+            if (S.over || S.lv + 1 >= a.n_levels) {
+                S.phase = ICP_PH_NEED;                     // the pair is through: the slot takes the next ticket
+            } else {
+                S.lv += 1; S.it = 0; S.done = 0; S.over = 0;
+                S.phase = ICP_PH_READY;
+            }
+        } else {
+            S.it += 1;
+            S.phase = ICP_PH_READY;
+        }
+    };
+    for (;;) {
+        // ---- tickets and initial poses ---------------------------------------------------------------------------------------
+        if (tid == 0) {
+            for (int s = 0; s < 2; ++s) {
+                if (sl[s].phase != ICP_PH_NEED) continue;
+                if (s == 1 && __hip_atomic_load(a.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) continue;
+                const int ticket = (int)__hip_atomic_fetch_add(a.ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int pair = ticket / a.members;
+                if (pair >= a.n_pairs) { sl[s].phase = ICP_PH_EMPTY; continue; }     // every slot has been handed out
+                IcpSlot &S = sl[s];
+                S.phase = ICP_PH_INIT; S.ticket = ticket; S.pair = pair; S.member = ticket - pair * a.members;
+                S.lv = 0; S.it = 0; S.done = 0; S.over = 0; S.failed_run = 0; S.final_pass = 0; S.gen = 0u; S.polls = 0u; S.wait_t0 = 0ull;
+                if (a.stage) { unsigned *stage = a.stage + (size_t)ticket * 4; stage[0] = 1u; stage[1] = (unsigned)blockIdx.x; stage[3] = __builtin_amdgcn_s_getreg((4 << 11) | (0 << 6) | 20); }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            if (sl[s].phase == ICP_PH_INIT) {              // the initial pose and scale: uploaded before the launch
+                const IcpState *st0 = a.states + sl[s].pair;
+                if (tid < 12) sT[s][tid] = (float)st0->T[tid];
+                if (tid == 12) sT[s][12] = (float)st0->scale;
+            }
+        __syncthreads();
+        if (tid == 0)
+            for (int s = 0; s < 2; ++s)
+                if (sl[s].phase == ICP_PH_INIT) sl[s].phase = ICP_PH_READY;
+        __syncthreads();
+        const int ph0 = sl[0].phase, ph1 = sl[1].phase;
+        if (ph0 == ICP_PH_EMPTY && ph1 == ICP_PH_EMPTY) return;
+        if ((ph0 == ICP_PH_NEED && ph1 == ICP_PH_EMPTY) || (ph0 == ICP_PH_EMPTY && ph1 == ICP_PH_NEED)) {
+            // (slot 1 still waiting for the grid's first tickets while slot 0 has run out: only with fewer slots than workgroups)
+            if (ph1 == ICP_PH_NEED && __hip_atomic_load(a.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) return;
+            continue;
+        }
+        int run = -1;
+        if (ph0 == ICP_PH_READY && (ph1 != ICP_PH_READY || sl[0].ticket < sl[1].ticket)) run = 0;
+        else if (ph1 == ICP_PH_READY) run = 1;
+        if (run < 0) {
+            // ---- no slot has its pose: wave 0 polls the generation lines of the waiting ones ----------------------------------
+            // One wave instruction per line (14 lanes, one 64-B request) returns the flags and the pose together.  Polling is a
+            // read-modify-write atomic, which executes at the memory side: polls by agent-scope (sc1) LOADS were seen to return a
+            // word their XCD had cached before the store for seconds, whatever the allocation flags.
+            if (tid < 64) {
+                bool got = false;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    if (sl[s].phase != ICP_PH_WAITING) continue;
+                    unsigned *genl = a.sync + gen_base + icp_sync_line(sl[s].pair, a.sync_rows);
+                    unsigned w = 0;
+                    if (tid < 14) w = __hip_atomic_fetch_add(genl + tid, (unsigned)a.zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned word = __builtin_amdgcn_readfirstlane(w);
+                    if ((word >> 3) != sl[s].gen) {
+                        if (tid >= 1 && tid <= 13) sT[s][tid - 1] = __uint_as_float(w);
+                        if (tid == 0) {
+                            if (a.dbg && sl[s].pair == 0 && sl[s].gen < 16u) a.dbg[((size_t)sl[s].member * 16 + sl[s].gen) * 8 + 6] = wall_clock64();
+                            advance(s, word);
+                        }
+                        got = true;
+                    } else if (tid == 0) {
+                        const unsigned polls = ++sl[s].polls;
+                        if ((polls & 63u) == 0u &&
+                            (wall_clock64() - sl[s].wait_t0 > ICP_WAIT_LIMIT_TICKS || __hip_atomic_load(a.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                            if (__hip_atomic_exchange(a.ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                                unsigned *arrive = a.sync + icp_sync_line(sl[s].pair, a.sync_rows);
+                                a.ctl[4] = (unsigned)sl[s].pair; a.ctl[5] = (unsigned)sl[s].member; a.ctl[6] = sl[s].gen; a.ctl[7] = polls;      // the first time-out, for the host's message
+                                a.ctl[8] = __hip_atomic_fetch_add(arrive, (unsigned)a.zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                a.ctl[9] = word;
+                                a.ctl[10] = (unsigned)sl[s].lv; a.ctl[11] = (unsigned)sl[s].it;
+                            }
+                            s_flag[3] = 1;
+                        }
+                    }
+                }
+                if (!got) __builtin_amdgcn_s_sleep(16);    // polls of one line from a hundred CUs at full rate saturate its channel and starve the arrivals
+            }
+            __syncthreads();
+            if (s_flag[3]) return;                         // a wait timed out: the error word is set, the host reports it
+            continue;
+        }
+        // ---- one pass of slot `run` ----------------------------------------------------------------------------------------------
+        const int pair = sl[run].pair, member = sl[run].member, lv = sl[run].lv, it = sl[run].it;
+        const unsigned gen = sl[run].gen;
+        const int failed_run = sl[run].failed_run;
+        const IcpBatchPair pr = a.pairs[pair];
+        IcpState *st = a.states + pair;
         const IcpLevel L = a.lv[lv];
-        int done = 0, over = 0;
-        for (int it = 0;; ++it) {
-            const int final_pass = (done || it >= L.iters);
-            ICP_STAMP(0);
+        const int done = sl[run].done;
+        const int final_pass = (done || it >= L.iters);
+        unsigned *stage = a.stage ? a.stage + (size_t)sl[run].ticket * 4 : nullptr;      // experiments: how far this slot got
+        unsigned *arrive = a.sync + icp_sync_line(pair, a.sync_rows);
+        unsigned *genl = a.sync + gen_base + icp_sync_line(pair, a.sync_rows);
+        double *slab = a.slab + (size_t)pair * a.members * ICP_SLAB;
+        unsigned long long *dbg = (a.dbg && pair == 0 && tid == 0) ? a.dbg + (size_t)member * 16 * 8 : nullptr;
+#define ICP_STAMP(k_) do { if (dbg && gen < 16u) dbg[gen * 8 + (k_)] = wall_clock64(); } while (0)
+        ICP_STAMP(0);
+        {
+            // the pose is the same in every lane: scalar registers (an LDS read lands in vector registers, twelve of them, live
+            // through the whole accumulation)
+            auto uni = [](float x) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(x))); };
+            const float *P = sT[run];
             float r[9], t[3];
-            r[0] = sT[0]; r[1] = sT[1]; r[2] = sT[2];  t[0] = sT[3];
-            r[3] = sT[4]; r[4] = sT[5]; r[5] = sT[6];  t[1] = sT[7];
-            r[6] = sT[8]; r[7] = sT[9]; r[8] = sT[10]; t[2] = sT[11];
+            r[0] = uni(P[0]); r[1] = uni(P[1]); r[2] = uni(P[2]);  t[0] = uni(P[3]);
+            r[3] = uni(P[4]); r[4] = uni(P[5]); r[5] = uni(P[6]);  t[1] = uni(P[7]);
+            r[6] = uni(P[8]); r[7] = uni(P[9]); r[8] = uni(P[10]); t[2] = uni(P[11]);
+            const float sc_u = uni(P[12]);
             ICP_STAMP(1);
             const int est = SCALE_OK ? (final_pass ? 0 : L.est_scale) : 0;
             if (est)
-                icp_accumulate_core<true>(cam, pr.depth_src, pr.nmap_tgt, sT[12], a.mind, a.maxd, L.md2, L.stride, L.Ws, L.Hs, r, t, member, a.members, sm, tot,
-                                          (dbg && gen < 16u) ? dbg + gen * 8 + 3 : nullptr);
+                icp_accumulate_core<true, TAB>(cam, pr.depth_src, pr.nmap_tgt, sc_u, a.mind, a.maxd, L.md2, L.stride, L.Ws, L.Hs, r, t, member, a.members, pr.src_pm, sm, tot,
+                                               (dbg && gen < 16u) ? dbg + gen * 8 + 3 : nullptr, ray_tab);
             else
-                icp_accumulate_core<false>(cam, pr.depth_src, pr.nmap_tgt, sT[12], a.mind, a.maxd, L.md2, L.stride, L.Ws, L.Hs, r, t, member, a.members, sm, tot,
-                                           (dbg && gen < 16u) ? dbg + gen * 8 + 3 : nullptr);
+                icp_accumulate_core<false, TAB>(cam, pr.depth_src, pr.nmap_tgt, sc_u, a.mind, a.maxd, L.md2, L.stride, L.Ws, L.Hs, r, t, member, a.members, pr.src_pm, sm, tot,
+                                                (dbg && gen < 16u) ? dbg + gen * 8 + 3 : nullptr, ray_tab);
             ICP_STAMP(2);
             if (stage && tid == 0) stage[0] = 2u + 16u * gen;
             if (tid < ICP_SLAB) {
@@ -812,13 +994,14 @@ __global__ __launch_bounds__(256, SCALE_OK ? 1 : 2) void icp_batch_kernel(Cam ca
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 s_flag[1] = last;
+                sl[run].final_pass = final_pass;
+                if (!last) { sl[run].phase = ICP_PH_WAITING; sl[run].polls = 0u; sl[run].wait_t0 = wall_clock64(); }
                 if (dbg && gen < 16u) dbg[gen * 8 + 7] = (unsigned long long)last;
             }
             ICP_STAMP(5);
             __syncthreads();
-            const int last = s_flag[1];
-            if (last) {
-                const int fin = icp_finish(slab, a.members, st, L.damping, L.eps, L.eig_rel, final_pass, sm, tot, est, sT, it);
+            if (s_flag[1]) {                               // the last arriver: sum, solve, new pose, publish
+                const int fin = icp_finish(slab, a.members, st, L.damping, L.eps, L.eig_rel, final_pass, sm, tot, est, sT[run], it);
                 if (tid < 64) {                            // wave 0 publishes
                     // thread 0 may just have written the new pose to sT: make that visible to lanes 1..12 of this wave
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -827,7 +1010,7 @@ __global__ __launch_bounds__(256, SCALE_OK ? 1 : 2) void icp_batch_kernel(Cam ca
                     // pose words and the arrival counter of the next pass: one instruction, issued before the state stores have drained
                     // (returning forms: their data comes back only after the memory side has performed them)
                     unsigned old = 0;
-                    if (tid >= 1 && tid <= 13) old = __hip_atomic_exchange(genl + tid, __float_as_uint(sT[tid - 1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (tid >= 1 && tid <= 13) old = __hip_atomic_exchange(genl + tid, __float_as_uint(sT[run][tid - 1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (tid == 14) old = __hip_atomic_exchange(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     asm volatile("" ::"v"(old));
                     unsigned word = 0;
@@ -845,72 +1028,43 @@ __global__ __launch_bounds__(256, SCALE_OK ? 1 : 2) void icp_batch_kernel(Cam ca
                             }
                         }
                         word = ((gen + 1u) << 3) | (fl_fail ? 4u : 0u) | (fl_over ? 2u : 0u) | (fl_done ? 1u : 0u);
-                        s_flag[2] = (int)word;
-                        s_flag[3] = 0;
                     }
                     // state stores written through, pose words and arrival counter in place: only then the flags word says so
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (tid == 0) (void)__hip_atomic_exchange(genl, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            } else if (tid < 64) {                         // wave 0 waits for the generation line
-                const unsigned long long t0 = wall_clock64();
-                unsigned w = 0, word = 0, polls = 0;
-                int failed = 0;
-                __builtin_amdgcn_s_sleep(100);             // the last arriver needs >= 3 us (sum, solve, update)
-                for (;;) {
-                    if (tid < 14) w = __hip_atomic_fetch_add(genl + tid, (unsigned)a.zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    word = __builtin_amdgcn_readfirstlane(w);
-                    if ((word >> 3) != gen) break;
-                    if ((++polls & 63u) == 0u &&
-                        (wall_clock64() - t0 > ICP_WAIT_LIMIT_TICKS || __hip_atomic_load(a.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
-                        failed = 1;
-                        break;
+                    if (tid == 0) {
+                        (void)__hip_atomic_exchange(genl, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (dbg && gen < 16u) dbg[gen * 8 + 6] = wall_clock64();
+                        advance(run, word);
                     }
-                    __builtin_amdgcn_s_sleep(16);
                 }
-                if (failed && tid == 0 && __hip_atomic_exchange(a.ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-                    a.ctl[4] = (unsigned)pair; a.ctl[5] = (unsigned)member; a.ctl[6] = gen; a.ctl[7] = polls;      // the first time-out, for the host's message
-                    a.ctl[8] = __hip_atomic_fetch_add(arrive, (unsigned)a.zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    a.ctl[9] = word;
-                    a.ctl[10] = (unsigned)lv; a.ctl[11] = (unsigned)it;
-                }
-                if (tid >= 1 && tid <= 13) sT[tid - 1] = __uint_as_float(w);
-                if (tid == 0) { s_flag[2] = (int)word; s_flag[3] = failed; }
             }
-            ICP_STAMP(6);
-            __syncthreads();
-            ++gen;
-            const int word = s_flag[2], failed = s_flag[3];
-            done = word & 1;
-            over = (word >> 1) & 1;
-            failed_run = (word >> 2) & 1;
-            __syncthreads();                               // s_flag is rewritten by the next pass
-            if (failed) return;                            // a wait timed out: the error word is set, the host reports it
-            if (final_pass) break;
         }
-        if (over) break;
-    }
 #undef ICP_STAMP
-    __syncthreads();                                       // shared state is rewritten by the next slot
+        __syncthreads();                                   // slot state and the shared scratch are rewritten by the next trip
     }
 }
 
 int launch_icp_batch(hipStream_t s, const Cam &cam, const IcpBatchArgs &a) {
     bool scale = false;
     for (int l = 0; l < a.n_levels; ++l) scale = scale || a.lv[l].est_scale != 0;
-    static int resident[2] = {0, 0};                       // workgroups the chip holds at once, per instantiation
-    if (!resident[scale]) {
+    const bool tab = cam.W + cam.H <= ICP_RAY_TAB_MAX;
+    const size_t lds = tab ? (size_t)(cam.W + cam.H) * sizeof(float) : 0;
+    using Kern = void (*)(Cam, IcpBatchArgs);
+    const Kern kern = scale ? (tab ? (Kern)icp_batch_kernel<true, true> : (Kern)icp_batch_kernel<true, false>)
+                            : (tab ? (Kern)icp_batch_kernel<false, true> : (Kern)icp_batch_kernel<false, false>);
+    static int resident[2][2] = {{0, 0}, {0, 0}};          // workgroups the chip holds at once, per instantiation
+    static size_t resident_lds[2][2] = {{0, 0}, {0, 0}};   // ... for this much dynamic LDS
+    if (!resident[scale][tab] || resident_lds[scale][tab] != lds) {
         int dev = 0, cus = 0, per_cu = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-        const hipError_t e = scale ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, icp_batch_kernel<true>, 256, 0)
-                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, icp_batch_kernel<false>, 256, 0);
+        const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds);
         if (e != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 1; }
-        resident[scale] = per_cu * cus;
+        resident[scale][tab] = per_cu * cus;
+        resident_lds[scale][tab] = lds;
     }
     const unsigned slots = (unsigned)a.n_pairs * (unsigned)a.members;
-    const unsigned grid = slots < (unsigned)resident[scale] ? slots : (unsigned)resident[scale];
-    if (scale) hipLaunchKernelGGL(icp_batch_kernel<true>, dim3(grid), dim3(256), 0, s, cam, a);
-    else hipLaunchKernelGGL(icp_batch_kernel<false>, dim3(grid), dim3(256), 0, s, cam, a);
+    const unsigned grid = slots < (unsigned)resident[scale][tab] ? slots : (unsigned)resident[scale][tab];
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, cam, a);
     TL3D_HIP(hipGetLastError());
     return TL3D_OK;
 }
@@ -923,9 +1077,9 @@ int launch_normals(hipStream_t s, const Cam &cam, const float *depth, float scal
     if (radius >= 1) {
         hipLaunchKernelGGL(smooth_depth_kernel, grid, dim3(256), 0, s, cam, depth, scale, mind, maxd, jump, radius, sdepth);
         TL3D_HIP(hipGetLastError());
-        hipLaunchKernelGGL(normals_kernel, grid, dim3(256), 0, s, cam, sdepth, scale, mind, maxd, jump, radius, nmap);
+        hipLaunchKernelGGL(normals_kernel<true>, grid, dim3(256), 0, s, cam, sdepth, scale, mind, maxd, jump, radius, nmap);
     } else {
-        hipLaunchKernelGGL(normals_kernel, grid, dim3(256), 0, s, cam, depth, scale, mind, maxd, jump, 1, nmap);
+        hipLaunchKernelGGL(normals_kernel<false>, grid, dim3(256), 0, s, cam, depth, scale, mind, maxd, jump, 1, nmap);
     }
     TL3D_HIP(hipGetLastError());
     return TL3D_OK;

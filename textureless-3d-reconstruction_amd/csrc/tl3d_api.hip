@@ -429,7 +429,8 @@ int tl3d_create(const tl3d_config *cfg, int device, tl3d_ctx **out) {
     if (!ctx->slots) { delete ctx; return set_err(TL3D_E_NOMEM, "host allocation failed"); }
     {
         const size_t npx = (size_t)cfg->width * cfg->height;
-        const size_t bytes[5] = {npx * sizeof(float), npx * sizeof(uint16_t), npx * 3, npx * sizeof(float4), npx * sizeof(float)};
+        const size_t npm = pm_pixels(cfg->width, cfg->height);      // normal maps and averaged depth: phase-major rows of 4 * ceil(W / 4) entries
+        const size_t bytes[5] = {npx * sizeof(float), npx * sizeof(uint16_t), npx * 3, npm * sizeof(float4), npm * sizeof(float)};
         FramePool *pools[5] = {&ctx->pool_depth, &ctx->pool_u16, &ctx->pool_bgr, &ctx->pool_nmap, &ctx->pool_sdepth};
         for (int k = 0; k < 5; ++k) {
             FramePool &fp = *pools[k];
@@ -1222,8 +1223,17 @@ int tl3d_download_normals(tl3d_ctx *ctx, int slot, float *out) {
     REQUIRE(out != nullptr, TL3D_E_INVALID, "null out");
     REQUIRE(ctx->slots[slot].has_normals, TL3D_E_STATE, "slot %d has no normal map (call tl3d_build_normals)", slot);
     TL3D_HIP(hipSetDevice(ctx->device));
-    TL3D_HIP(hipMemcpyAsync(out, ctx->slots[slot].nmap, (size_t)ctx->cam.W * ctx->cam.H * sizeof(float4), hipMemcpyDefault, ctx->stream));
-    TL3D_HIP(hipStreamSynchronize(ctx->stream));
+    // the map lives in phase-major rows (tl3d_internal.h: pm_index); the caller gets it row-major
+    const int W = ctx->cam.W, H = ctx->cam.H, w4 = pm_w4(W);
+    float4 *tmp = (float4 *)malloc(pm_pixels(W, H) * sizeof(float4));
+    REQUIRE(tmp != nullptr, TL3D_E_NOMEM, "host allocation failed");
+    hipError_t e = hipMemcpyAsync(tmp, ctx->slots[slot].nmap, pm_pixels(W, H) * sizeof(float4), hipMemcpyDefault, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { free(tmp); TL3D_HIP(e); }
+    float4 *o4 = (float4 *)out;
+    for (int v = 0; v < H; ++v)
+        for (int u = 0; u < W; ++u) o4[(size_t)v * W + u] = tmp[pm_index(u, v, w4)];
+    free(tmp);
     return TL3D_OK;
 }
 
@@ -1307,6 +1317,7 @@ int tl3d_icp_enqueue(tl3d_ctx *ctx, int lane, int slot_src, double scale_src, in
     IcpRun *r = ln.run_host;
     r->depth_src = ss.smooth_radius > 0 ? ss.sdepth : ss.depth;      // the window-averaged depth when the slot's normals were built smoothed
     r->nmap_tgt = st.nmap;
+    r->src_pm = ss.smooth_radius > 0 ? 1 : 0;
     r->scale = (float)scale_src;
     r->md2 = (float)prm->max_dist * (float)prm->max_dist;
     r->mind = (float)ctx->cfg.min_depth;
@@ -1531,7 +1542,7 @@ int tl3d_icp_batch_enqueue(tl3d_ctx *ctx, const tl3d_icp_pair *pairs, int n_pair
         b.pairs_host[i].depth_src = ss.smooth_radius > 0 ? ss.sdepth : ss.depth;
         b.pairs_host[i].nmap_tgt = st.nmap;
         b.pairs_host[i].scale = (float)pairs[i].scale_src;
-        b.pairs_host[i].pad = 0;
+        b.pairs_host[i].src_pm = ss.smooth_radius > 0 ? 1 : 0;
         IcpState &h = b.states_host[i];
         memset(&h, 0, sizeof(h));
         memcpy(h.T, pairs[i].T_init, sizeof(h.T));

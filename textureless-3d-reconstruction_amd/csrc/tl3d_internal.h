@@ -16,6 +16,17 @@ struct Cam {
     double fxd, fyd, cxd, cyd;   // fp64 path (reference-exact back-projection)
 };
 
+// PHASE-MAJOR ROWS (normal maps and window-averaged depth: what the registration gathers from).  Pixel u of a row sits at
+// (u & 3) * W4 + (u >> 2), W4 = ceil(W / 4): the row is kept as its four pixel phases one after the other.  A registration level
+// samples every stride-th pixel (stride 4 and 2 in the pipeline's schedule) and the projected targets of neighbouring samples keep
+// the stride over long runs, so in a row-major map every sample pays a 64-B sector of its own for a 16-B entry (8.3 MB fetched
+// per 1080p pair-iteration at stride 4 for 2.1 MB used); here samples 4 px apart are neighbours in memory: four entries per
+// sector.  Stride-1 accesses cost the same sectors as before (64 consecutive pixels = four runs of 16 entries).  Same values,
+// another address: every result is bit for bit what the row-major map gave.
+__host__ __device__ __forceinline__ int pm_w4(int W) { return (W + 3) >> 2; }
+__host__ __device__ __forceinline__ size_t pm_pixels(int W, int H) { return (size_t)4 * pm_w4(W) * H; }
+__host__ __device__ __forceinline__ size_t pm_index(int u, int v, int w4) { return (size_t)v * (size_t)(4 * w4) + (size_t)((u & 3) * w4 + (u >> 2)); }
+
 struct Grid {
     int nx, ny, nz;              // voxels
     int nbx, nby, nbz;           // bricks (8^3 voxels)
@@ -83,6 +94,7 @@ struct IcpRun {                  // per-run arguments of the ICP kernels, read f
     float scale, md2, mind, maxd;
     int stride, Ws, Hs, est_scale;   // est_scale: the source depth's scale is a 7th unknown (Sim(3))
     double damping, eps, eig_rel;
+    int src_pm, pad;             // src_pm: depth_src is a window-averaged depth in phase-major rows (pm_index), else the frame's row-major image
 };
 
 // Batched registration (icp_batch_kernel): every pair of a batch runs ALL its levels and iterations inside one launch.
@@ -92,7 +104,7 @@ constexpr int ICP_BATCH_SAMPLES_PER_MEMBER = 4096;    // 32 workgroups per pair 
                                                       // (512 in flight) a 512-pair launch runs at 3.4-3.6 us per pair-iteration whatever the
                                                       // number of members (4 ... 32: the memory system's rate of scattered reads bounds it), and
                                                       // a pair registered alone takes 101 / 54 / 34 / 24 us per iteration with 4 / 8 / 16 / 32
-struct IcpBatchPair { const float *depth_src; const float4 *nmap_tgt; float scale; int pad; };
+struct IcpBatchPair { const float *depth_src; const float4 *nmap_tgt; float scale; int src_pm; };    // src_pm: as IcpRun::src_pm
 struct IcpLevel { float md2; int stride, Ws, Hs, iters, est_scale; double damping, eps, eig_rel; };
 struct IcpBatchArgs {
     const IcpBatchPair *pairs;   // [n_pairs]
@@ -125,8 +137,8 @@ struct Slot {
     uint16_t *depth_u16 = nullptr;   // [H][W] millimetres, kept when the frame was uploaded as TL3D_DEPTH_U16_MM (TSDF gathers read it)
     bool has_u16 = false;
     uint8_t *bgr = nullptr;      // [H][W][3]
-    float4 *nmap = nullptr;      // [H][W] (nx,ny,nz,d), lazily allocated
-    float *sdepth = nullptr;     // [H][W] window-averaged depth the normal map was taken from (tl3d_set_normal_smoothing > 0); registration reads it as the source depth too
+    float4 *nmap = nullptr;      // [H][4 * W4] (nx,ny,nz,d) in phase-major rows (pm_index), lazily allocated
+    float *sdepth = nullptr;     // [H][4 * W4], phase-major rows: window-averaged depth the normal map was taken from (tl3d_set_normal_smoothing > 0); registration reads it as the source depth too
     int smooth_radius = 0;       // radius sdepth / nmap were built with (0: nmap from the depth image itself)
     hipEvent_t ev_upload = nullptr;   // recorded on the main stream after the slot's last upload
     hipEvent_t ev_normals = nullptr;  // recorded on the main stream after the slot's normal map was built
