@@ -806,17 +806,25 @@ __device__ __forceinline__ size_t icp_sync_line(int pair, int rows) {        // 
 // SCALE_OK: the launch may hold levels that estimate the source depth's scale (Sim(3)).  The common instantiation (false) carries
 // neither the scale column's sums nor the 7-unknown solver: 256 registers instead of 512, i.e. TWO workgroups per CU instead of one
 // -- twice the pairs in flight (a waiting member holds its slot).
-// TWO SLOTS PER WORKGROUP (round 4).  The trace of a 512-pair launch (tools/bench_icp.py, TL3D_ICP_TRACE) showed a pass of a pair at
-// ~21 us of which a member accumulated for 9 and then sat out 10-12: the stragglers' arrivals, the last arriver's sum + solve + pose
-// update (7 us on one wave) and the poll.  A workgroup therefore holds two (pair, member) slots and runs whichever has its pose:
-// while slot A's pair is being solved, slot B accumulates.  Nothing blocks on ONE slot: a workgroup with a ready slot runs it, a
-// workgroup with none polls both generation lines in turn -- so every pair whose tickets are all handed out still completes whatever
-// the other slots of its workgroups hold (the argument above, per slot), and the slots it frees take the next tickets.  The second
-// slot only takes a ticket once every workgroup of the grid has had the chance of a first one (tickets handed out >= gridDim.x): a
-// launch with fewer slots than the chip holds workgroups spreads over all CUs as before.
+// SEVERAL SLOTS PER WORKGROUP (round 4; ICP_SLOTS).  The trace of a 512-pair launch (tools/bench_icp.py, TL3D_ICP_TRACE) showed a pass
+// of a pair at ~21 us of which a member accumulated for 9 and then sat out 10-12: the stragglers' arrivals, the last arriver's sum +
+// solve + pose update (5-7 us on one wave) and the poll.  A workgroup therefore holds several (pair, member) slots and runs whichever
+// has its pose, the oldest first: while slot A's pair is being solved, slot B accumulates.  With two slots a pair's pass stretches to
+// 33 us (a member's workgroup may be busy with its other slot for a pass when the pose arrives) and the workgroups still idle a
+// third of the time; with four they were busy and the launch no faster: what remained was the cost per member and pass, and the
+// answer to that fewer members per pair (tl3d_internal.h: ICP_BATCH_SAMPLES_PER_MEMBER).  Two slots it is.
+// Nothing blocks on ONE slot: a workgroup with a ready slot runs it, a workgroup with none polls the generation lines of all its
+// waiting slots in turn -- so every pair whose tickets are all handed out still completes whatever the other slots of its workgroups
+// hold (the argument above, per slot), and the slots it frees take the next tickets.  Slot s only takes a ticket once every workgroup
+// of the grid has had the chance of s earlier ones (tickets handed out >= s * gridDim.x): a launch with fewer slots than the chip
+// holds workgroups spreads over all CUs as before.
 // TAB: the pixel-ray factors of the W columns and H rows sit in (dynamic) LDS, filled once per workgroup (icp_accumulate_core);
 // frames too large for that (W + H > ICP_RAY_TAB_MAX) run the instantiation that divides.
 constexpr int ICP_RAY_TAB_MAX = 12288;                     // floats: 48 KB
+#ifndef TL3D_ICP_SLOTS
+#define TL3D_ICP_SLOTS 2
+#endif
+constexpr int ICP_SLOTS = TL3D_ICP_SLOTS;                  // (pair, member) slots a workgroup works on in turn
 enum { ICP_PH_NEED = 0, ICP_PH_INIT = 1, ICP_PH_READY = 2, ICP_PH_WAITING = 3, ICP_PH_EMPTY = 4 };
 struct IcpSlot {                                           // LDS; written by thread 0 only, read by all after a barrier
     int phase, ticket, pair, member;
@@ -828,8 +836,8 @@ template <bool SCALE_OK, bool TAB>
 __global__ __launch_bounds__(256, SCALE_OK ? 1 : 2) void icp_batch_kernel(Cam cam, IcpBatchArgs a) {
     __shared__ double sm[8][ICP_SLAB];
     __shared__ double tot[ICP_SLAB];
-    __shared__ float sT[2][16];                            // per slot: the pose as 12 floats + the source depth's scale
-    __shared__ IcpSlot sl[2];
+    __shared__ float sT[ICP_SLOTS][16];                    // per slot: the pose as 12 floats + the source depth's scale
+    __shared__ IcpSlot sl[ICP_SLOTS];
     __shared__ int s_flag[4];                              // [1] last arriver, [3] leave the launch (a wait timed out)
     extern __shared__ float ray_tab_lds[];                 // TAB: [W] x factors, then [H] y factors
     const float *ray_tab = ray_tab_lds;
@@ -839,8 +847,7 @@ __global__ __launch_bounds__(256, SCALE_OK ? 1 : 2) void icp_batch_kernel(Cam ca
         for (int i = tid; i < cam.H; i += 256) ray_tab_lds[cam.W + i] = ((float)i - cam.cy) / cam.fy;
     }
     if (tid == 0) {
-        sl[0].phase = ICP_PH_NEED;
-        sl[1].phase = ICP_PH_NEED;
+        for (int s = 0; s < ICP_SLOTS; ++s) sl[s].phase = ICP_PH_NEED;
         s_flag[3] = 0;
     }
     __syncthreads();
@@ -867,9 +874,9 @@ __global__ __launch_bounds__(256, SCALE_OK ? 1 : 2) void icp_batch_kernel(Cam ca
     for (;;) {
         // ---- tickets and initial poses ---------------------------------------------------------------------------------------
         if (tid == 0) {
-            for (int s = 0; s < 2; ++s) {
+            for (int s = 0; s < ICP_SLOTS; ++s) {
                 if (sl[s].phase != ICP_PH_NEED) continue;
-                if (s == 1 && __hip_atomic_load(a.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) continue;
+                if (s > 0 && __hip_atomic_load(a.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)s * gridDim.x) continue;
                 const int ticket = (int)__hip_atomic_fetch_add(a.ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const int pair = ticket / a.members;
                 if (pair >= a.n_pairs) { sl[s].phase = ICP_PH_EMPTY; continue; }     // every slot has been handed out
@@ -881,7 +888,7 @@ __global__ __launch_bounds__(256, SCALE_OK ? 1 : 2) void icp_batch_kernel(Cam ca
         }
         __syncthreads();
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < ICP_SLOTS; ++s)
             if (sl[s].phase == ICP_PH_INIT) {              // the initial pose and scale: uploaded before the launch
                 const IcpState *st0 = a.states + sl[s].pair;
                 if (tid < 12) sT[s][tid] = (float)st0->T[tid];
@@ -889,19 +896,19 @@ __global__ __launch_bounds__(256, SCALE_OK ? 1 : 2) void icp_batch_kernel(Cam ca
             }
         __syncthreads();
         if (tid == 0)
-            for (int s = 0; s < 2; ++s)
+            for (int s = 0; s < ICP_SLOTS; ++s)
                 if (sl[s].phase == ICP_PH_INIT) sl[s].phase = ICP_PH_READY;
         __syncthreads();
-        const int ph0 = sl[0].phase, ph1 = sl[1].phase;
-        if (ph0 == ICP_PH_EMPTY && ph1 == ICP_PH_EMPTY) return;
-        if ((ph0 == ICP_PH_NEED && ph1 == ICP_PH_EMPTY) || (ph0 == ICP_PH_EMPTY && ph1 == ICP_PH_NEED)) {
-            // (slot 1 still waiting for the grid's first tickets while slot 0 has run out: only with fewer slots than workgroups)
-            if (ph1 == ICP_PH_NEED && __hip_atomic_load(a.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) return;
-            continue;
+        int run = -1, n_wait = 0;
+#pragma unroll
+        for (int s = 0; s < ICP_SLOTS; ++s) {
+            const int ph = sl[s].phase;
+            if (ph == ICP_PH_READY && (run < 0 || sl[s].ticket < sl[run].ticket)) run = s;      // the oldest pair first
+            n_wait += (ph == ICP_PH_WAITING);
         }
-        int run = -1;
-        if (ph0 == ICP_PH_READY && (ph1 != ICP_PH_READY || sl[0].ticket < sl[1].ticket)) run = 0;
-        else if (ph1 == ICP_PH_READY) run = 1;
+        // Nothing in hand: slot 0, which takes a ticket whenever it needs one, is neither ready nor waiting, so it has found every
+        // ticket handed out -- and so would the later slots that have not tried yet.
+        if (run < 0 && n_wait == 0) return;
         if (run < 0) {
             // ---- no slot has its pose: wave 0 polls the generation lines of the waiting ones ----------------------------------
             // One wave instruction per line (14 lanes, one 64-B request) returns the flags and the pose together.  Polling is a
@@ -910,7 +917,7 @@ __global__ __launch_bounds__(256, SCALE_OK ? 1 : 2) void icp_batch_kernel(Cam ca
             if (tid < 64) {
                 bool got = false;
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
+                for (int s = 0; s < ICP_SLOTS; ++s) {
                     if (sl[s].phase != ICP_PH_WAITING) continue;
                     unsigned *genl = a.sync + gen_base + icp_sync_line(sl[s].pair, a.sync_rows);
                     unsigned w = 0;

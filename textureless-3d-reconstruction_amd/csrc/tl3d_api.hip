@@ -1517,7 +1517,7 @@ int tl3d_icp_batch_enqueue(tl3d_ctx *ctx, const tl3d_icp_pair *pairs, int n_pair
     }
     // workgroups per pair: a function of the level geometry only, so a pair's sums (and pose) do not depend on the batch it is in
     long long members = (ns_max + ICP_BATCH_SAMPLES_PER_MEMBER - 1) / ICP_BATCH_SAMPLES_PER_MEMBER;
-    if (members > ICP_BATCH_MAX_MEMBERS) members = ICP_BATCH_MAX_MEMBERS;
+    if (members > ICP_BATCH_MEMBERS_CAP) members = ICP_BATCH_MEMBERS_CAP;
 #ifdef TL3D_EXPERIMENTS
     if (const char *e = getenv("TL3D_ICP_MEMBERS")) {
         const long long m = atoll(e);

@@ -99,11 +99,15 @@ struct IcpRun {                  // per-run arguments of the ICP kernels, read f
 
 // Batched registration (icp_batch_kernel): every pair of a batch runs ALL its levels and iterations inside one launch.
 constexpr int ICP_MAX_LEVELS = 4;
-constexpr int ICP_BATCH_MAX_MEMBERS = 64;    // workgroups that share one pair
-constexpr int ICP_BATCH_SAMPLES_PER_MEMBER = 4096;    // 32 workgroups per pair of 1080p frames at stride 4.  With two workgroups per CU
-                                                      // (512 in flight) a 512-pair launch runs at 3.4-3.6 us per pair-iteration whatever the
-                                                      // number of members (4 ... 32: the memory system's rate of scattered reads bounds it), and
-                                                      // a pair registered alone takes 101 / 54 / 34 / 24 us per iteration with 4 / 8 / 16 / 32
+constexpr int ICP_BATCH_MAX_MEMBERS = 64;    // workgroups that may share one pair (what the buffers are sized for)
+// Samples per member and pass.  A member's pass costs ~4.5 us whatever it accumulates (wave + workgroup reduction, partial store,
+// arrival, barriers, poll) plus ~0.55 us per sample and thread; measured on 255 pairs of 1080p frames (tools/bench_icp.py, round 4,
+// two slots per workgroup): stride 4 at 32 / 16 / 8 members per pair 1.35 / 1.03 / 0.92 us per pair-iteration, the two-level
+// schedule 57 / 66 / 65 k pairs/s (45 k with the 64 members of round 3).  16 members at 1080p stride 4, at most 32: a pair
+// registered alone still spreads over 16-32 CUs.  A function of the level geometry only, never of the batch: a pair's sums (and
+// pose) do not depend on the batch it is in.
+constexpr int ICP_BATCH_SAMPLES_PER_MEMBER = 8192;
+constexpr int ICP_BATCH_MEMBERS_CAP = 32;
 struct IcpBatchPair { const float *depth_src; const float4 *nmap_tgt; float scale; int src_pm; };    // src_pm: as IcpRun::src_pm
 struct IcpLevel { float md2; int stride, Ws, Hs, iters, est_scale; double damping, eps, eig_rel; };
 struct IcpBatchArgs {
