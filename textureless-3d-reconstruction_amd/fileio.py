@@ -32,7 +32,7 @@ class DepthImageLoader:
         """
         filepath = Path(filepath)
         if filepath.suffix == ".npy":
-            return np.load(str(filepath)).astype(np.float32)
+            return np.load(str(filepath)).astype(np.float32, copy=False)
         if filepath.suffix == ".png":
             from PIL import Image
             try:
@@ -235,6 +235,48 @@ def read_image_bgr(path) -> Optional[np.ndarray]:
         return None
 
 
+_pil_cache_blocks = 0
+
+
+def keep_pil_blocks(n_images: int):
+    """Let Pillow keep the storage of `n_images` decoded 1080p-class images for re-use (Image.core.set_blocks_max; off by default).
+    Without it every decode maps ~8 MB afresh and unmaps it again: with a pool of decode threads that is a page-fault and mmap-lock
+    storm inside one process -- measured here on 8 cores, 1080x1920 JPEGs: 4 threads 75 frames/s without the cache (51 ms per
+    call against 12 ms alone), 260 frames/s with it.  Harmless where the hook does not exist."""
+    global _pil_cache_blocks
+    try:
+        from PIL import Image
+        want = max(int(n_images), 0) * 2                      # 16 MB blocks; an RGB 1080p image takes one, a 4K image three
+        if want > _pil_cache_blocks and want > Image.core.get_blocks_max():
+            Image.core.set_blocks_max(want)
+            _pil_cache_blocks = want
+    except Exception:
+        pass
+
+
+def read_npy_into(path, dst: np.ndarray) -> bool:
+    """An .npy file's payload straight into dst (same dtype, shape and C order; e.g. pinned staging) with ONE read(2) -- no
+    mapping of the file (2000 minor page faults per 1080p frame, on the process-wide mmap lock: 4 decode threads reached 400
+    frames/s through np.load(mmap_mode="r") + memmove and 1650 through this), no interpreter lock while the bytes move.
+    False when the file holds something else (the caller falls back to np.load)."""
+    fmt = np.lib.format
+    try:
+        with open(str(path), "rb") as f:
+            ver = fmt.read_magic(f)
+            if ver == (1, 0):
+                shape, fortran, dt = fmt.read_array_header_1_0(f)
+            elif ver == (2, 0):
+                shape, fortran, dt = fmt.read_array_header_2_0(f)
+            else:
+                return False
+            if fortran or dt != dst.dtype or tuple(shape) != dst.shape or dt.hasobject or not dst.flags["C_CONTIGUOUS"]:
+                return False
+            got = f.readinto(memoryview(dst).cast("B"))
+            return got == dst.nbytes
+    except (OSError, ValueError):
+        return False
+
+
 def copy_bytes(dst: np.ndarray, src, nbytes: int):
     """memcpy into a C-contiguous array without the interpreter lock (ctypes releases it around foreign calls): the
     decode workers of FramePrefetcher copy into their pinned staging buffers side by side."""
@@ -290,6 +332,7 @@ def load_data(rgb_folder, depth_folder, verbose: bool = True):
         return img, dfile, depth
 
     from concurrent.futures import ThreadPoolExecutor
+    keep_pil_blocks(2 * min(16, max(1, usable_cpus())))
     with ThreadPoolExecutor(max_workers=min(16, max(1, usable_cpus()))) as pool:
         decoded = pool.map(one, files)                 # results in file order: the messages and lists are the serial loop's
         for f, (img, dfile, depth) in zip(files, decoded):
@@ -335,39 +378,62 @@ class FramePrefetcher:
 
     def __init__(self, ctx, rgb_files, depth_files, n_staging: int = 0, workers: int = 0, raw_u16: bool = True):
         from concurrent.futures import ThreadPoolExecutor
-        from .fusion import PinnedArray
         assert len(rgb_files) == len(depth_files)
         self.ctx, self.rgb_files, self.depth_files = ctx, list(rgb_files), list(depth_files)
         self.raw_u16 = raw_u16
         h, w = ctx.height, ctx.width
-        # decode is the bottleneck of a file-fed run (JPEG ~10 ms, 16-bit PNG ~15 ms per 1080p frame and thread): one
-        # worker per granted CPU but two, as many staging buffers as can be in flight
+        # Decode is the bottleneck of a file-fed run (JPEG ~6 ms, .npy ~2 ms, 16-bit PNG ~10 ms per 1080p frame and thread): one
+        # worker per granted CPU but two.  Frames are handed on IN ORDER but decoded out of order, so a ring of workers + 2
+        # staging buffers left the workers idle 40 % of the time behind the slowest frame (7.9 of 14 busy, 930 frames/s; a ring of
+        # 2 x workers + 4: 13.5 busy, 1470 frames/s -- tools/bench_prefetch.py).  A staging buffer is page-locked memory of ONE kind
+        # (f32 depth, 16-bit depth, colour), taken from the process-wide cache when ring position b is first handed to a worker
+        # (by the iterating thread, whose current device is the context's): a data set of .npy depth never pays for the 16-bit
+        # ring, and the locking of position b runs beside the decodes of the positions before it.
         workers = int(workers) if workers else min(16, max(2, usable_cpus() - 2))
-        self.n_staging = max(2, int(n_staging) if n_staging else workers + 2)
-        self._f32 = [PinnedArray((h, w), np.float32) for _ in range(self.n_staging)]
-        self._u16 = [PinnedArray((h, w), np.uint16) for _ in range(self.n_staging)]
-        self._bgr = [PinnedArray((h, w, 3), np.uint8) for _ in range(self.n_staging)]
         self.workers = max(1, int(workers))
+        self.n_staging = max(2, int(n_staging) if n_staging else 2 * self.workers + 4)
+        self._shape = {"f32": ((h, w), np.float32), "u16": ((h, w), np.uint16), "bgr": ((h, w, 3), np.uint8)}
+        self._bufs = {k: [None] * self.n_staging for k in self._shape}
+        keep_pil_blocks(2 * self.workers)                   # a colour and a depth image per worker
         self._pool = ThreadPoolExecutor(max_workers=self.workers)
         self.decode_s = 0.0
 
+    def _ensure(self, i, b):
+        """the staging buffers frame i may need at ring position b (iterating thread, before the decode is submitted)"""
+        from .fusion import PinnedCache
+        suffix = Path(self.depth_files[i]).suffix
+        kinds = ["bgr"] if self.rgb_files[i] is not None else []
+        if suffix == ".npy":
+            kinds.append("f32")
+        elif suffix == ".png" and self.raw_u16:
+            kinds.append("u16")                             # (a PNG that is not 16-bit gray, or needs resizing, is rare: see _buf)
+        else:
+            kinds += ["f32", "u16"]
+        for k in kinds:
+            if self._bufs[k][b] is None:
+                self._bufs[k][b] = PinnedCache.take(*self._shape[k])
+
+    def _buf(self, kind, b) -> np.ndarray:
+        """staging buffer b of one kind (only the worker that holds ring position b touches entry b)"""
+        pa = self._bufs[kind][b]
+        if pa is None:                                      # a file that is not what its suffix promised
+            from .fusion import PinnedCache
+            pa = self._bufs[kind][b] = PinnedCache.take(*self._shape[kind])
+        return pa.array
+
     def _decode(self, i, b):
         """One frame into staging buffer b.  Everything bulky runs outside the interpreter lock: PIL's decoders release it,
-        the copies into pinned memory are ctypes memmoves, an .npy depth map is memory-mapped and copied once."""
+        the copies into pinned memory are ctypes memmoves, an .npy depth map is read straight into the staging buffer."""
         import time
         t0 = time.perf_counter()
         h, w = self.ctx.height, self.ctx.width
         bgr = None
-        if self.rgb_files[i] is not None and decode_bgr_into(self.rgb_files[i], self._bgr[b].array):
-            bgr = self._bgr[b].array
+        if self.rgb_files[i] is not None and decode_bgr_into(self.rgb_files[i], self._buf("bgr", b)):
+            bgr = self._buf("bgr", b)
         path = Path(self.depth_files[i])
         dst = None
-        if path.suffix == ".npy":
-            m = np.load(str(path), mmap_mode="r")
-            if m.dtype == np.float32 and m.shape == (h, w) and m.flags["C_CONTIGUOUS"]:
-                dst = self._f32[b].array
-                copy_bytes(dst, m, dst.nbytes)
-            del m
+        if path.suffix == ".npy" and read_npy_into(path, self._buf("f32", b)):
+            dst = self._buf("f32", b)
         if dst is None and path.suffix == ".png" and self.raw_u16:
             from PIL import Image
             try:
@@ -377,7 +443,7 @@ class FramePrefetcher:
                         rows = _pil_row_pointers(im, w, h, 2)
                         if rows is not None:
                             from . import _cabi as abi
-                            dst = self._u16[b].array
+                            dst = self._buf("u16", b)
                             abi.check(abi.load().tl3d_host_copy_rows(dst.ctypes.data, rows, h, 2 * w))
             except Exception:
                 dst = None
@@ -387,7 +453,7 @@ class FramePrefetcher:
                 raise IOError(f"cannot read depth {self.depth_files[i]}")
             if d.shape != (h, w):
                 d = resize_bilinear(d.astype(np.float32) / (1000.0 if d.dtype == np.uint16 else 1.0), w, h)
-            dst = self._u16[b].array if d.dtype == np.uint16 else self._f32[b].array
+            dst = self._buf("u16", b) if d.dtype == np.uint16 else self._buf("f32", b)
             d = np.ascontiguousarray(d, dtype=dst.dtype)
             copy_bytes(dst, d, dst.nbytes)
         self.decode_s += time.perf_counter() - t0
@@ -404,6 +470,7 @@ class FramePrefetcher:
         for i in range(n):
             while True:
                 while nxt < n and len(pending) + len(in_flight) < S:
+                    self._ensure(nxt, nxt % S)
                     pending[nxt] = self._pool.submit(self._decode, nxt, nxt % S)
                     nxt += 1
                 if i in pending:
@@ -420,10 +487,13 @@ class FramePrefetcher:
             self.ctx.slot_wait(in_flight.popleft() % self.ctx.n_slots)
 
     def close(self):
+        from .fusion import PinnedCache
         self._pool.shutdown(wait=True)
-        for group in (self._f32, self._u16, self._bgr):
-            for p in group:
-                p.free()
+        for group in self._bufs.values():
+            for b, pa in enumerate(group):
+                if pa is not None:
+                    PinnedCache.give(pa)                     # stays page-locked for the next prefetcher (up to PinnedCache.limit_bytes)
+                    group[b] = None
 
 
 def save_depth_like_processor(depth_m: np.ndarray, out_dir, frame_id: str):

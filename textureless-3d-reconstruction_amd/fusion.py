@@ -54,7 +54,7 @@ class GridSpec:
 
 
 class PinnedArray:
-    """numpy view of page-locked host memory from tl3d_pinned_alloc (async H2D copies need it to overlap)."""
+    """A numpy array in page-locked host memory (tl3d_pinned_alloc): the source of asynchronous uploads."""
 
     def __init__(self, shape, dtype):
         self.lib = abi.load()
@@ -76,6 +76,60 @@ class PinnedArray:
             self.free()
         except Exception:
             pass
+
+
+class PinnedCache:
+    """Page-locked staging buffers kept between uses.  Locking and unlocking host memory costs ~1.5 ms per 10 MB each way (measured:
+    a ring of 32 x 18.6 MB staging buffers 51 ms to set up, 74 ms to tear down -- a third of a 384-frame file-fed run), so the frame
+    prefetcher takes its buffers from here and hands them back; at most `limit_bytes` stay cached, the rest is freed at once, and
+    everything is freed when the interpreter exits.  Thread-safe (the decode workers take buffers side by side)."""
+    limit_bytes = 1 << 30
+    _free = {}
+    _cached = 0
+    _lock = None
+
+    @classmethod
+    def _lk(cls):
+        if cls._lock is None:
+            import atexit
+            import threading
+            cls._lock = threading.Lock()
+            atexit.register(cls.clear)
+        return cls._lock
+
+    @classmethod
+    def take(cls, shape, dtype) -> PinnedArray:
+        key = (tuple(int(x) for x in shape), np.dtype(dtype).str)
+        with cls._lk():
+            lst = cls._free.get(key)
+            if lst:
+                pa = lst.pop()
+                cls._cached -= pa.nbytes
+                return pa
+        return PinnedArray(shape, dtype)
+
+    @classmethod
+    def give(cls, pa: PinnedArray):
+        if pa is None or pa._p is None:
+            return
+        key = (tuple(pa.array.shape), pa.array.dtype.str)
+        with cls._lk():
+            if cls._cached + pa.nbytes <= cls.limit_bytes:
+                cls._free.setdefault(key, []).append(pa)
+                cls._cached += pa.nbytes
+                return
+        pa.free()
+
+    @classmethod
+    def clear(cls):
+        with cls._lk():
+            lists, cls._free, cls._cached = list(cls._free.values()), {}, 0
+        for lst in lists:
+            for pa in lst:
+                try:
+                    pa.free()
+                except Exception:
+                    pass
 
 
 # numpy images of tl3d_icp_pair / tl3d_icp_result (include/tl3d.h; sizes checked against the ctypes structures at import)
