@@ -435,7 +435,9 @@ def main():
                             "frac_of_8TBps": round(cen_bytes / (rows["centroid_s2_us_per_frame"] * 1e-6) / 8e12, 4), "frames_per_launch": 32,
                             "launches": int(n_acc)}
         ctx.reset()
-        rows["icp"] = {"iters": args.icp_iters, "stride": 4, "pairs_per_launch": 64, "prior": "analytic inter-frame motion"}
+        rows["icp"] = {"iters": args.icp_iters, "stride": 4, "pairs_per_launch": 64, "prior": "analytic inter-frame motion",
+                       "workgroups_per_pair": int(min(32, -(-((W + 3) // 4) * ((H + 3) // 4) // 8192))), "pair_slots_per_workgroup": 2,
+                       "algorithmic_bytes_per_pair_iteration": 20 * ((W + 3) // 4) * ((H + 3) // 4)}
         sampled("icp_single_chain_us_per_iteration",
                 lambda k: ctx.icp((k - 1) % n_res, k % n_res, T_init=T_rel[k % n_res], iters=args.icp_iters, stride=4, max_dist=0.05, eps=0.0), 24,
                 lambda t_: 1e6 * t_ / (args.icp_iters + 1), digits=2)
@@ -445,6 +447,9 @@ def main():
         fixed = [dict(iters=args.icp_iters, stride=4, max_dist=0.05, eps=0.0)]
         sampled("icp_batch_pairs_per_s", lambda k: ctx.icp_batch(all_pairs, fixed, T_init=T_rel), 2, lambda t_: n_res / t_)
         rows["icp_batch_us_per_pair_iteration"] = round(1e6 / rows["icp_batch_pairs_per_s"] / (args.icp_iters + 1), 3)
+        # 20 B per sampled pixel (4 B source depth + 16 B target normal and depth), SURVEY.md section 8d
+        rows["icp"]["batch_achieved_GBps"] = round(rows["icp"]["algorithmic_bytes_per_pair_iteration"] / rows["icp_batch_us_per_pair_iteration"] / 1e3, 1)
+        rows["icp"]["batch_frac_of_8TBps"] = round(rows["icp"]["batch_achieved_GBps"] / 8000.0, 4)
         two = [dict(iters=10, stride=4, max_dist=0.2, eps=1e-7), dict(iters=15, stride=2, max_dist=0.05, eps=1e-7)]
         sampled("icp_batch_two_level_from_identity_pairs_per_s", lambda k: ctx.icp_batch(all_pairs, two), 2, lambda t_: n_res / t_)
         sampled("icp_batch_one_pair_us_per_iteration", lambda k: ctx.icp_batch(all_pairs[1:2], fixed, T_init=T_rel[1:2]), 16,

@@ -8,4 +8,6 @@ bash tools/prof_round.sh "$TAG" > "gpurun_out/prof_round_${TAG}.log" 2>&1; echo 
 for c in 2 3 4 4b; do
   timeout -k 5 300 python3 tools/run_config.py --config $c --out "gpurun_out/${TAG}_config_runs.jsonl" > "gpurun_out/run_config_$c.log" 2>&1; echo "config $c rc=$?"
 done
+bash tools/pmc_icp.sh "$TAG" > "gpurun_out/pmc_icp_${TAG}.log" 2>&1; echo "pmc_icp rc=$?"
+timeout -k 5 200 python3 tools/bench_icp.py --json "gpurun_out/${TAG}_bench_icp.json" > "gpurun_out/${TAG}_bench_icp.txt" 2>&1; echo "bench_icp rc=$?"
 tail -5 "gpurun_out/prof_round_${TAG}.log"
