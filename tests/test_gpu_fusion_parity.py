@@ -225,6 +225,42 @@ def test_tsdf_lane_mappings_agree_for_rolled_and_top_down_cameras():
     assert orc.tsdf[:, 1].sum() > 100000 and np.array_equal(g, orc.tsdf)
 
 
+@pytest.mark.parametrize("width,height,radius", [(161, 119, 0), (162, 120, 1), (163, 121, 1)])
+def test_normal_maps_in_phase_major_rows_give_the_oracle_for_any_width(width, height, radius):
+    """The library keeps normal maps and window-averaged depth in phase-major rows (pixel u at (u & 3) * ceil(W / 4) + (u >> 2)):
+    widths that are not multiples of 4, plain and smoothed normals, host and device destinations of tl3d_download_normals, and
+    both registration kernels reading through that layout (per-iteration and batched; strides 1, 2, 4) against the oracle."""
+    import torch
+    from oracle import c_oracle
+    from tl3d import synth
+    cam = dict(width=width, height=height, fx=150.0, fy=150.0, cx=0.5 * width, cy=0.5 * height)
+    poses, frames = small_scene_frames(n=3, deg=1.5, cam=cam)
+    ctx = tl3d.FusionContext(width, height, cam["fx"], cam["fy"], cam["cx"], cam["cy"], n_slots=3, grid=None)
+    orc = c_oracle.Oracle(width, height, cam["fx"], cam["fy"], cam["cx"], cam["cy"], 0.1, 50.0, dims=(8, 8, 8), origin=(0.0, 0.0, 0.0),
+                          voxel_size=0.02, sdf_trunc=0.08)
+    with ctx:
+        for i, f in enumerate(frames):
+            ctx.upload(i, *f)
+        ctx.set_normal_smoothing(radius)
+        for i in range(3):
+            ctx.build_normals(i, depth_jump=0.05)
+        onm = [orc.normals_smooth(f[0], radius, depth_jump=0.05)[1] if radius else orc.normals(f[0], depth_jump=0.05) for f in frames]
+        dev = torch.empty((height, width, 4), dtype=torch.float32, device="cuda")
+        for i in range(3):
+            assert np.array_equal(ctx.download_normals(i), onm[i])
+            ctx.download_normals(i, out=dev)
+            assert np.array_equal(dev.cpu().numpy(), onm[i])
+        for stride in (1, 2, 4):
+            lv = [dict(iters=6, stride=stride, max_dist=0.1, eps=0.0)]
+            one = ctx.icp(0, 1, iters=6, stride=stride, max_dist=0.1, eps=0.0)
+            batch = ctx.icp_batch([(0, 1), (1, 2)], lv)
+            src = orc.normals_smooth(frames[0][0], radius, depth_jump=0.05)[0] if radius else frames[0][0]
+            ores = orc.icp(src, onm[1], iters=6, stride=stride, max_dist=0.1, eps=0.0)
+            for res in (one, batch[0]):
+                assert res["n_src"] == ores["n_src"] and abs(res["n_corr"] - ores["n_corr"]) <= 2
+                assert np.linalg.norm(res["T"] - ores["T"]) <= 1e-8
+
+
 def test_icp_lanes_match_blocking_calls():
     """Asynchronous ICP lanes (independent pairs in flight on separate streams) give the blocking call's result."""
     poses, frames = small_scene_frames(n=6, deg=1.5)

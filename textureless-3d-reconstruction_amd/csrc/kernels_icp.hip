@@ -833,7 +833,7 @@ struct IcpSlot {                                           // LDS; written by th
     unsigned long long wait_t0;
 };
 template <bool SCALE_OK, bool TAB>
-__global__ __launch_bounds__(256, SCALE_OK ? 1 : 2) void icp_batch_kernel(Cam cam, IcpBatchArgs a) {
+__global__ __launch_bounds__(256, 2) void icp_batch_kernel(Cam cam, IcpBatchArgs a) {
     __shared__ double sm[8][ICP_SLAB];
     __shared__ double tot[ICP_SLAB];
     __shared__ float sT[ICP_SLOTS][16];                    // per slot: the pose as 12 floats + the source depth's scale
@@ -1072,6 +1072,19 @@ int launch_icp_batch(hipStream_t s, const Cam &cam, const IcpBatchArgs &a) {
     const unsigned slots = (unsigned)a.n_pairs * (unsigned)a.members;
     const unsigned grid = slots < (unsigned)resident[scale][tab] ? slots : (unsigned)resident[scale][tab];
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, cam, a);
+    TL3D_HIP(hipGetLastError());
+    return TL3D_OK;
+}
+
+// a normal map (phase-major rows) as the row-major [H][W] image the caller of tl3d_download_normals gets
+__global__ __launch_bounds__(256) void nmap_rowmajor_kernel(int W, int H, const float4 *__restrict__ nmap, float4 *__restrict__ out) {
+    const int u = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int v = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (u < W && v < H) out[(size_t)v * W + u] = nmap[pm_index(u, v, pm_w4(W))];
+}
+
+int launch_nmap_rowmajor(hipStream_t s, const Cam &cam, const float4 *nmap, float4 *out) {
+    hipLaunchKernelGGL(nmap_rowmajor_kernel, dim3((cam.W + 63) / 64, (cam.H + 3) / 4), dim3(256), 0, s, cam.W, cam.H, nmap, out);
     TL3D_HIP(hipGetLastError());
     return TL3D_OK;
 }

@@ -1224,6 +1224,12 @@ int tl3d_download_normals(tl3d_ctx *ctx, int slot, float *out) {
     REQUIRE(ctx->slots[slot].has_normals, TL3D_E_STATE, "slot %d has no normal map (call tl3d_build_normals)", slot);
     TL3D_HIP(hipSetDevice(ctx->device));
     // the map lives in phase-major rows (tl3d_internal.h: pm_index); the caller gets it row-major
+    if (is_device_ptr(out)) {
+        const int rc2 = launch_nmap_rowmajor(ctx->stream, ctx->cam, ctx->slots[slot].nmap, (float4 *)out);
+        if (rc2) return rc2;
+        TL3D_HIP(hipStreamSynchronize(ctx->stream));
+        return TL3D_OK;
+    }
     const int W = ctx->cam.W, H = ctx->cam.H, w4 = pm_w4(W);
     float4 *tmp = (float4 *)malloc(pm_pixels(W, H) * sizeof(float4));
     REQUIRE(tmp != nullptr, TL3D_E_NOMEM, "host allocation failed");

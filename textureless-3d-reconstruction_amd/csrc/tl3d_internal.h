@@ -415,6 +415,7 @@ int launch_tsdf_update(hipStream_t s, const Cam &cam, const Grid &g, int n, int 
                        void *scratch, unsigned long long *counters, bool count, int max_blocks, int xcd_group);
 int launch_fold_free(hipStream_t s, const Grid &g, int2 *grid, unsigned *free_cnt);
 // normals + icp
+int launch_nmap_rowmajor(hipStream_t s, const Cam &cam, const float4 *nmap, float4 *out);
 int launch_normals(hipStream_t s, const Cam &cam, const float *depth, float scale, float mind, float maxd, float jump, int radius, float *sdepth,
                    float4 *nmap);
 int launch_icp_batch(hipStream_t s, const Cam &cam, const IcpBatchArgs &a);

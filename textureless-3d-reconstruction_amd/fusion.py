@@ -398,8 +398,11 @@ class FusionContext:
     def build_normals(self, slot: int, scale=1.0, depth_jump=0.05):
         abi.check(self._lib.tl3d_build_normals(self._h, int(slot), float(scale), float(depth_jump)))
 
-    def download_normals(self, slot: int) -> np.ndarray:
-        out = np.empty((self.height, self.width, 4), np.float32)
+    def download_normals(self, slot: int, out=None) -> np.ndarray:
+        """The slot's normal map as a row-major [H][W][4] image (nx, ny, nz, depth); out: a host array or a device tensor of that
+        shape to fill instead (the library keeps the map in phase-major rows and converts on the way out)."""
+        if out is None:
+            out = np.empty((self.height, self.width, 4), np.float32)
         abi.check(self._lib.tl3d_download_normals(self._h, int(slot), abi.ptr(out)))
         return out
 

@@ -58,7 +58,8 @@ for radius in [int(x) for x in args.radius.split(",")]:
             ("stride 4 x %d" % args.iters, [dict(iters=args.iters, stride=4, max_dist=0.05, eps=0.0)], Tp, args.iters + 1),
             ("stride 2 x %d" % args.iters, [dict(iters=args.iters, stride=2, max_dist=0.05, eps=0.0)], Tp, args.iters + 1),
             ("stride 1 x 4", [dict(iters=4, stride=1, max_dist=0.05, eps=0.0)], Tp, 5),
-            ("two-level from identity", [dict(iters=10, stride=4, max_dist=0.2, eps=1e-7), dict(iters=15, stride=2, max_dist=0.05, eps=1e-7)], None, None)):
+            ("two-level from identity", [dict(iters=10, stride=4, max_dist=0.2, eps=1e-7), dict(iters=15, stride=2, max_dist=0.05, eps=1e-7)], None, None),
+            ("Sim(3) stride 4 x %d" % args.iters, [dict(iters=args.iters, stride=4, max_dist=0.05, eps=0.0, estimate_scale=True)], Tp, args.iters + 1)):
         if args.cases and not any(c in name for c in args.cases.split(",")):
             continue
         res = ctx.icp_batch(pairs, levels, T_init=init)

@@ -37,10 +37,10 @@ with open(os.path.join(out, "summary.txt"), "w") as fh:
         a = {c: sum(v) / len(v) for c, v in agg[k].items()}
         if "icp_batch" in k and "SQ_INSTS_VALU" in a and "GRBM_GUI_ACTIVE" in a:
             # one launch = 127 pairs x 11 passes; 1024 SIMDs; a vector instruction occupies its SIMD's issue port for >= 4 cycles
-            cyc = a["GRBM_GUI_ACTIVE"]
+            cyc = a["GRBM_GUI_ACTIVE"] / 8.0                 # the counter is summed over the 8 XCDs
             pp = 127 * 11
             print(f"    -> vector instructions per pair-pass {a['SQ_INSTS_VALU'] / pp:10.0f}  (x 64 lanes / 129600 samples = {a['SQ_INSTS_VALU'] / pp * 64 / 129600:.1f} per sample)", file=fh)
-            print(f"    -> vector issue: {a['SQ_INSTS_VALU'] * 4 / 1024 / cyc:.3f} of the launch at 4 cycles per instruction and SIMD", file=fh)
+            print(f"    -> vector issue: {a['SQ_INSTS_VALU'] * 4 / 1024 / cyc:.3f} of the launch at 4 cycles per instruction and SIMD ({a['SQ_INSTS_VALU'] * 4.4 / 1024 / cyc:.3f} at the measured 4.4), launch = {cyc / 1e6:.2f} M cycles per XCD", file=fh)
             if "SQ_WAVE_CYCLES" in a and "SQ_WAIT_INST_ANY" in a:
                 print(f"    -> wave-cycles waiting for an instruction's operands (SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES) {a['SQ_WAIT_INST_ANY'] / a['SQ_WAVE_CYCLES']:.3f}; "
                       f"waiting for anything (SQ_WAIT_ANY) {a.get('SQ_WAIT_ANY', 0) / a['SQ_WAVE_CYCLES']:.3f}; issuing {a.get('SQ_ACTIVE_INST_ANY', 0) / a['SQ_WAVE_CYCLES']:.3f}", file=fh)
