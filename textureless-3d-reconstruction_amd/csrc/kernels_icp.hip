@@ -833,7 +833,7 @@ struct IcpSlot {                                           // LDS; written by th
     unsigned long long wait_t0;
 };
 template <bool SCALE_OK, bool TAB>
-__global__ __launch_bounds__(256, 2) void icp_batch_kernel(Cam cam, IcpBatchArgs a) {
+__global__ __launch_bounds__(256, SCALE_OK ? 1 : 2) void icp_batch_kernel(Cam cam, IcpBatchArgs a) {
     __shared__ double sm[8][ICP_SLAB];
     __shared__ double tot[ICP_SLAB];
     __shared__ float sT[ICP_SLOTS][16];                    // per slot: the pose as 12 floats + the source depth's scale

@@ -158,8 +158,8 @@ constexpr int ICP_SLAB = 40;     // doubles per block partial: 30 sums of the po
 
 // TSDF updates are issued in batches of up to TL3D_TSDF_MAXBATCH frames (one bit per frame in a brick's frame mask): one prep
 // chain (5 launches) for the whole batch on the side stream, then ONE update launch on the main stream that reads and writes
-// every touched record once per batch.  Three batch scratch buffers are taken in turn, so the prep chains of batches k+1 and k+2
-// run beside the update of batch k.
+// every touched record once per batch.  Four batch scratch buffers are taken in turn (three prep streams), so the prep chains of
+// the next batches run beside the update of batch k.
 #define TL3D_TSDF_MAXBATCH 32
 constexpr int TSDF_SCRATCHES = 4;
 
