@@ -454,6 +454,9 @@ def main():
         sampled("icp_batch_two_level_from_identity_pairs_per_s", lambda k: ctx.icp_batch(all_pairs, two), 2, lambda t_: n_res / t_)
         sampled("icp_batch_one_pair_us_per_iteration", lambda k: ctx.icp_batch(all_pairs[1:2], fixed, T_init=T_rel[1:2]), 16,
                 lambda t_: 1e6 * t_ / (args.icp_iters + 1), digits=2)
+        st_icp = ctx.stats()
+        rows["icp"]["batch_timeouts"] = int(st_icp.get("icp_batch_timeouts", 0))          # in-kernel waits that hit their bound (0: none)
+        rows["icp"]["batch_fallback_pairs"] = int(st_icp.get("icp_batch_fallback_pairs", 0))
         cap_pts = H * W
         xyz_d = torch.empty((cap_pts, 3), dtype=torch.float32, device=dev)
         rgb_d = torch.empty((cap_pts, 3), dtype=torch.uint8, device=dev)

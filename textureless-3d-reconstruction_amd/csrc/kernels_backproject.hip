@@ -53,8 +53,11 @@ __global__ __launch_bounds__(1024) void scan_kernel(const unsigned *__restrict__
 #ifndef TL3D_BP_SLEEP
 #define TL3D_BP_SLEEP 1                        // x 64 cycles between two polls of a granule
 #endif
-constexpr int BP_TILE = 2048;                  // samples per workgroup (8 per thread)
-constexpr int BP_PER = BP_TILE / 256;
+// Samples per workgroup (TILE, a template parameter: 8, 4 or 2 per thread).  A tile walks a chain of ~8 dependent memory round trips
+// (ticket, loads, publish, look-back, arrival, stores) whatever its size, so what a launch costs is that chain times the tiles a
+// CU has to take one after another, and a level of few samples wants SMALL tiles: the reference's default stride 2 at 1080p is
+// 518 k samples = 253 tiles of 2048, one workgroup on every CU and nothing beside it to hide the chain (see bp_tile_samples).
+constexpr int BP_TILE_MAX = 2048;
 constexpr int BP_WIN = 1024;                   // predecessors one look-back round inspects (4 per thread)
 constexpr unsigned long long BP_AGG = 1ull << 62, BP_PFX = 2ull << 62, BP_VAL = (1ull << 62) - 1ull;
 constexpr unsigned BP_SPIN_LIMIT = 1u << 17;   // polls of one granule (~0.1 s) before giving up (sets the error word)
@@ -68,12 +71,13 @@ constexpr unsigned BP_F_STATIC_ORDER = 0x40000000u;   // internal BpArgs.flags b
 // flag, no fence needed (MI355X guide, Guideline 16, form R2).  All words are zero between launches: the buffer is zeroed
 // when allocated and the tile that FINISHES last re-arms it (by then every tile has stopped polling), so a launch needs
 // no memset in front of it and has no per-launch arguments (it can be captured and replayed).
-template <bool WRITE>
+template <bool WRITE, int BP_TILE>
 __global__ __launch_bounds__(256) void bp_fused_kernel(Cam cam, BpArgs a, PoseD p, const float *__restrict__ depth,
                                                        const uint8_t *__restrict__ bgr, const double *__restrict__ xf,
                                                        const double *__restrict__ yf, unsigned long long *state,
                                                        float *__restrict__ xyz, uint8_t *__restrict__ rgb, unsigned long long cap,
                                                        unsigned long long *__restrict__ total_out) {
+    constexpr int BP_PER = BP_TILE / 256;
     // one LDS block, carved by hand: [xyz staging | rgb staging | per-(iteration, wave) counts | reduction scratch | scalars]
     constexpr int XYZ_B = WRITE ? (3 * BP_TILE + 4) * 4 : 16, RGB_B = WRITE ? 3 * BP_TILE + 16 : 16;
     constexpr int O_WAVE = XYZ_B + RGB_B, O_RED = O_WAVE + BP_PER * 16, O_SC = O_RED + 64;
@@ -345,13 +349,29 @@ int launch_bp_bounds(hipStream_t s, const Cam &cam, const BpArgs &a, const PoseD
     return TL3D_OK;
 }
 
+// tile size of a launch: a function of the number of samples only (the output does not depend on it: order-preserving either way)
+int bp_tile_samples(const BpArgs &a) {
+#ifdef TL3D_EXPERIMENTS
+    if (const char *e = getenv("TL3D_BP_TILE")) {
+        const int t = atoi(e);
+        if (t == 512 || t == 1024 || t == 2048) return t;
+    }
+#endif
+    const long long ns = (long long)a.Ws * a.Hs;
+    return ns > (3ll << 19) ? 2048 : (ns > (3ll << 17) ? 1024 : 512);        // > 1.5 M samples: 2048; > 393 k: 1024; else 512
+}
+
 int bp_fused_tiles(const BpArgs &a) {
     const long long ns = (long long)a.Ws * a.Hs;
-    const long long nt = (ns + BP_TILE - 1) / BP_TILE;
+    const long long tile = bp_tile_samples(a);
+    const long long nt = (ns + tile - 1) / tile;
     return (int)(nt < 1 ? 1 : nt);
 }
 
-int bp_state_words(const BpArgs &a) { return BP_HDR + bp_fused_tiles(a); }
+int bp_state_words(const BpArgs &a) {               // sized for the smallest tile: a context's scratch serves every launch shape
+    const long long ns = (long long)a.Ws * a.Hs;
+    return BP_HDR + (int)((ns + 511) / 512) + 1;
+}
 
 // state: device buffer of at least bp_state_words(a) 64-bit words, ALL ZERO (zeroed once by the owner; the kernel leaves it
 // zero again, except the error word [1]); total_out: device word that receives the count
@@ -369,24 +389,30 @@ int launch_bp_fused(hipStream_t s, const Cam &cam, const BpArgs &a, const PoseD 
     constexpr int pin = 0;
 #endif
     BpArgs ad = a;
+    const int tile = bp_tile_samples(a);
+    const int ti = tile == 2048 ? 0 : (tile == 1024 ? 1 : 2);
+    using Kern = void (*)(Cam, BpArgs, PoseD, const float *, const uint8_t *, const double *, const double *, unsigned long long *, float *, uint8_t *,
+                          unsigned long long, unsigned long long *);
+    static const Kern kw[3] = {bp_fused_kernel<true, 2048>, bp_fused_kernel<true, 1024>, bp_fused_kernel<true, 512>};
+    static const Kern kc[3] = {bp_fused_kernel<false, 2048>, bp_fused_kernel<false, 1024>, bp_fused_kernel<false, 512>};
     // how many workgroups of this kernel the device holds at once, from the runtime (registers, LDS, CU count), not a constant
-    static int resident = -1;
-    if (resident < 0) {
+    static int resident[3] = {-1, -1, -1};
+    if (resident[ti] < 0) {
         int per_cu = 0, cus = 0, dev = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bp_fused_kernel<true>, 256, 0) == hipSuccess && per_cu > 0 && cus > 0)
-            resident = per_cu * cus;
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kw[ti], 256, 0) == hipSuccess && per_cu > 0 && cus > 0)
+            resident[ti] = per_cu * cus;
         else {
             (void)hipGetLastError();
-            resident = 0;                                  // unknown: always dynamic order
+            resident[ti] = 0;                              // unknown: always dynamic order
         }
     }
-    const bool stat = pin == 2 || (pin == 0 && !force_dynamic && nt <= resident);
+    const bool stat = pin == 2 || (pin == 0 && !force_dynamic && nt <= resident[ti]);
     if (stat) ad.flags |= BP_F_STATIC_ORDER;
     if (xyz && rgb)
-        hipLaunchKernelGGL(bp_fused_kernel<true>, dim3(nt), dim3(256), 0, s, cam, ad, p, depth, bgr, xf, yf, state, xyz, rgb, cap, total_out);
+        hipLaunchKernelGGL(kw[ti], dim3(nt), dim3(256), 0, s, cam, ad, p, depth, bgr, xf, yf, state, xyz, rgb, cap, total_out);
     else
-        hipLaunchKernelGGL(bp_fused_kernel<false>, dim3(nt), dim3(256), 0, s, cam, ad, p, depth, bgr, xf, yf, state, nullptr, nullptr, 0ull, total_out);
+        hipLaunchKernelGGL(kc[ti], dim3(nt), dim3(256), 0, s, cam, ad, p, depth, bgr, xf, yf, state, (float *)nullptr, (uint8_t *)nullptr, 0ull, total_out);
     TL3D_HIP(hipGetLastError());
     return TL3D_OK;
 }
