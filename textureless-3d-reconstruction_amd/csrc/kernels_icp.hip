@@ -906,6 +906,9 @@ __global__ __launch_bounds__(256, SCALE_OK ? 1 : 2) void icp_batch_kernel(Cam ca
             if (ph == ICP_PH_READY && (run < 0 || sl[s].ticket < sl[run].ticket)) run = s;      // the oldest pair first
             n_wait += (ph == ICP_PH_WAITING);
         }
+        // Every wave has taken its decision from the same slot states before anybody changes them: wave 0's poll below may move a
+        // slot to READY, and a wave that read the states only then would run a pass while the others poll (barriers out of step).
+        __syncthreads();
         // Nothing in hand: slot 0, which takes a ticket whenever it needs one, is neither ready nor waiting, so it has found every
         // ticket handed out -- and so would the later slots that have not tried yet.
         if (run < 0 && n_wait == 0) return;
