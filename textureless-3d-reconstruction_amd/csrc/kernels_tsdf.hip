@@ -1317,6 +1317,17 @@ int launch_tsdf_prepare(hipStream_t s, const Cam &cam, const Grid &g, int n, int
     hipLaunchKernelGGL(brick_cull_kernel, dim3(nquad < 256 ? nquad : 256, n), dim3(256), 0, s, cam, g, B, fr, py, free_cnt);
     TL3D_HIP(hipGetLastError());
     if (classify_only) return TL3D_OK;                    // (tl3d_count_bricks: which bricks WOULD get records is all that is asked)
+    // The batch list ordered by cost, dearest bricks first (a one-frame batch: every brick costs the same; the update walks the list).
+    // A brick's cost is the number of frames that list it -- the frame masks, which the cull has just finished -- so the two small
+    // kernels go BEFORE the sub-brick classification, not behind it: beside an update kernel the classification stretches over the
+    // whole update period and ends when the update drains, and whatever follows it in the chain sits in front of the next update
+    // (12-37 us per 400 us step in the timeline of round 4).  Measured: 78.6-79.0 k frames/s either way (three
+    // interleaved runs each) -- the step is bound by the sum of the work, not by that gap; the shorter tail is kept.
+    if (n > 1) {
+        hipLaunchKernelGGL(batch_hist_kernel, dim3(ORDER_BLOCKS), dim3(256), 0, s, g, B);
+        hipLaunchKernelGGL(batch_order_kernel, dim3(ORDER_BLOCKS), dim3(256), 0, s, g, B);
+        TL3D_HIP(hipGetLastError());
+    }
     // sub-brick masks of the listed bricks (their number is known only on the device: a fixed grid strides over each list)
     const int nbricks = g.nbx * g.nby * g.nbz;
     int ncb = (nbricks + 31) / 32;                       // 8 bricks per wave, 4 waves per workgroup
@@ -1324,11 +1335,6 @@ int launch_tsdf_prepare(hipStream_t s, const Cam &cam, const Grid &g, int n, int
     if (ncb > cap) ncb = cap;
     hipLaunchKernelGGL(subbrick_classify_kernel, dim3(ncb, n), dim3(256), 0, s, cam, g, py, B);
     TL3D_HIP(hipGetLastError());
-    if (n > 1) {                                         // dearest bricks first (a one-frame batch: every brick costs the same; the update walks the list)
-        hipLaunchKernelGGL(batch_hist_kernel, dim3(ORDER_BLOCKS), dim3(256), 0, s, g, B);
-        hipLaunchKernelGGL(batch_order_kernel, dim3(ORDER_BLOCKS), dim3(256), 0, s, g, B);
-        TL3D_HIP(hipGetLastError());
-    }
     return TL3D_OK;
 }
 
