@@ -294,8 +294,11 @@ static int alloc_grid(tl3d_ctx *ctx, const tl3d_config *cfg) {
             ctx->own_tsdf = true;
             if (hipMemsetAsync(ctx->tsdf, 0, pool_b, ctx->stream) != hipSuccess) return set_err(TL3D_E_HIP, "memset failed");
         }
-        {   // Side streams for the prep chains of the batches (descriptors, tiles, pyramid, brick and sub-brick classification):
-            // the chains of batches k+1 and k+2 run beside the update kernel of batch k.  Three streams, taken in turn (one per batch scratch).
+        {   // Side streams for the prep chains of the batches (descriptors, tiles, pyramid, brick classes, cost order, sub-brick
+            // classes): the chains of the next batches run beside the update kernel of batch k.  Three streams, taken in turn, and
+            // TSDF_SCRATCHES = 4 batch scratches.  Beside an update kernel a chain's big kernels stretch over a whole update period each,
+            // so a chain is three periods long and three are in flight; a fourth stream with six scratches was slower (74.1 k against
+            // 76.5 k frames/s: the step is bound by the sum of the work), two streams too (77.3 k against 79.2 k).
             // (A higher stream priority for the chains changes nothing measurable: 55.4k against 55.3k frames/s.)
             ctx->n_prep_streams = env_int("TL3D_PREP_STREAMS", 3);
             if (ctx->n_prep_streams < 1) ctx->n_prep_streams = 1;
@@ -318,9 +321,9 @@ static int alloc_grid(tl3d_ctx *ctx, const tl3d_config *cfg) {
         ctx->tsdf_batch = env_int("TL3D_TSDF_BATCH", 32);
         if (ctx->tsdf_batch < 1) ctx->tsdf_batch = 1;
         if (ctx->tsdf_batch > TL3D_TSDF_MAXBATCH) ctx->tsdf_batch = TL3D_TSDF_MAXBATCH;
-        {   // Workgroups of the update kernel: THREE per CU.  Four fit (127 VGPRs) and the kernel alone is fastest with exactly
-            // four (0.41 ms per 32 frames against 0.46), but the prep chains of the next two batches run beside it and need
-            // wave slots: 61.4k frames/s with 768 workgroups, 59.5k with 1024, 58.2k with 2048 (256 CUs).
+        {   // Workgroups of the update kernel (the pair form: ~56 vector registers, eight waves per SIMD, tasks by ticket): 12 per CU.
+            // Round 4, same box, interleaved: 1536 / 2048 / 3072 workgroups 74.8 / 76.5 / 77.8 k frames/s; 4096 and 6144 inside
+            // the spread of 3072 (77.9 / 78.2 k against 77.5 k).  (Round 3's frame-major kernel, 128 registers, wanted three per CU.)
             int cus = 0;
             if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || cus < 1) cus = 256;
             ctx->tsdf_max_blocks = env_int("TL3D_UPDATE_BLOCKS", 12 * cus);
@@ -328,7 +331,7 @@ static int alloc_grid(tl3d_ctx *ctx, const tl3d_config *cfg) {
         if (ctx->tsdf_max_blocks < 8) ctx->tsdf_max_blocks = 8;
         ctx->tsdf_xcd_group = env_int("TL3D_XCD_GROUP", 1);       // consecutive list entries per ticket chunk (1: best balance; 16: 41.8k against 43.8k frames/s)
         ctx->tsdf_single_stream = env_int("TL3D_SINGLE_STREAM", 0) != 0;
-        {   // the scratch of the three batches in flight: one allocation; the frame masks start out zero (the update re-arms them)
+        {   // the scratch of the batches in flight (TSDF_SCRATCHES): one allocation; the frame masks start out zero (the update re-arms them)
             const size_t each = (tsdf_batch_scratch_bytes(ctx->cam, g, ctx->tsdf_batch) + 255) & ~(size_t)255;
             void *slab = nullptr;
             if (hipMalloc(&slab, each * TSDF_SCRATCHES) != hipSuccess) return set_err(TL3D_E_NOMEM, "TSDF scratch alloc (%zu B) failed", each * TSDF_SCRATCHES);
