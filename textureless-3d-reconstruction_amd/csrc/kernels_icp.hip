@@ -14,8 +14,10 @@
 // depth) + 16 (target normal+depth gather) = 20 B.
 //
 // Batched form (icp_batch_kernel, tl3d_icp_batch_*): many pairs, each through all its coarse-to-fine levels and all its
-// iterations, in ONE launch; the workgroups that share a pair meet at a per-pair barrier in device memory after every
-// pass.  Same accumulate / solve code as the per-iteration kernel; what the pipeline uses.
+// iterations, in ONE persistent launch; the workgroups that share a pair meet at a per-pair barrier in device memory after every
+// pass, and every workgroup works on two (pair, member) slots in turn.  Same accumulate / solve code as the per-iteration
+// kernel; what the pipeline uses.
+// Maps: normal maps and window-averaged depth live in PHASE-MAJOR ROWS (tl3d_internal.h: pm_index); a raw frame is row-major.
 #include "tl3d_internal.h"
 
 namespace tl3d {
@@ -786,14 +788,14 @@ __global__ __launch_bounds__(256) void icp_iter_kernel(Cam cam, const IcpRun *__
 // wave instruction (13 lanes, one 64-B request) that returns the flags and the pose together: no fence and no load on
 // the waiting side.  Publishing and polling are read-modify-write atomics, which execute at the memory side: polls by
 // agent-scope (sc1) LOADS were seen to return a word their XCD had cached before the store for seconds (88 of 113
-// members of a pair stuck, the 25 on the publisher's XCD gone ahead), whatever the allocation flags.  A long first sleep,
-// then short ones: polls of one line from a hundred CUs at full rate saturate its channel and starve the arrivals.
+// members of a pair stuck, the 25 on the publisher's XCD gone ahead), whatever the allocation flags.  Short sleeps between
+// polls: polls of one line from a hundred CUs at full rate saturate its channel and starve the arrivals.
 // Arrival counter and generation line of a pair are different lines; consecutive pairs' lines are > 4 KB apart.
 // Waiting needs the pair's other workgroups to be running.  The launch is therefore PERSISTENT: at most as many workgroups as
 // the chip holds at once, each taking (pair, member) TICKETS in a loop -- one when it starts, the next when its pair is through
 // all its passes.  The tickets handed out at any moment form a window of consecutive (pair, member) slots held by running
 // workgroups: every pair that lies wholly inside the window completes, its workgroups come back for tickets, and the pair at
-// the window's upper end gets its missing members from them (members <= 64 against >= 256 running workgroups: the grid is
+// the window's upper end gets its missing members from them (members <= 32 against >= 256 running workgroups: the grid is
 // what the occupancy query says the chip holds, never less than one workgroup per CU).  Nothing
 // depends on WHEN the hardware starts a workgroup.  (Until round 3 the grid was one workgroup per slot, tickets taken at
 // the start: the last pair of a 128-pair batch of 720p frames then waited for the grid's last two or three workgroups, which
