@@ -360,3 +360,32 @@ def test_layout_from_counts_goes_sparse_per_channel_when_that_halves_the_channel
     assert s.pool_tsdf == 0 and s.pool_centroid > 0 and s.sparse
     s = layout_from_counts(g, nbr, nbr)
     assert not s.sparse and s.device_bytes() == g.device_bytes()
+
+
+def test_read_npy_into_fills_a_staging_buffer_or_declines(tmp_path):
+    """fileio.read_npy_into: the payload of a matching .npy lands in the destination with one read (what the decode workers of
+    FramePrefetcher do with depth files); anything else -- other dtype, other shape, Fortran order, a pickled array, a file that is
+    not .npy -- is declined so that the caller falls back to np.load."""
+    from tl3d import fileio
+    rng = np.random.default_rng(3)
+    a = rng.random((37, 53), dtype=np.float32)
+    np.save(tmp_path / "a.npy", a)
+    dst = np.full((37, 53), -1.0, np.float32)
+    assert fileio.read_npy_into(tmp_path / "a.npy", dst) and np.array_equal(dst, a)
+    # version-2 header (a long dictionary), same payload
+    with open(tmp_path / "a2.npy", "wb") as f:
+        np.lib.format.write_array_header_2_0(f, dict(descr=np.lib.format.dtype_to_descr(a.dtype), fortran_order=False, shape=a.shape))
+        f.write(a.tobytes())
+    dst[:] = -1.0
+    assert fileio.read_npy_into(tmp_path / "a2.npy", dst) and np.array_equal(dst, a)
+    for name, arr in (("f64.npy", a.astype(np.float64)), ("shape.npy", a[:, :52]), ("fortran.npy", np.asfortranarray(a))):
+        np.save(tmp_path / name, arr)
+        dst[:] = -1.0
+        assert not fileio.read_npy_into(tmp_path / name, dst) and np.all(dst == -1.0)
+    (tmp_path / "short.npy").write_bytes((tmp_path / "a.npy").read_bytes()[:-8])                   # truncated payload
+    assert not fileio.read_npy_into(tmp_path / "short.npy", dst)
+    (tmp_path / "junk.npy").write_bytes(b"not an npy file")
+    assert not fileio.read_npy_into(tmp_path / "junk.npy", dst)
+    assert not fileio.read_npy_into(tmp_path / "missing.npy", dst)
+    fileio.keep_pil_blocks(4)                                                                        # harmless wherever Pillow lacks the hook
+    assert np.array_equal(fileio.DepthImageLoader.load_depth(tmp_path / "a.npy"), a)
