@@ -174,6 +174,11 @@ int tl3d_sync(tl3d_ctx *ctx);
 /* The hipStream_t the context enqueues on (the caller's, tl3d_config.stream, or the library's own): so that a caller can put ITS device
  * work -- a collective on the grid memory -- in the same order instead of waiting for the device (tl3d.distributed does). */
 int tl3d_get_stream(tl3d_ctx *ctx, void **stream);
+/* The frame buffers of a destroyed context stay in a process-wide cache (by device and size, at most 64 GiB) for the next context
+ * of the same shape: the reference's process reconstructs one sequence per run (D2R:705-808), a service reconstructs many, and
+ * memory the driver has just taken back is slow to come out of it again.  This call returns all of it to the driver (a host that
+ * shares the GPU with another allocator calls it between batches of sequences); an allocation that fails does so by itself. */
+int tl3d_release_cached_memory(void);
 
 /* a2: frames.  Replaces DepthImageLoader.load_depth's dtype handling (D2R:80-97) and the in-RAM frame
  * lists self.images/self.depths (D2R:434-437).  bgr may be NULL (colour (0,0,0)). */

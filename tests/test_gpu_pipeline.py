@@ -479,3 +479,38 @@ def test_cli_two_ranks_estimate_scale_equal_one_process(tmp_path):
     pts, _ = rn.read_ply(two)
     ref_p, _ = _reference_cpu_path(frames, rel, ReconstructionConfig(**CAM, voxel_size=0.005, subsample_factor=2))
     assert len(pts) > 20000 and rn.chamfer_mean(pts, ref_p) < 1e-3
+
+
+@pytest.mark.gpu
+def test_frame_slabs_of_a_destroyed_context_serve_the_next_one_and_can_be_released():
+    """tl3d_destroy hands the frame slabs to a process-wide cache (by device and size) instead of the driver; the next context of the
+    same shape takes them from there -- same results, no stale contents visible (every buffer is written before it is read) -- and
+    tl3d_release_cached_memory gives the memory back."""
+    import torch
+    from helpers import small_scene_frames, make_pair
+    poses, frames = small_scene_frames(n=3, deg=2.0)
+    grids = []
+    for rep in range(3):
+        ctx, orc = make_pair(n_slots=3)
+        with ctx:
+            for i, ((d, c), p) in enumerate(zip(frames, poses)):
+                ctx.upload(i, d + 0.25 * rep if rep == 1 else d, c)     # the second context leaves other depths behind in the slabs
+                ctx.build_normals(i)
+                ctx.integrate(i, p)
+            res = ctx.icp_batch([(0, 1), (1, 2)], [dict(iters=5, stride=2, max_dist=0.1)])
+            grids.append((ctx.download_grid(tl3d.CH_TSDF), [r["T"].copy() for r in res]))
+    assert np.array_equal(grids[0][0], grids[2][0]) and all(np.array_equal(a, b) for a, b in zip(grids[0][1], grids[2][1]))
+    assert not np.array_equal(grids[0][0], grids[1][0])
+    # slabs large enough to show in the device's free memory: 8 frames of 1080 x 1920 (66 MB of depth + 50 MB of colour)
+    tl3d.release_cached_memory()
+    free0 = torch.cuda.mem_get_info(0)[0]
+    big = tl3d.FusionContext(1080, 1920, 1719.0, 1719.0, 540.0, 960.0, n_slots=8, grid=None)
+    with big:
+        z, zc = np.ones((1920, 1080), np.float32), np.zeros((1920, 1080, 3), np.uint8)
+        for i in range(8):
+            big.upload(i, z, zc)
+        big.sync()
+    held = free0 - torch.cuda.mem_get_info(0)[0]
+    tl3d.release_cached_memory()
+    after = free0 - torch.cuda.mem_get_info(0)[0]
+    assert held >= 100 << 20 and after <= held - (100 << 20), (held, after)        # the cache held the slabs and let go of them

@@ -9,6 +9,6 @@ from . import _cabi  # noqa: F401
 
 _cabi.ensure_hw_queues()        # before the process's first HIP call (the runtime reads it once): see _cabi.ensure_hw_queues
 from ._cabi import CH_CENTROID, CH_TSDF, EXTRACT_CENTROID, EXTRACT_TSDF, ICP_LANES, Tl3dError  # noqa: F401
-from .fusion import FusionContext, GridSpec  # noqa: F401
+from .fusion import FusionContext, GridSpec, release_cached_memory  # noqa: F401
 
-__all__ = ["FusionContext", "GridSpec", "Tl3dError", "CH_TSDF", "CH_CENTROID", "EXTRACT_CENTROID", "EXTRACT_TSDF"]
+__all__ = ["FusionContext", "GridSpec", "release_cached_memory", "Tl3dError", "CH_TSDF", "CH_CENTROID", "EXTRACT_CENTROID", "EXTRACT_TSDF"]

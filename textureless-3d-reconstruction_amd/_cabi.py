@@ -21,7 +21,7 @@ TSDF_MAX_WEIGHT = 65536
 
 # every symbol include/tl3d.h declares (checked by tests/test_cabi_symbols.py against the header text)
 SYMBOLS = [
-    "tl3d_last_error", "tl3d_version", "tl3d_device_count", "tl3d_runtime_info", "tl3d_probe_hw_queues", "tl3d_grid_max_weight", "tl3d_create", "tl3d_destroy", "tl3d_sync", "tl3d_get_stream",
+    "tl3d_last_error", "tl3d_version", "tl3d_device_count", "tl3d_runtime_info", "tl3d_probe_hw_queues", "tl3d_grid_max_weight", "tl3d_create", "tl3d_destroy", "tl3d_sync", "tl3d_get_stream", "tl3d_release_cached_memory",
     "tl3d_upload_frame", "tl3d_download_depth", "tl3d_pinned_alloc", "tl3d_pinned_free", "tl3d_upload_frame_async",
     "tl3d_slot_wait", "tl3d_attach_grid", "tl3d_backproject", "tl3d_backproject_device", "tl3d_frame_bounds", "tl3d_frames_bounds", "tl3d_count_bricks", "tl3d_accumulate_centroid",
     "tl3d_accumulate_points", "tl3d_points_bounds", "tl3d_integrate", "tl3d_build_normals",
@@ -163,6 +163,7 @@ def load():
         "tl3d_destroy": [vp],
         "tl3d_sync": [vp],
         "tl3d_get_stream": [vp, C.POINTER(vp)],
+        "tl3d_release_cached_memory": [],
         "tl3d_upload_frame": [vp, i32, vp, i32, vp],
         "tl3d_download_depth": [vp, i32, vp],
         "tl3d_pinned_alloc": [C.c_size_t, C.POINTER(vp)],

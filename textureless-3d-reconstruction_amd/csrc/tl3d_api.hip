@@ -4,6 +4,7 @@
 #include <stdlib.h>
 #include <math.h>
 
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -77,6 +78,18 @@ int rccl_load() {
 const char *rccl_msg(int rc) { return g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "RCCL error"; }
 }  // namespace
 
+
+// hipMalloc for the large allocations of a grid: if the device is out of memory while the frame-slab cache (pool_release) holds
+// some, give that back and try once more
+static hipError_t device_malloc_big(void **p, size_t bytes) {
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipSuccess) return e;
+    (void)hipGetLastError();
+    (void)tl3d_release_cached_memory();
+    e = hipMalloc(p, bytes);
+    if (e != hipSuccess) (void)hipGetLastError();
+    return e;
+}
 
 static bool is_device_ptr(const void *p) {
     if (!p) return false;
@@ -290,7 +303,7 @@ static int alloc_grid(tl3d_ctx *ctx, const tl3d_config *cfg) {
             ctx->tsdf_w_unknown = true;                 // caller-owned memory: contents unknown
         } else {
             const size_t pool_b = (size_t)g.tsdf_cap << 12;
-            if (hipMalloc(&ctx->tsdf, pool_b) != hipSuccess) return set_err(TL3D_E_NOMEM, "TSDF record pool alloc (%zu B) failed", pool_b);
+            if (device_malloc_big((void **)&ctx->tsdf, pool_b) != hipSuccess) return set_err(TL3D_E_NOMEM, "TSDF record pool alloc (%zu B) failed", pool_b);
             ctx->own_tsdf = true;
             if (hipMemsetAsync(ctx->tsdf, 0, pool_b, ctx->stream) != hipSuccess) return set_err(TL3D_E_HIP, "memset failed");
         }
@@ -334,7 +347,7 @@ static int alloc_grid(tl3d_ctx *ctx, const tl3d_config *cfg) {
         {   // the scratch of the batches in flight (TSDF_SCRATCHES): one allocation; the frame masks start out zero (the update re-arms them)
             const size_t each = (tsdf_batch_scratch_bytes(ctx->cam, g, ctx->tsdf_batch) + 255) & ~(size_t)255;
             void *slab = nullptr;
-            if (hipMalloc(&slab, each * TSDF_SCRATCHES) != hipSuccess) return set_err(TL3D_E_NOMEM, "TSDF scratch alloc (%zu B) failed", each * TSDF_SCRATCHES);
+            if (device_malloc_big(&slab, each * TSDF_SCRATCHES) != hipSuccess) return set_err(TL3D_E_NOMEM, "TSDF scratch alloc (%zu B) failed", each * TSDF_SCRATCHES);
             ctx->tsdf_scratch_slab = slab;
             size_t zoff = 0, zbytes = 0;
             tsdf_batch_scratch_zero_range(ctx->cam, g, ctx->tsdf_batch, &zoff, &zbytes);
@@ -353,7 +366,7 @@ static int alloc_grid(tl3d_ctx *ctx, const tl3d_config *cfg) {
             ctx->centroid = (unsigned long long *)cfg->ext_centroid;
         } else {
             const size_t pool_b = (size_t)g.cen_cap << 14;
-            if (hipMalloc(&ctx->centroid, pool_b) != hipSuccess) return set_err(TL3D_E_NOMEM, "centroid record pool alloc (%zu B) failed", pool_b);
+            if (device_malloc_big((void **)&ctx->centroid, pool_b) != hipSuccess) return set_err(TL3D_E_NOMEM, "centroid record pool alloc (%zu B) failed", pool_b);
             ctx->own_centroid = true;
             if (hipMemsetAsync(ctx->centroid, 0, pool_b, ctx->stream) != hipSuccess) return set_err(TL3D_E_HIP, "memset failed");
         }
@@ -441,7 +454,9 @@ int tl3d_create(const tl3d_config *cfg, int device, tl3d_ctx **out) {
             fp.remaining = cfg->n_slots;
             fp.max_slabs = (cfg->n_slots + FRAME_SLAB_BLOCKS - 1) / FRAME_SLAB_BLOCKS;
             fp.slabs = (void **)calloc((size_t)fp.max_slabs, sizeof(void *));
-            if (!fp.slabs) { (void)tl3d_destroy(ctx); return set_err(TL3D_E_NOMEM, "host allocation failed"); }
+            fp.slab_bytes = (size_t *)calloc((size_t)fp.max_slabs, sizeof(size_t));
+            fp.device = device;
+            if (!fp.slabs || !fp.slab_bytes) { (void)tl3d_destroy(ctx); return set_err(TL3D_E_NOMEM, "host allocation failed"); }
         }
     }
 
@@ -488,12 +503,61 @@ int tl3d_create(const tl3d_config *cfg, int device, tl3d_ctx **out) {
 
 // One block of a frame pool (nullptr when the device is out of memory).  A slab is sized for the slots still without a
 // buffer of this kind, at most FRAME_SLAB_BLOCKS of them, so a context never holds more than it was created for.
+// Frame slabs outlive their context in a PROCESS-WIDE CACHE (by device and size): a process that reconstructs one sequence after
+// another creates a context per sequence, and memory the driver has just taken back comes out of hipMalloc at ~26 GB/s -- the
+// second reconstruct() of a 1000-frame 720p sequence spent 0.7 s re-allocating the 25 GB its predecessor had freed, five times its
+// whole first run (tools/run_config.py --config 4, round 4).  A released slab is kept (nothing on the device refers to it any
+// more: tl3d_destroy has waited for the device) and handed to the next pool that asks for exactly that size; at most
+// SLAB_CACHE_LIMIT bytes stay cached, the rest is freed at once; tl3d_release_cached_memory() frees everything (a host that
+// shares the GPU with another allocator calls it when it is done with a batch of sequences).
+namespace {
+struct CachedSlab { int device; size_t bytes; void *p; };
+std::mutex g_slab_mutex;
+std::vector<CachedSlab> g_slab_cache;
+size_t g_slab_cached = 0;
+constexpr size_t SLAB_CACHE_LIMIT = (size_t)64 << 30;
+
+void *slab_alloc(int device, size_t bytes) {
+    {
+        std::lock_guard<std::mutex> lk(g_slab_mutex);
+        for (size_t i = g_slab_cache.size(); i-- > 0;)
+            if (g_slab_cache[i].device == device && g_slab_cache[i].bytes == bytes) {
+                void *p = g_slab_cache[i].p;
+                g_slab_cached -= bytes;
+                g_slab_cache.erase(g_slab_cache.begin() + (long)i);
+                return p;
+            }
+    }
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes) == hipSuccess) return p;
+    (void)hipGetLastError();
+    // out of memory with slabs of other sizes in the cache: give them back and try once more
+    if (tl3d_release_cached_memory() == TL3D_OK && hipMalloc(&p, bytes) == hipSuccess) return p;
+    (void)hipGetLastError();
+    return nullptr;
+}
+
+void slab_free(int device, size_t bytes, void *p) {
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(g_slab_mutex);
+        if (g_slab_cached + bytes <= SLAB_CACHE_LIMIT) {
+            g_slab_cache.push_back({device, bytes, p});
+            g_slab_cached += bytes;
+            return;
+        }
+    }
+    (void)hipFree(p);
+}
+}  // namespace
+
 static void *pool_take(FramePool &fp) {
     if (fp.cur_left == 0) {
         if (fp.remaining <= 0 || fp.n_slabs >= fp.max_slabs) return nullptr;
         const int nb = fp.remaining < FRAME_SLAB_BLOCKS ? fp.remaining : FRAME_SLAB_BLOCKS;
-        void *p = nullptr;
-        if (hipMalloc(&p, fp.block * (size_t)nb) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        void *p = slab_alloc(fp.device, fp.block * (size_t)nb);
+        if (!p) return nullptr;
+        fp.slab_bytes[fp.n_slabs] = fp.block * (size_t)nb;
         fp.slabs[fp.n_slabs++] = p;
         fp.cur = (char *)p;
         fp.cur_left = nb;
@@ -505,11 +569,31 @@ static void *pool_take(FramePool &fp) {
     return out;
 }
 
+// (the caller has waited for the device: nothing in flight refers to the slabs)
 static void pool_release(FramePool &fp) {
-    for (int i = 0; i < fp.n_slabs; ++i) (void)hipFree(fp.slabs[i]);
+    for (int i = 0; i < fp.n_slabs; ++i) slab_free(fp.device, fp.slab_bytes[i], fp.slabs[i]);
     free(fp.slabs);
+    free(fp.slab_bytes);
     fp.slabs = nullptr;
+    fp.slab_bytes = nullptr;
     fp.n_slabs = fp.max_slabs = 0;
+}
+
+int tl3d_release_cached_memory(void) {
+    std::vector<CachedSlab> take;
+    {
+        std::lock_guard<std::mutex> lk(g_slab_mutex);
+        take.swap(g_slab_cache);
+        g_slab_cached = 0;
+    }
+    int dev0 = -1;
+    (void)hipGetDevice(&dev0);
+    for (const CachedSlab &c : take) {
+        (void)hipSetDevice(c.device);
+        (void)hipFree(c.p);
+    }
+    if (dev0 >= 0) (void)hipSetDevice(dev0);
+    return TL3D_OK;
 }
 
 int tl3d_destroy(tl3d_ctx *ctx) {
@@ -517,6 +601,7 @@ int tl3d_destroy(tl3d_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)flush_updates(ctx);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    (void)hipDeviceSynchronize();                           // the frame slabs go to the process-wide cache, not back to the driver: nothing may still read them
     if (ctx->slots) {
         for (int i = 0; i < ctx->cfg.n_slots; ++i) {
             if (ctx->slots[i].ev_upload) (void)hipEventDestroy(ctx->slots[i].ev_upload);

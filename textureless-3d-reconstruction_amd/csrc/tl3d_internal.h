@@ -133,7 +133,9 @@ struct FramePool {
     char *cur = nullptr;          // next free block of the newest slab
     int cur_left = 0;
     void **slabs = nullptr;       // [max_slabs]
+    size_t *slab_bytes = nullptr; // [max_slabs] size of each slab (they go back to the process-wide slab cache by size)
     int n_slabs = 0, max_slabs = 0;
+    int device = 0;
 };
 
 struct Slot {

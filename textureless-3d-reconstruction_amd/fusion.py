@@ -132,6 +132,13 @@ class PinnedCache:
                     pass
 
 
+def release_cached_memory():
+    """Return what the library keeps between contexts to the system: the device frame slabs of destroyed contexts
+    (tl3d_release_cached_memory) and the page-locked staging buffers of closed prefetchers (PinnedCache)."""
+    PinnedCache.clear()
+    abi.check(abi.load().tl3d_release_cached_memory())
+
+
 # numpy images of tl3d_icp_pair / tl3d_icp_result (include/tl3d.h; sizes checked against the ctypes structures at import)
 _ICP_PAIR_DT = np.dtype([("slot_src", "<i4"), ("slot_tgt", "<i4"), ("scale_src", "<f8"), ("T_init", "<f8", (16,))])
 _ICP_RESULT_DT = np.dtype([("T", "<f8", (16,)), ("fitness", "<f8"), ("rmse", "<f8"), ("n_corr", "<i8"), ("n_src", "<i8"),

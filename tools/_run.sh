@@ -1,9 +1,7 @@
 cd $GRAFT_REPO_ROOT
-for rep in 1 2 3; do
-for lib in libtl3d_prev.so libtl3d.so; do
-  TL3D_LIB=$PWD/textureless-3d-reconstruction_amd/$lib timeout -k 5 120 python3 bench.py --no-cpu-baseline --no-rows --no-single --steps 8 2>/dev/null | python3 -c "
+timeout -k 10 200 python -m pytest tests -m gpu -x -q -k "frame_slabs" 2>&1 | tail -5
+for c in 4 3 2; do
+timeout -k 10 280 python tools/run_config.py --config $c --out gpurun_out/r04c_config_runs.jsonl 2>/dev/null | python3 -c "
 import json,sys
-j=json.loads(sys.stdin.read()); r=j['roofline']; print('$lib', round(j['value']), 'f/s  update', r['us_per_frame'], 'us/frame  frac', r['frac'], ' all', round(1e3*r['ms_per_frame_all_kernels'],2))" >> gpurun_out/r04_order_ab.txt
-done; done
-cat gpurun_out/r04_order_ab.txt
-timeout -k 10 400 python -m pytest tests -m gpu -x -q -k "tsdf or batch or headline or sparse or fusion or config5" 2>&1 | tail -2
+d=json.loads(sys.stdin.read().strip().split(chr(10))[-1]); print('config $c: first', d['first_call_in_process']['reconstruct_s'], d['first_call_in_process']['stage_s'], 'second', d['second_call_in_process']['reconstruct_s'], d['second_call_in_process']['stage_s'])"
+done
