@@ -614,6 +614,37 @@ def test_icp_batch_matches_oracle_and_the_per_level_calls():
     assert np.linalg.norm(got[0]["T"] - ores["T"]) <= 1e-9 and got[0]["iters_run"] == ores["iters_run"] and got[0]["n_src"] == ores["n_src"]
 
 
+def test_batched_registration_is_bitwise_repeatable_poses_and_statistics():
+    """The same batch launched again gives the same bits: poses AND the statistics the host reads afterwards (rmse, fitness,
+    correspondences).  The statistics of a batch's LAST pairs used to differ from run to run with identical poses: the sums of
+    consecutive passes of a pair are written by different workgroups (different XCDs), and as plain stores the line of the
+    last-but-one pass could be written back after the final pass's when the launch ended (they are write-through now)."""
+    from tl3d import synth
+    W, H = 540, 960
+    cam = dict(width=W, height=H, fx=859.5, fy=859.5, cx=270.0, cy=480.0)
+    scene = synth.object_scene(with_room=True)
+    n = 25
+    poses = synth.orbit_poses(n, 1.0, 0.7)
+    with tl3d.FusionContext(W, H, cam["fx"], cam["fy"], cam["cx"], cam["cy"], n_slots=n, grid=None) as ctx:
+        for i, p in enumerate(poses):
+            ctx.upload(i, synth.render(scene, p, want_color=False, **cam)[0], None)
+        ctx.set_normal_smoothing(1)
+        for i in range(n):
+            ctx.build_normals(i)
+        pairs = [(i - 1, i) for i in range(1, n)]
+        for levels in ([dict(iters=10, stride=4, max_dist=0.05, eps=0.0)],
+                       [dict(iters=10, stride=4, max_dist=0.2, eps=1e-7), dict(iters=15, stride=2, max_dist=0.05, eps=1e-7)]):
+            ref = None
+            for _ in range(8):
+                res = ctx.icp_batch(pairs, levels)
+                now = (np.stack([r["T"] for r in res]),
+                       np.array([[r["rmse"], r["fitness"], r["n_corr"], r["n_src"], r["iters_run"], r["status"]] for r in res]))
+                if ref is None:
+                    ref = now
+                assert np.array_equal(now[0], ref[0]) and np.array_equal(now[1], ref[1])
+        assert ctx.stats()["icp_batch_timeouts"] == 0
+
+
 def test_brick_merge_sends_free_space_as_counts_and_records_only_where_there_are_records():
     """The device form of the multi-GPU merge (tl3d.distributed.allreduce_context_grids) on one rank (gloo, world size 1: every
     sum is the identity, so the grid must come out as the oracle's bit for bit): the pending free-space counts are summed as 4 bytes

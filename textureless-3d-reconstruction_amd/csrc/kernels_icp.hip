@@ -717,7 +717,7 @@ __device__ __forceinline__ int icp_finish(const double *slab, int nblocks, IcpSt
         double s = 0.0;
         for (int b = 0; b < nblocks; ++b) s += __hip_atomic_load(slab + (size_t)b * ICP_SLAB + 32 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         sums[32 + t] = s;
-        state->sums[32 + t] = s;
+        st_agent(&state->sums[32 + t], s);                 // write-through, as every state word: see the note at sums[t] below
     }
     __syncthreads();
     if (t < 32) {
@@ -725,7 +725,13 @@ __device__ __forceinline__ int icp_finish(const double *slab, int nblocks, IcpSt
 #pragma unroll
         for (int g = 1; g < 8; ++g) s += part[g][t];
         sums[t] = s;
-        state->sums[t] = s;
+        // WRITE-THROUGH (agent scope), not a plain store: in a batched launch the sums of consecutive passes of one pair are written
+        // by different workgroups, i.e. from different XCDs, and a plain store sits in its XCD's L2 until that writes it back --
+        // the line of pass n - 1 could reach memory AFTER the line of the final pass (both flushed at the end of the launch, in no
+        // order): the statistics the host read (rmse, fitness, correspondences) were then those of the last-but-one pose.  Seen as
+        // run-to-run differences of rmse / n_corr of the LAST pairs of a batch with bit-identical poses (tools/bench_icp.py, round 4);
+        // the pose words have always been written through.
+        st_agent(&state->sums[t], s);
     }
     __syncthreads();
     if (final_pass || t >= 64) return 0;                   // wave 0 solves

@@ -65,10 +65,21 @@ for radius in [int(x) for x in args.radius.split(",")]:
         res = ctx.icp_batch(pairs, levels, T_init=init)
         ctx.sync()
         ts = []
+        ref_T = np.stack([r["T"] for r in res])
+        ref_stats = np.array([[r["rmse"], r["fitness"], r["n_corr"], r["n_src"], r["iters_run"], r["status"]] for r in res])
+        mismatches = 0
+        stat_mismatches = 0
+        worst = None
         for _ in range(args.reps):
             t0 = time.perf_counter()
             res = ctx.icp_batch(pairs, levels, T_init=init)
             ts.append(time.perf_counter() - t0)
+            mismatches += int(not np.array_equal(np.stack([r["T"] for r in res]), ref_T))      # every launch must give the same bits
+            st_now = np.array([[r["rmse"], r["fitness"], r["n_corr"], r["n_src"], r["iters_run"], r["status"]] for r in res])
+            if not np.array_equal(st_now, ref_stats):
+                stat_mismatches += 1
+                bad = np.nonzero(np.any(st_now != ref_stats, axis=1))[0]
+                worst = dict(pairs=bad[:8].tolist(), now=st_now[bad[0]].tolist(), first=ref_stats[bad[0]].tolist())
         t = sorted(ts)[len(ts) // 2]
         key = f"radius {radius}, {name}"
         row = dict(pairs_per_s=round(len(pairs) / t, 1), ms=round(1e3 * t, 3))
@@ -77,6 +88,10 @@ for radius in [int(x) for x in args.radius.split(",")]:
         row["rmse_mean"] = float(np.mean([r["rmse"] for r in res]))
         row["iters_mean"] = float(np.mean([r["iters_run"] for r in res]))
         row["T_digest"] = float(np.sum([np.abs(r["T"]).sum() for r in res]))
+        row["launches_differing_from_the_first"] = mismatches
+        row["launches_with_other_statistics"] = stat_mismatches
+        if worst:
+            row["example"] = worst
         out[key] = row
         print(f"{key:44s} {row}", flush=True)
 out["stats"] = {k: v for k, v in ctx.stats().items() if k.startswith("icp")}
