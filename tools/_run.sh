@@ -1,6 +1,7 @@
 cd $GRAFT_REPO_ROOT
-export TMPDIR=/tmp
-timeout -k 10 300 python bench.py > gpurun_out/r04_final2_bench.json 2> gpurun_out/r04_final2_bench.err; echo "bench rc=$?"
-timeout -k 5 200 python3 tools/bench_icp.py --json gpurun_out/r04d_bench_icp.json > gpurun_out/r04d_bench_icp.txt 2>&1; echo "bench_icp rc=$?"
-bash tools/pmc_icp.sh r04d > gpurun_out/pmc_icp_r04d.log 2>&1; echo "pmc_icp rc=$?"
-timeout -k 5 100 python tools/bench_bp.py 2>&1 | grep -v amdgpu > gpurun_out/r04d_bench_bp.txt
+: > gpurun_out/r04f_config_runs.jsonl
+for c in 2 3 4 4b; do
+timeout -k 10 280 python tools/run_config.py --config $c --out gpurun_out/r04f_config_runs.jsonl 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().split(chr(10))[-1]); print('config $c:', d['frames_per_s_whole_pipeline'], 'f/s; calls', d['first_call_in_process']['reconstruct_s'], d['second_call_in_process']['reconstruct_s'], d['third_call_in_process']['reconstruct_s'], d['stage_s'])"
+done

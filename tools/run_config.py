@@ -122,15 +122,25 @@ def main():
     with contextlib.redirect_stdout(log):
         pts, col, est = pipe.reconstruct()
     t_rec = time.perf_counter() - t0
+    second_timings = pipe.timings
+    # ... and a third time (the second call still pays for what the first context's destruction left to do: its buffers return to
+    # the library's caches while the second context is being built)
+    pipe = DepthToReconstructionPipeline(cfg)
+    pipe.set_frames(images, depths)
+    t0 = time.perf_counter()
+    with contextlib.redirect_stdout(log):
+        pts, col, est = pipe.reconstruct()
+    t_third = time.perf_counter() - t0
     occupancy = [l.strip() for l in log.getvalue().splitlines() if "Occupancy" in l][-1:]
     # (the second call is not always the faster one: with 1000 resident 720p frames it re-allocates 25 GB the first context has
     # just freed, and the driver hands such memory back at ~26 GB/s -- config 4's second registration stage takes 0.7 s for that
     # reason alone; both calls are in the record, the headline figure is the better of the two)
     out = dict(config=name, frames=n, width=W, height=H, valid_pixel_fraction=round(valid_frac, 3), render_s=round(t_render, 1),
-               reconstruct_s=round(min(t_rec, t_first), 3), frames_per_s_whole_pipeline=round(n / min(t_rec, t_first), 1),
-               stage_s=pipe.timings if t_rec <= t_first else first_timings,
+               reconstruct_s=round(min(t_rec, t_first, t_third), 3), frames_per_s_whole_pipeline=round(n / min(t_rec, t_first, t_third), 1),
+               stage_s=pipe.timings if t_third <= min(t_rec, t_first) else (second_timings if t_rec <= t_first else first_timings),
                first_call_in_process=dict(reconstruct_s=round(t_first, 3), frames_per_s=round(n / t_first, 1), stage_s=first_timings),
-               second_call_in_process=dict(reconstruct_s=round(t_rec, 3), frames_per_s=round(n / t_rec, 1), stage_s=pipe.timings),
+               second_call_in_process=dict(reconstruct_s=round(t_rec, 3), frames_per_s=round(n / t_rec, 1), stage_s=second_timings),
+               third_call_in_process=dict(reconstruct_s=round(t_third, 3), frames_per_s=round(n / t_third, 1), stage_s=pipe.timings),
                layout=occupancy[0] if occupancy else "dense without asking (small grid)")
     if pts is None:
         out["error"] = "reconstruction failed"
